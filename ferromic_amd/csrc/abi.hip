@@ -1,0 +1,745 @@
+// abi.hip — implementation of include/ferromic_hip.h: device memory, layout conversion, kernel
+// dispatch and totals collection.  No CPU compute path exists here: without a GPU every entry
+// point fails with FMH_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ferromic_hip.h"
+#include "sweep_kernels.hpp"
+
+using namespace fmh;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(_e == hipErrorNoDevice ? FMH_ERR_NO_DEVICE : FMH_ERR_HIP, "%s: %s (%s:%d)", \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                         \
+  } while (0)
+
+#define FMH_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != FMH_OK) return _s; \
+  } while (0)
+
+extern "C" const char* fmh_last_error(void) { return g_last_error.c_str(); }
+extern "C" int fmh_abi_version(void) { return FMH_ABI_VERSION; }
+
+static int device_count_checked(int* n) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c <= 0) {
+    *n = 0;
+    return fail(FMH_ERR_NO_DEVICE, "no HIP device available (%s); libferromic_hip has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  }
+  *n = c;
+  return FMH_OK;
+}
+
+extern "C" int fmh_device_count(int* h_count) {
+  if (!h_count) return fail(FMH_ERR_INVALID, "h_count is NULL");
+  return device_count_checked(h_count);
+}
+
+static int use_device(int device) {
+  int n = 0;
+  FMH_TRY(device_count_checked(&n));
+  if (device < 0 || device >= n) return fail(FMH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  return FMH_OK;
+}
+
+extern "C" int fmh_device_info(int device, char* h_name, size_t name_cap, int* h_cus, uint64_t* h_mem) {
+  FMH_TRY(use_device(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (h_name && name_cap) snprintf(h_name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  if (h_cus) *h_cus = prop.multiProcessorCount;
+  if (h_mem) *h_mem = (uint64_t)prop.totalGlobalMem;
+  return FMH_OK;
+}
+
+extern "C" int fmh_device_alloc(int device, size_t bytes, void** d_out) {
+  if (!d_out) return fail(FMH_ERR_INVALID, "d_out is NULL");
+  FMH_TRY(use_device(device));
+  HIP_TRY(hipMalloc(d_out, bytes ? bytes : 16));
+  return FMH_OK;
+}
+extern "C" int fmh_device_free(int device, void* d_ptr) {
+  FMH_TRY(use_device(device));
+  HIP_TRY(hipFree(d_ptr));
+  return FMH_OK;
+}
+extern "C" int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream) {
+  FMH_TRY(use_device(device));
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return FMH_OK;
+}
+extern "C" int fmh_copy_to_device(int device, void* d_dst, const void* h_src, size_t bytes, void* stream) {
+  FMH_TRY(use_device(device));
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return FMH_OK;
+}
+extern "C" int fmh_stream_synchronize(int device, void* stream) {
+  FMH_TRY(use_device(device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return FMH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct fmh_matrix {
+  int device = 0;
+  uint8_t* data = nullptr;
+  uint8_t* bits = nullptr;  // called bit-rows or null
+  size_t pitch = 0, bits_pitch = 0;
+  size_t variants = 0, samples = 0, ploidy = 0;
+  uint32_t columns = 0, nvec = 0;
+  uint8_t max_allele = 0;
+  bool owns = true;
+};
+
+struct fmh_groups {
+  int device = 0;
+  int n_groups = 0;   // caller's P
+  int padded = 0;     // kernel P (1, 2, 4 or 8)
+  uint8_t* masks = nullptr;  // [padded][pitch]
+  size_t pitch = 0;
+  uint32_t columns = 0;
+  uint64_t sizes[FMH_MAX_GROUPS] = {0};
+};
+
+static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int check_dims(size_t variants, size_t samples, size_t ploidy) {
+  if (ploidy == 0 || samples == 0) return fail(FMH_ERR_INVALID, "samples and ploidy must be positive");
+  const unsigned long long cols = (unsigned long long)samples * ploidy;
+  if (cols > 0x7FFFFFF0ull) return fail(FMH_ERR_INVALID, "samples*ploidy = %llu too large", cols);
+  (void)variants;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, int with_missing,
+                                uint8_t max_allele, int device, fmh_matrix** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMH_TRY(check_dims(variants, samples, ploidy));
+  FMH_TRY(use_device(device));
+  fmh_matrix* m = new fmh_matrix();
+  m->device = device;
+  m->variants = variants;
+  m->samples = samples;
+  m->ploidy = ploidy;
+  m->columns = (uint32_t)(samples * ploidy);
+  m->pitch = round_up(m->columns, 16);
+  m->nvec = (uint32_t)(m->pitch / 16);
+  m->bits_pitch = with_missing ? round_up(m->pitch / 8, 4) : 0;
+  m->max_allele = max_allele;
+  const size_t bytes = variants * m->pitch;
+  hipError_t e = hipMalloc((void**)&m->data, bytes ? bytes : 16);
+  if (e == hipSuccess && with_missing) {
+    const size_t bb = variants * m->bits_pitch;
+    e = hipMalloc((void**)&m->bits, bb ? bb : 16);
+  }
+  if (e != hipSuccess) {
+    if (m->data) (void)hipFree(m->data);
+    delete m;
+    return fail(FMH_ERR_HIP, "hipMalloc of %zu-byte matrix failed: %s", bytes, hipGetErrorString(e));
+  }
+  *out = m;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing, size_t variants, size_t samples,
+                                 size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  if (!h_data && variants) return fail(FMH_ERR_INVALID, "h_data is NULL");
+  FMH_TRY(fmh_matrix_alloc(variants, samples, ploidy, h_missing != nullptr, max_allele, device, out));
+  fmh_matrix* m = *out;
+  auto bail = [&](int code) { fmh_matrix_destroy(m); *out = nullptr; return code; };
+  if (variants == 0) return FMH_OK;
+  // zero the padding columns, then a pitched copy of the packed rows
+  hipError_t e = hipMemset(m->data, 0, variants * m->pitch);
+  if (e == hipSuccess)
+    e = hipMemcpy2D(m->data, m->pitch, h_data, m->columns, m->columns, variants, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "matrix upload failed: %s", hipGetErrorString(e)));
+  if (h_missing) {
+    const size_t words = (variants * (size_t)m->columns + 63) / 64;
+    unsigned long long* d_words = nullptr;
+    e = hipMalloc((void**)&d_words, words * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_words, h_missing, words * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      const size_t total = variants * m->bits_pitch;
+      const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+      hipLaunchKernelGGL(missing_to_called_rows, dim3(blocks), dim3(256), 0, 0, d_words, variants, m->columns,
+                         m->bits, m->bits_pitch);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (d_words) (void)hipFree(d_words);
+    if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "missing-mask upload failed: %s", hipGetErrorString(e)));
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_bits, size_t bits_pitch, size_t variants,
+                               size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMH_TRY(check_dims(variants, samples, ploidy));
+  FMH_TRY(use_device(device));
+  const size_t cols = samples * ploidy;
+  if (!d_data) return fail(FMH_ERR_INVALID, "d_data is NULL");
+  if (pitch % 16 != 0 || pitch < cols) return fail(FMH_ERR_INVALID, "pitch %zu must be a multiple of 16 and >= %zu", pitch, cols);
+  if (((uintptr_t)d_data) % 16 != 0) return fail(FMH_ERR_INVALID, "d_data must be 16-byte aligned");
+  if (d_bits && (bits_pitch % 2 != 0 || bits_pitch * 8 < round_up(cols, 16)))
+    return fail(FMH_ERR_INVALID, "bits_pitch %zu too small or odd", bits_pitch);
+  fmh_matrix* m = new fmh_matrix();
+  m->device = device;
+  m->data = (uint8_t*)d_data;
+  m->bits = (uint8_t*)d_bits;
+  m->pitch = pitch;
+  m->bits_pitch = d_bits ? bits_pitch : 0;
+  m->variants = variants;
+  m->samples = samples;
+  m->ploidy = ploidy;
+  m->columns = (uint32_t)cols;
+  m->nvec = (uint32_t)(round_up(cols, 16) / 16);
+  m->max_allele = max_allele;
+  m->owns = false;
+  *out = m;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_destroy(fmh_matrix* m) {
+  if (!m) return FMH_OK;
+  if (m->owns) {
+    (void)hipSetDevice(m->device);
+    if (m->data) (void)hipFree(m->data);
+    if (m->bits) (void)hipFree(m->bits);
+  }
+  delete m;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_info(const fmh_matrix* m, size_t* variants, size_t* samples, size_t* ploidy, size_t* pitch,
+                               size_t* bits_pitch, int* has_missing, uint8_t* max_allele, int* device) {
+  if (!m) return fail(FMH_ERR_INVALID, "matrix is NULL");
+  if (variants) *variants = m->variants;
+  if (samples) *samples = m->samples;
+  if (ploidy) *ploidy = m->ploidy;
+  if (pitch) *pitch = m->pitch;
+  if (bits_pitch) *bits_pitch = m->bits_pitch;
+  if (has_missing) *has_missing = m->bits != nullptr;
+  if (max_allele) *max_allele = m->max_allele;
+  if (device) *device = m->device;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_device_ptrs(const fmh_matrix* m, void** d_data, void** d_bits) {
+  if (!m) return fail(FMH_ERR_INVALID, "matrix is NULL");
+  if (d_data) *d_data = m->data;
+  if (d_bits) *d_bits = m->bits;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_download(const fmh_matrix* m, uint8_t* h_data, uint64_t* h_missing) {
+  if (!m) return fail(FMH_ERR_INVALID, "matrix is NULL");
+  if (!h_data) return fail(FMH_ERR_INVALID, "h_data is NULL");
+  FMH_TRY(use_device(m->device));
+  if (m->variants == 0) return FMH_OK;
+  HIP_TRY(hipMemcpy2D(h_data, m->columns, m->data, m->pitch, m->columns, m->variants, hipMemcpyDeviceToHost));
+  if (m->bits) {
+    if (!h_missing) return fail(FMH_ERR_INVALID, "matrix has a missing mask but h_missing is NULL");
+    const size_t words = (m->variants * (size_t)m->columns + 63) / 64;
+    unsigned long long* d_words = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_words, words * 8));
+    const int blocks = (int)std::min<size_t>((words + 255) / 256, 65535);
+    hipLaunchKernelGGL(called_rows_to_missing, dim3(blocks), dim3(256), 0, 0, m->bits, m->bits_pitch, m->variants,
+                       m->columns, d_words, words);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h_missing, d_words, words * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_words);
+    if (e != hipSuccess) return fail(FMH_ERR_HIP, "missing-mask download failed: %s", hipGetErrorString(e));
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_scan_max_allele(const fmh_matrix* m, uint8_t* h_max, void* stream) {
+  if (!m || !h_max) return fail(FMH_ERR_INVALID, "NULL argument");
+  FMH_TRY(use_device(m->device));
+  unsigned int* d_out = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_out, 4));
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_out, 0, 4, st);
+  unsigned int host = 0;
+  if (e == hipSuccess && m->variants) {
+    const size_t total = m->variants * (size_t)m->columns;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(max_allele_kernel, dim3(blocks), dim3(256), 0, st, m->data, m->pitch, m->bits, m->bits_pitch,
+                       m->variants, m->columns, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&host, d_out, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(FMH_ERR_HIP, "max-allele scan failed: %s", hipGetErrorString(e));
+  *h_max = (uint8_t)host;
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_generate(fmh_matrix* m, uint64_t seed, uint64_t first_site, const uint32_t* h_thr,
+                                   const uint8_t* h_pop_of_column, int n_pops, uint32_t missing_thr, void* stream) {
+  if (!m || !h_thr || !h_pop_of_column) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n_pops < 1 || n_pops > 255) return fail(FMH_ERR_INVALID, "n_pops out of range");
+  for (uint32_t h = 0; h < m->columns; ++h)
+    if (h_pop_of_column[h] >= n_pops) return fail(FMH_ERR_INVALID, "pop_of_column[%u] = %u >= n_pops", h, h_pop_of_column[h]);
+  if (missing_thr && !m->bits) return fail(FMH_ERR_INVALID, "missing_threshold set but the matrix has no mask");
+  FMH_TRY(use_device(m->device));
+  if (m->variants == 0) return FMH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* d_thr = nullptr;
+  uint8_t* d_pop = nullptr;
+  const size_t thr_bytes = (size_t)n_pops * m->variants * 4;
+  HIP_TRY(hipMalloc((void**)&d_thr, thr_bytes));
+  hipError_t e = hipMalloc((void**)&d_pop, m->columns);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_thr, h_thr, thr_bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pop, h_pop_of_column, m->columns, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    const size_t total = m->variants * (m->pitch / 16);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(generate_kernel, dim3(blocks), dim3(256), 0, st, m->data, m->pitch, m->bits, m->bits_pitch,
+                       m->variants, m->columns, m->nvec, seed, first_site, d_thr, d_pop, missing_thr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_thr);
+  if (d_pop) (void)hipFree(d_pop);
+  if (e != hipSuccess) return fail(FMH_ERR_HIP, "generate failed: %s", hipGetErrorString(e));
+  if (m->max_allele < 1) m->max_allele = 1;
+  return FMH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// groups
+// ------------------------------------------------------------------------------------------------
+static int padded_groups(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
+
+extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int n_groups, fmh_groups** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!m || !h_mask) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n_groups < 1 || n_groups > FMH_MAX_GROUPS) return fail(FMH_ERR_INVALID, "n_groups %d out of range 1..%d", n_groups, FMH_MAX_GROUPS);
+  FMH_TRY(use_device(m->device));
+  fmh_groups* g = new fmh_groups();
+  g->device = m->device;
+  g->n_groups = n_groups;
+  g->padded = padded_groups(n_groups);
+  g->pitch = m->pitch;
+  g->columns = m->columns;
+  std::vector<uint8_t> staged((size_t)g->padded * g->pitch, 0);
+  for (int p = 0; p < n_groups; ++p) {
+    uint64_t cnt = 0;
+    for (uint32_t h = 0; h < m->columns; ++h) {
+      const uint8_t v = h_mask[(size_t)p * m->columns + h] ? 1 : 0;
+      staged[(size_t)p * g->pitch + h] = v;
+      cnt += v;
+    }
+    g->sizes[p] = cnt;
+  }
+  hipError_t e = hipMalloc((void**)&g->masks, staged.size());
+  if (e == hipSuccess) e = hipMemcpy(g->masks, staged.data(), staged.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (g->masks) (void)hipFree(g->masks);
+    delete g;
+    return fail(FMH_ERR_HIP, "group mask upload failed: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return FMH_OK;
+}
+
+extern "C" int fmh_groups_destroy(fmh_groups* g) {
+  if (!g) return FMH_OK;
+  (void)hipSetDevice(g->device);
+  if (g->masks) (void)hipFree(g->masks);
+  delete g;
+  return FMH_OK;
+}
+
+extern "C" int fmh_groups_sizes(const fmh_groups* g, int* n_groups, uint64_t* h_sizes) {
+  if (!g) return fail(FMH_ERR_INVALID, "groups is NULL");
+  if (n_groups) *n_groups = g->n_groups;
+  if (h_sizes) for (int p = 0; p < g->n_groups; ++p) h_sizes[p] = g->sizes[p];
+  return FMH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-device workspace: block partials, totals, harmonic table, timing events
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+  bool ready = false;
+  int cus = 0;
+  int max_grid = 0;
+  double* part_f64 = nullptr;
+  unsigned long long* part_u64 = nullptr;
+  double* out_f64 = nullptr;
+  unsigned long long* out_u64 = nullptr;
+  double* h_f64 = nullptr;  // pinned
+  unsigned long long* h_u64 = nullptr;
+  double* harmonic = nullptr;
+  size_t harmonic_len = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+static Workspace g_ws[64];
+static std::mutex g_ws_mutex;
+static bool g_timing = false;
+static double g_timing_ms = 0.0;
+static uint64_t g_timing_launches = 0;
+
+static int workspace(int device, Workspace** out) {
+  if (device < 0 || device >= 64) return fail(FMH_ERR_INVALID, "device index %d unsupported", device);
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  Workspace& w = g_ws[device];
+  if (!w.ready) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    w.cus = prop.multiProcessorCount;
+    w.max_grid = w.cus * 8;
+    HIP_TRY(hipMalloc((void**)&w.part_f64, (size_t)w.max_grid * kMaxF64 * 8));
+    HIP_TRY(hipMalloc((void**)&w.part_u64, (size_t)w.max_grid * kMaxU64 * 8));
+    HIP_TRY(hipMalloc((void**)&w.out_f64, kMaxF64 * 8));
+    HIP_TRY(hipMalloc((void**)&w.out_u64, kMaxU64 * 8));
+    HIP_TRY(hipHostMalloc((void**)&w.h_f64, kMaxF64 * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&w.h_u64, kMaxU64 * 8, hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&w.ev0));
+    HIP_TRY(hipEventCreate(&w.ev1));
+    w.ready = true;
+  }
+  *out = &w;
+  return FMH_OK;
+}
+
+// H_k = sum_{i=1..k} 1/i summed ascending (harmonic(), stats.rs:4234-4240); table index k.
+static int ensure_harmonic(Workspace* w, size_t max_k, hipStream_t st) {
+  if (w->harmonic && w->harmonic_len > max_k) return FMH_OK;
+  std::vector<double> table(max_k + 2);
+  double sum = 0.0;
+  table[0] = 0.0;
+  for (size_t k = 1; k < table.size(); ++k) {
+    sum += 1.0 / (double)k;
+    table[k] = sum;
+  }
+  if (w->harmonic) HIP_TRY(hipFree(w->harmonic));
+  w->harmonic = nullptr;
+  HIP_TRY(hipMalloc((void**)&w->harmonic, table.size() * 8));
+  HIP_TRY(hipMemcpyAsync(w->harmonic, table.data(), table.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  w->harmonic_len = table.size();
+  return FMH_OK;
+}
+
+extern "C" int fmh_timing_enable(int on) { g_timing = on != 0; return FMH_OK; }
+extern "C" int fmh_timing_reset(void) { g_timing_ms = 0.0; g_timing_launches = 0; return FMH_OK; }
+extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
+  if (ms) *ms = g_timing_ms;
+  if (launches) *launches = g_timing_launches;
+  return FMH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------------------
+template <int P, int MODE, bool MISSING, bool GENERAL>
+static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStream_t st, int* grid_out) {
+  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL>;
+  static thread_local int cached_occ[64];
+  static thread_local size_t cached_smem[64];
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  if (cached_occ[dev] == 0 || cached_smem[dev] != smem) {
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, smem));
+    if (occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+    cached_occ[dev] = occ;
+    cached_smem[dev] = smem;
+  }
+  const size_t ntiles = (args.row_count + kTileRows - 1) / kTileRows;
+  size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t cap = (size_t)w->cus * cached_occ[dev];
+  if (blocks > cap) blocks = cap;
+  if (blocks > (size_t)w->max_grid) blocks = w->max_grid;
+  if (blocks < 1) blocks = 1;
+  if (g_timing) HIP_TRY(hipEventRecord(w->ev0, st));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kBlock), smem, st, args);
+  HIP_TRY(hipGetLastError());
+  if (g_timing) HIP_TRY(hipEventRecord(w->ev1, st));
+  *grid_out = (int)blocks;
+  return FMH_OK;
+}
+
+template <int P, int MODE>
+static int launch_pm(Workspace* w, const SweepArgs& a, size_t smem, hipStream_t st, bool missing, bool general, int* grid) {
+  if (missing) return general ? launch_one<P, MODE, true, true>(w, a, smem, st, grid) : launch_one<P, MODE, true, false>(w, a, smem, st, grid);
+  return general ? launch_one<P, MODE, false, true>(w, a, smem, st, grid) : launch_one<P, MODE, false, false>(w, a, smem, st, grid);
+}
+
+struct SweepResult {
+  double f64[kMaxF64];
+  unsigned long long u64[kMaxU64];
+};
+
+static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, void* stream, SweepResult* res) {
+  if (!m || !g) return fail(FMH_ERR_INVALID, "matrix or groups is NULL");
+  if (g->device != m->device || g->pitch != m->pitch || g->columns != m->columns)
+    return fail(FMH_ERR_INVALID, "groups were built for a different matrix geometry");
+  if (a.row_begin > m->variants || a.row_count > m->variants - a.row_begin)
+    return fail(FMH_ERR_INVALID, "row range [%zu, +%zu) exceeds %zu variants", a.row_begin, a.row_count, m->variants);
+  FMH_TRY(use_device(m->device));
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(m->device, &w));
+  hipStream_t st = (hipStream_t)stream;
+  a.mv.data = m->data;
+  a.mv.bits = m->bits;
+  a.mv.pitch = m->pitch;
+  a.mv.bits_pitch = m->bits_pitch;
+  a.mv.columns = m->columns;
+  a.mv.nvec = m->nvec;
+  a.masks = g->masks;
+  for (int p = 0; p < 8; ++p) a.group_size[p] = p < g->n_groups ? (uint32_t)g->sizes[p] : 0;
+  a.n_groups = g->n_groups;
+  a.max_allele = m->max_allele;
+  a.part_f64 = w->part_f64;
+  a.part_u64 = w->part_u64;
+  if (mode & kModeDiversity) {
+    FMH_TRY(ensure_harmonic(w, m->columns + 1, st));
+    a.harmonic = w->harmonic;
+  }
+  memset(res, 0, sizeof *res);
+  if (a.row_count == 0) return FMH_OK;
+  const bool missing = m->bits != nullptr;
+  const bool general = m->max_allele > 1;
+  const int P = g->padded;
+  const size_t smem = (size_t)P * m->nvec * 16;
+  if (smem > 150 * 1024) return fail(FMH_ERR_UNSUPPORTED, "P=%d masks of %u columns need %zu B of LDS (> 150 KiB)", P, m->columns, smem);
+  int grid = 0;
+  int rc = FMH_ERR_UNSUPPORTED;
+#define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
+  if (mode == kModeSummary) {
+    if (P == 1) CASE(1, kModeSummary); else if (P == 2) CASE(2, kModeSummary); else if (P == 4) CASE(4, kModeSummary); else CASE(8, kModeSummary);
+  } else if (mode == (kModeSummary | kModeHudson)) {
+    if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
+    CASE(2, kModeSummary | kModeHudson);
+  } else if (mode == (kModeSummary | kModeDiversity)) {
+    if (P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
+    CASE(1, kModeSummary | kModeDiversity);
+  } else if (mode == kModeWc) {
+    if (P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
+    if (P == 2) CASE(2, kModeWc); else if (P == 4) CASE(4, kModeWc); else CASE(8, kModeWc);
+  } else {
+    return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
+  }
+#undef CASE
+  FMH_TRY(rc);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(128), 0, st, w->part_f64, w->part_u64, grid, w->out_f64, w->out_u64);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(w->h_f64, w->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(w->h_u64, w->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  memcpy(res->f64, w->h_f64, sizeof res->f64);
+  memcpy(res->u64, w->h_u64, sizeof res->u64);
+  if (g_timing) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    g_timing_ms += ms;
+    g_timing_launches += 1;
+  }
+  return FMH_OK;
+}
+
+static void fill_pop_totals(const fmh_groups* g, const SweepResult& r, int p, fmh_pop_totals* t) {
+  t->haplotype_capacity = g->sizes[p];
+  t->segregating_sites = r.u64[kOffPopSeg + p];
+  t->uncallable_sites = r.u64[kOffPopUnc + p];
+  t->pi_sum = r.f64[kOffPopF64 + p];
+}
+
+static int check_formula(int formula) {
+  if (formula != FMH_FORMULA_SPARSE && formula != FMH_FORMULA_DENSE && formula != FMH_FORMULA_SUMMARY)
+    return fail(FMH_ERR_INVALID, "unknown formula %d", formula);
+  return FMH_OK;
+}
+
+extern "C" int fmh_population_summaries(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                        int formula, uint32_t* d_alt, uint32_t* d_called, fmh_pop_totals* h_totals,
+                                        void* stream) {
+  FMH_TRY(check_formula(formula));
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = formula;
+  a.alt = d_alt;
+  a.called = d_called;
+  SweepResult r;
+  FMH_TRY(run_sweep(m, g, kModeSummary, a, stream, &r));
+  if (h_totals) for (int p = 0; p < g->n_groups; ++p) fill_pop_totals(g, r, p, &h_totals[p]);
+  return FMH_OK;
+}
+
+extern "C" int fmh_hudson_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                int formula, const fmh_hudson_sites* sites, fmh_hudson_totals* h_totals, void* stream) {
+  FMH_TRY(check_formula(formula));
+  if (g && g->n_groups != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups, got %d", g->n_groups);
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = formula;
+  if (sites) {
+    a.fst = sites->d_fst; a.dxy = sites->d_dxy; a.pi1 = sites->d_pi1; a.pi2 = sites->d_pi2;
+    a.num = sites->d_num; a.den = sites->d_den; a.alt = sites->d_alt; a.called = sites->d_called;
+  }
+  SweepResult r;
+  FMH_TRY(run_sweep(m, g, kModeSummary | kModeHudson, a, stream, &r));
+  if (h_totals) {
+    fmh_hudson_totals* t = h_totals;
+    memset(t, 0, sizeof *t);
+    t->numerator_sum = r.f64[kOffHudF64 + 0];
+    t->denominator_sum = r.f64[kOffHudF64 + 1];
+    t->pi1_sum = r.f64[kOffHudF64 + 2];
+    t->pi2_sum = r.f64[kOffHudF64 + 3];
+    t->dxy_sum_all = r.f64[kOffHudF64 + 4];
+    t->site_num_sum = r.f64[kOffHudF64 + 5];
+    t->site_den_sum = r.f64[kOffHudF64 + 6];
+    t->site_dxy_sum = r.f64[kOffHudF64 + 7];
+    t->dxy_uncallable_sites = r.u64[kOffHudU64 + 0];
+    t->sites_with_components = r.u64[kOffHudU64 + 1];
+    t->site_dxy_skipped = r.u64[kOffHudU64 + 2];
+    fill_pop_totals(g, r, 0, &t->pop[0]);
+    fill_pop_totals(g, r, 1, &t->pop[1]);
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                   double* d_pi, double* d_theta, uint32_t* d_called, uint32_t* d_distinct,
+                                   fmh_pop_totals* h_totals, void* stream) {
+  if (g && g->n_groups != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group, got %d", g->n_groups);
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = FMH_FORMULA_SPARSE;
+  a.site_pi = d_pi;
+  a.site_theta = d_theta;
+  a.called = d_called;
+  a.site_distinct = d_distinct;
+  SweepResult r;
+  FMH_TRY(run_sweep(m, g, kModeSummary | kModeDiversity, a, stream, &r));
+  if (h_totals) fill_pop_totals(g, r, 0, h_totals);
+  return FMH_OK;
+}
+
+extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a,
+                            double* d_b, uint8_t* d_state, uint32_t* d_group_called, fmh_wc_totals* h_totals,
+                            void* stream) {
+  if (g && g->n_groups < 2) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups, got %d", g->n_groups);
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = FMH_FORMULA_SPARSE;
+  a.wc_a = d_a;
+  a.wc_b = d_b;
+  a.wc_state = d_state;
+  a.called = d_group_called;
+  // kernel slots follow the padded-P pair order; map them to the caller's G-group order
+  int slot_of[32];
+  for (int k = 0; k < 32; ++k) { a.wc_slot[k] = -1; slot_of[k] = -1; }
+  if (g) {
+    const int P = g->padded, G = g->n_groups;
+    a.wc_slot[0] = 0;
+    slot_of[0] = 0;
+    int k = 1;
+    for (int i = 0; i < P; ++i)
+      for (int j = i + 1; j < P; ++j, ++k) {
+        if (i < G && j < G) {
+          int idx = 1;
+          for (int x = 0; x < G; ++x)
+            for (int y = x + 1; y < G; ++y, ++idx)
+              if (x == i && y == j) slot_of[k] = idx;
+          a.wc_slot[k] = (int8_t)slot_of[k];
+        }
+      }
+  }
+  SweepResult r;
+  FMH_TRY(run_sweep(m, g, kModeWc, a, stream, &r));
+  if (h_totals) {
+    memset(h_totals, 0, sizeof *h_totals);
+    h_totals->sites_attempted = row_count;
+    const int P = g->padded;
+    const int nw = 1 + P * (P - 1) / 2;
+    for (int k = 0; k < nw; ++k) {
+      if (slot_of[k] < 0) continue;
+      h_totals->sum_a[slot_of[k]] = r.f64[kOffWcA + k];
+      h_totals->sum_b[slot_of[k]] = r.f64[kOffWcB + k];
+      h_totals->informative_sites[slot_of[k]] = r.u64[kOffWcInf + k];
+    }
+  }
+  return FMH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// totals packing for a single all-reduce(sum)
+// ------------------------------------------------------------------------------------------------
+extern "C" int fmh_hudson_totals_pack(const fmh_hudson_totals* t, double* f, uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  f[0] = t->numerator_sum; f[1] = t->denominator_sum; f[2] = t->pi1_sum; f[3] = t->pi2_sum;
+  f[4] = t->dxy_sum_all; f[5] = t->site_num_sum; f[6] = t->site_den_sum; f[7] = t->site_dxy_sum;
+  f[8] = t->pop[0].pi_sum; f[9] = t->pop[1].pi_sum;
+  u[0] = t->dxy_uncallable_sites; u[1] = t->sites_with_components; u[2] = t->site_dxy_skipped;
+  u[3] = t->pop[0].segregating_sites; u[4] = t->pop[0].uncallable_sites;
+  u[5] = t->pop[1].segregating_sites; u[6] = t->pop[1].uncallable_sites;
+  u[7] = t->pop[0].haplotype_capacity; u[8] = t->pop[1].haplotype_capacity;  // identical on every rank; divide after a sum
+  u[9] = 1;  // ranks summed
+  return FMH_OK;
+}
+
+extern "C" int fmh_hudson_totals_unpack(fmh_hudson_totals* t, const double* f, const uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  memset(t, 0, sizeof *t);
+  t->numerator_sum = f[0]; t->denominator_sum = f[1]; t->pi1_sum = f[2]; t->pi2_sum = f[3];
+  t->dxy_sum_all = f[4]; t->site_num_sum = f[5]; t->site_den_sum = f[6]; t->site_dxy_sum = f[7];
+  t->pop[0].pi_sum = f[8]; t->pop[1].pi_sum = f[9];
+  t->dxy_uncallable_sites = u[0]; t->sites_with_components = u[1]; t->site_dxy_skipped = u[2];
+  t->pop[0].segregating_sites = u[3]; t->pop[0].uncallable_sites = u[4];
+  t->pop[1].segregating_sites = u[5]; t->pop[1].uncallable_sites = u[6];
+  const uint64_t ranks = u[9] ? u[9] : 1;
+  t->pop[0].haplotype_capacity = u[7] / ranks;
+  t->pop[1].haplotype_capacity = u[8] / ranks;
+  return FMH_OK;
+}

@@ -1,0 +1,898 @@
+// sweep_kernels.hpp — hand-written gfx950 (CDNA4, wave64) kernels for the per-site allele-count
+// sweep and its fused statistics epilogues.  Included by abi.hip only.
+//
+// Geometry
+//   * genotype matrix: site-major u8, row pitch a multiple of 16 B, padding bytes zero;
+//     optional "called" bit-row per site (bit h set = entry h is called).
+//   * one workgroup = 4 waves; one wave owns a tile of 64 consecutive sites.  A wave is split in
+//     four 16-lane groups (one DPP row each).  Group g sweeps rows 16g .. 16g+15 of the tile, one
+//     row per step; its 16 lanes read the row as consecutive 16-byte vectors (256 B contiguous per
+//     group per load instruction, 16 B/lane), so every HBM byte is fetched exactly once, coalesced.
+//   * membership masks (0/1 bytes per column, one per population) live in LDS and are shared by
+//     all waves; counts are v_dot4_u32_u8 of genotype bytes against mask bytes.
+//   * after the 16 steps lane L of the wave holds the integer counts of row L of the tile, so the
+//     f64 statistics run on all 64 lanes at once and every per-site track is written with fully
+//     coalesced 256/512-B stores.
+//   * regional sums are kept per lane across tiles (persistent grid), reduced once per block and
+//     combined in fixed block order by a one-block finalize kernel (deterministic for a given grid).
+//
+// All f64 arithmetic mirrors the reference expression by expression (file:line cited at each
+// function) and is compiled with -ffp-contract=off so per-site values are bit-identical to the
+// Rust code for equal counts.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmh {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kTileRows = 64;
+constexpr double kFstEps = 1e-12;  // FST_EPSILON, stats.rs:26
+
+enum Mode : int { kModeSummary = 1, kModeHudson = 2, kModeDiversity = 4, kModeWc = 8 };
+enum Formula : int { kFormulaSparse = 0, kFormulaDense = 1, kFormulaSummary = 2 };
+
+struct MatrixView {
+  const uint8_t* data;
+  const uint8_t* bits;  // called bits, may be null
+  size_t pitch;
+  size_t bits_pitch;
+  uint32_t columns;  // H = samples * ploidy
+  uint32_t nvec;     // 16-byte vectors per row = ceil(H/16) (<= pitch/16)
+};
+
+struct SweepArgs {
+  MatrixView mv;
+  const uint8_t* masks;   // device [P][pitch] 0/1 bytes
+  uint32_t group_size[8]; // mask popcounts
+  int n_groups;           // caller's group count (<= kernel P; padded groups are never reported)
+  size_t row_begin;
+  size_t row_count;
+  int formula;
+  int max_allele;         // matrix max allele (general kernel loop bound upper limit)
+  // per-site outputs (nullable)
+  uint32_t* alt;          // [P][row_count]
+  uint32_t* called;       // [P][row_count]
+  double* fst; double* dxy; double* pi1; double* pi2; double* num; double* den;  // Hudson
+  double* site_pi; double* site_theta; uint32_t* site_distinct;                  // diversity (pop 0)
+  const double* harmonic;  // device table H_k, k = 0..H (stats.rs:4234-4240)
+  double* wc_a; double* wc_b; uint8_t* wc_state;                                 // W&C [(1+npairs)][row_count]
+  int8_t wc_slot[32];      // kernel slot k (padded-P pair order) -> caller slot, -1 = not reported
+  // block partials
+  double* part_f64;        // [grid][kMaxF64]
+  unsigned long long* part_u64;  // [grid][kMaxU64]
+};
+
+// slots of the per-block partial vectors
+constexpr int kPopF64 = 1;  // pi_sum
+constexpr int kPopU64 = 2;  // seg, uncallable
+// Hudson f64: numerator_sum, denominator_sum, pi1_sum, pi2_sum, dxy_sum_all, site_num_sum, site_den_sum, site_dxy_sum
+constexpr int kHudF64 = 8;
+// Hudson u64: dxy_uncallable_sites, sites_with_components, site_dxy_skipped
+constexpr int kHudU64 = 3;
+constexpr int kMaxF64 = 64;
+constexpr int kMaxU64 = 64;
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot4(a, b, c, false);  // v_dot4_u32_u8
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+
+// all-reduce (sum) inside one 16-lane DPP row: xor-1, xor-2 via quad_perm, then row_half_mirror,
+// then row_mirror.  Every lane of the row ends with the row total.
+__device__ __forceinline__ uint32_t row16_sum(uint32_t x) {
+  x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp<0x141>(x);  // row_half_mirror
+  x += dpp<0x140>(x);  // row_mirror
+  return x;
+}
+__device__ __forceinline__ uint32_t row16_or(uint32_t x) {
+  x |= dpp<0xB1>(x);
+  x |= dpp<0x4E>(x);
+  x |= dpp<0x141>(x);
+  x |= dpp<0x140>(x);
+  return x;
+}
+
+// 4 called-bits -> four 0/1 bytes
+__device__ __forceinline__ uint32_t nib_to_bytes(uint32_t nib) {
+  return ((nib & 0xFu) * 0x00204081u) & 0x01010101u;
+}
+// bytes equal to `a` -> 0x01, others 0x00 (exact, no cross-byte carries)
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t a4) {
+  uint32_t y = x ^ a4;
+  uint32_t t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+  return (~t & 0x80808080u) >> 7;
+}
+__device__ __forceinline__ uint32_t or_bytes(uint32_t x) {
+  x |= x >> 16;
+  x |= x >> 8;
+  return x & 0xFFu;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double f64_nan() { return __longlong_as_double(0x7FF8000000000000LL); }
+
+// ------------------------------------------------------------------------------------------------
+// reference formulas (each mirrors one Rust function expression by expression)
+// ------------------------------------------------------------------------------------------------
+
+// pi_from_components, stats.rs:2723-2733 (caller guarantees n >= 2)
+__device__ __forceinline__ double pi_sparse(uint32_t total_called, double sum_counts_sq) {
+  double n = (double)total_called;
+  double inv_n = 1.0 / n;
+  double sum_p2 = sum_counts_sq * inv_n * inv_n;
+  return n / (n - 1.0) * (1.0 - sum_p2);
+}
+// dense_pi_from_counts, stats.rs:1700-1709 == general dense arms 3090-3093 / 4581-4584 (n >= 2)
+__device__ __forceinline__ double pi_dense(uint32_t total_called, double sum_sq) {
+  double n = (double)total_called;
+  return n / (n - 1.0) * (1.0 - sum_sq / (n * n));
+}
+// no-missing biallelic arm, stats.rs:3239-3247 / 4500-4507 (n >= 2)
+__device__ __forceinline__ double pi_dense_nomissing(uint32_t total, uint32_t alt, double sum_sq) {
+  if (alt == 0 || alt == total) return 0.0;
+  double n = (double)total;
+  double scale = n / (n - 1.0);
+  double inv_n_sq = 1.0 / (n * n);
+  return scale * (1.0 - sum_sq * inv_n_sq);
+}
+// dense_dxy_from_biallelic_counts, stats.rs:1712-1733 (n1, n2 > 0)
+__device__ __forceinline__ double dxy_dense_biallelic(uint32_t n1, uint32_t alt1, uint32_t n2, uint32_t alt2) {
+  double n1_f = (double)n1, n2_f = (double)n2;
+  double alt1_f = (double)alt1 / n1_f;
+  double alt2_f = (double)alt2 / n2_f;
+  double ref1 = 1.0 - alt1_f;
+  double ref2 = 1.0 - alt2_f;
+  double dot = ref1 * ref2 + alt1_f * alt2_f;
+  if (dot < 0.0) dot = 0.0;
+  double dxy = 1.0 - dot;
+  if (dxy < 0.0) dxy = 0.0; else if (dxy > 1.0) dxy = 1.0;
+  return dxy;
+}
+__device__ __forceinline__ double clamp01(double x) {  // f64::max(0.0).min(1.0)
+  x = x > 0.0 ? x : 0.0;
+  return x < 1.0 ? x : 1.0;
+}
+
+// calculate_variance_components, stats.rs:2034-2127.  n[i], c[i] for the r groups with data, in
+// group order; global_p = sum c / sum n.
+template <int R>
+__device__ __forceinline__ void wc_components(const uint32_t (&n)[R], const uint32_t (&c)[R], int r_i,
+                                              double global_p, double& a, double& b) {
+  double r = (double)r_i;
+  a = 0.0; b = 0.0;
+  if (r < 2.0) return;
+  unsigned long long total_h = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) if (i < r_i) total_h += n[i];
+  double n_bar = (double)total_h / r;
+  if ((n_bar - 1.0) < 1e-9) return;
+  double sum_sq_diff_n = 0.0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) if (i < r_i) { double diff = (double)n[i] - n_bar; sum_sq_diff_n += diff * diff; }
+  double c_squared = (r > 0.0 && n_bar > 0.0) ? sum_sq_diff_n / (r * n_bar * n_bar) : 0.0;
+  double numerator_s_squared = 0.0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) if (i < r_i) {
+    double freq = (double)c[i] / (double)n[i];
+    double diff_p = freq - global_p;
+    numerator_s_squared += (double)n[i] * diff_p * diff_p;
+  }
+  double s_squared = ((r - 1.0) > 1e-9 && n_bar > 1e-9) ? numerator_s_squared / ((r - 1.0) * n_bar) : 0.0;
+  double x_wc = global_p * (1.0 - global_p) - ((r - 1.0) / r) * s_squared;
+  double a_numerator_term = s_squared - (x_wc / (n_bar - 1.0));
+  double a_denominator_factor = 1.0 - (c_squared / (r - 1.0));
+  a = a_numerator_term / a_denominator_factor;
+  b = (n_bar / (n_bar - 1.0)) * x_wc;
+}
+
+// fst_estimate_from_components, stats.rs:1781-1812 -> state code
+__device__ __forceinline__ uint8_t wc_classify(double a, double b) {
+  double denominator = a + b;
+  if (denominator > kFstEps) return 0;   // Calculable
+  if (denominator < -kFstEps) return 1;  // ComponentsYieldIndeterminateRatio
+  if (fabs(a) > kFstEps) return 0;       // Calculable(+-inf)
+  return 2;                              // NoInterPopulationVariance
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-site state: integer tallies of one site for P populations, fed allele by allele
+// ------------------------------------------------------------------------------------------------
+template <int P>
+struct SiteTally {
+  uint32_t n[P];         // called haplotypes per population
+  uint32_t alt[P];       // calls of allele 1
+  uint32_t distinct[P];  // alleles with count > 0
+  unsigned long long ssq[P];  // sum of count^2 (exact)
+  uint32_t n_all;        // called entries over ALL columns of the row
+};
+
+template <int P>
+constexpr int npairs() { return P * (P - 1) / 2; }
+
+// W&C accumulators of one site (stats.rs:1839-1985)
+template <int P>
+struct WcSite {
+  double a[1 + (P * (P - 1)) / 2];
+  double b[1 + (P * (P - 1)) / 2];
+};
+
+template <int P>
+__device__ __forceinline__ void wc_add_allele(const uint32_t (&n)[P], const uint32_t (&c)[P], WcSite<P>& w) {
+  // groups with data, in group order (stats.rs:1907-1922)
+  uint32_t vn[P], vc[P];
+  int valid = 0;
+  unsigned long long total_called = 0, total_target = 0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    if (n[i] != 0) {
+      // compacting insert without dynamic register indexing
+#pragma unroll
+      for (int j = 0; j < P; ++j) if (j == valid) { vn[j] = n[i]; vc[j] = c[i]; }
+      ++valid;
+      total_called += n[i];
+      total_target += c[i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < P; ++j) if (j >= valid) { vn[j] = 1; vc[j] = 0; }
+  if (valid < 2) return;  // stats.rs:1925-1930
+  double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
+  double ca, cb;
+  wc_components<P>(vn, vc, valid, global_freq, ca, cb);
+  w.a[0] += ca;
+  w.b[0] += cb;
+  int k = 1;
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+#pragma unroll
+    for (int j = i + 1; j < P; ++j) {
+      if (n[i] != 0 && n[j] != 0) {  // stats.rs:1950-1952
+        uint32_t pn[2] = {n[i], n[j]};
+        uint32_t pc[2] = {c[i], c[j]};
+        unsigned long long pair_total = (unsigned long long)n[i] + n[j];
+        double pair_global = pair_total > 0 ? (double)((unsigned long long)c[i] + c[j]) / (double)pair_total : 0.0;
+        double pa, pb;
+        wc_components<2>(pn, pc, 2, pair_global, pa, pb);
+        w.a[k] += pa;
+        w.b[k] += pb;
+      }
+      ++k;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row counting cores.  Each returns values already all-reduced over the 16-lane group.
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint4 load_vec(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+__device__ __forceinline__ uint4 called_bytes(uint32_t bits16) {
+  uint4 v;
+  v.x = nib_to_bytes(bits16);
+  v.y = nib_to_bytes(bits16 >> 4);
+  v.z = nib_to_bytes(bits16 >> 8);
+  v.w = nib_to_bytes(bits16 >> 12);
+  return v;
+}
+
+// Biallelic row: alt[p] = sum of allele bytes over called members, n[p] = called members.
+template <int P, bool MISSING, bool NEED_ALL>
+__device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+                                                    const uint8_t* __restrict__ row_ptr,
+                                                    const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
+                                                    uint32_t (&alt)[P], uint32_t (&n)[P], uint32_t& n_all) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) { alt[p] = 0; n[p] = 0; }
+  n_all = 0;
+  const uint32_t nvec = mv.nvec;
+  if (row_ok) {
+#pragma unroll 4
+    for (uint32_t v = gl; v < nvec; v += 16) {
+      uint4 g = load_vec(row_ptr + (size_t)v * 16);
+      uint4 cb;
+      if (MISSING) {
+        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)v * 2);
+        cb = called_bytes(bits16);
+        if (NEED_ALL) n_all += __builtin_popcount(bits16);
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        uint4 m = lds_mask[(uint32_t)p * nvec + v];
+        if (MISSING) {
+          m.x &= cb.x; m.y &= cb.y; m.z &= cb.z; m.w &= cb.w;
+          n[p] = dot4(m.x, 0x01010101u, n[p]);
+          n[p] = dot4(m.y, 0x01010101u, n[p]);
+          n[p] = dot4(m.z, 0x01010101u, n[p]);
+          n[p] = dot4(m.w, 0x01010101u, n[p]);
+        }
+        alt[p] = dot4(g.x, m.x, alt[p]);
+        alt[p] = dot4(g.y, m.y, alt[p]);
+        alt[p] = dot4(g.z, m.z, alt[p]);
+        alt[p] = dot4(g.w, m.w, alt[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    alt[p] = row16_sum(alt[p]);
+    if (MISSING) n[p] = row16_sum(n[p]);
+  }
+  if (MISSING && NEED_ALL) n_all = row16_sum(n_all);
+}
+
+// General row, pass 0: n[p], n_all and an upper bound (bitwise OR) of the called allele values.
+template <int P, bool MISSING>
+__device__ __forceinline__ void count_row_called(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+                                                 const uint8_t* __restrict__ row_ptr,
+                                                 const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
+                                                 uint32_t (&n)[P], uint32_t& n_all, uint32_t& allele_or) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) n[p] = 0;
+  n_all = 0;
+  allele_or = 0;
+  const uint32_t nvec = mv.nvec;
+  if (row_ok) {
+#pragma unroll 2
+    for (uint32_t v = gl; v < nvec; v += 16) {
+      uint4 g = load_vec(row_ptr + (size_t)v * 16);
+      uint4 cb;
+      if (MISSING) {
+        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)v * 2);
+        cb = called_bytes(bits16);
+        n_all += __builtin_popcount(bits16);
+        // keep only called bytes in the OR (0/1 byte * 0xFF)
+        g.x &= cb.x * 0xFFu; g.y &= cb.y * 0xFFu; g.z &= cb.z * 0xFFu; g.w &= cb.w * 0xFFu;
+      }
+      allele_or |= or_bytes(g.x | g.y | g.z | g.w);
+      if (MISSING) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          uint4 m = lds_mask[(uint32_t)p * nvec + v];
+          n[p] = dot4(m.x & cb.x, 0x01010101u, n[p]);
+          n[p] = dot4(m.y & cb.y, 0x01010101u, n[p]);
+          n[p] = dot4(m.z & cb.z, 0x01010101u, n[p]);
+          n[p] = dot4(m.w & cb.w, 0x01010101u, n[p]);
+        }
+      }
+    }
+  }
+  if (MISSING) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) n[p] = row16_sum(n[p]);
+    n_all = row16_sum(n_all);
+  }
+  allele_or = row16_or(allele_or);
+}
+
+// General row, pass per allele value a: c[p] = called members carrying allele a.
+template <int P, bool MISSING>
+__device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+                                                 const uint8_t* __restrict__ row_ptr,
+                                                 const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
+                                                 uint32_t a, uint32_t (&c)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) c[p] = 0;
+  const uint32_t nvec = mv.nvec;
+  const uint32_t a4 = a * 0x01010101u;
+  if (row_ok) {
+#pragma unroll 2
+    for (uint32_t v = gl; v < nvec; v += 16) {
+      uint4 g = load_vec(row_ptr + (size_t)v * 16);
+      uint4 e;
+      e.x = eq_bytes(g.x, a4); e.y = eq_bytes(g.y, a4); e.z = eq_bytes(g.z, a4); e.w = eq_bytes(g.w, a4);
+      if (MISSING) {
+        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)v * 2);
+        uint4 cb = called_bytes(bits16);
+        e.x &= cb.x; e.y &= cb.y; e.z &= cb.z; e.w &= cb.w;
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        uint4 m = lds_mask[(uint32_t)p * nvec + v];
+        c[p] = dot4(e.x, m.x, c[p]);
+        c[p] = dot4(e.y, m.y, c[p]);
+        c[p] = dot4(e.z, m.z, c[p]);
+        c[p] = dot4(e.w, m.w, c[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) c[p] = row16_sum(c[p]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// regional accumulators kept per lane
+// ------------------------------------------------------------------------------------------------
+template <int P, int MODE>
+struct LaneTotals {
+  double pop_pi[P];
+  unsigned long long pop_seg[P];
+  unsigned long long pop_unc[P];
+  double hud[kHudF64];
+  unsigned long long hud_u[kHudU64];
+  double wc_a[(MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1];
+  double wc_b[(MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1];
+  unsigned long long wc_inf[(MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1];
+
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int p = 0; p < P; ++p) { pop_pi[p] = 0.0; pop_seg[p] = 0; pop_unc[p] = 0; }
+#pragma unroll
+    for (int i = 0; i < kHudF64; ++i) hud[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < kHudU64; ++i) hud_u[i] = 0;
+    constexpr int NW = (MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { wc_a[i] = 0.0; wc_b[i] = 0.0; wc_inf[i] = 0; }
+  }
+};
+
+// layout of the per-block partial vectors (also used by the host to unpack)
+//   f64: [p*1 + 0] pop pi_sum (p < P) | [8 + i] Hudson f64 i | [16 + k] wc_a[k] | [16 + 29 + k] ... too big
+// -> W&C uses its own compact layout: f64 [k] = a, [29 + k] = b ; u64 [k] = informative
+constexpr int kOffPopF64 = 0;    // P <= 8 entries
+constexpr int kOffHudF64 = 8;    // 8 entries
+constexpr int kOffPopSeg = 0;    // u64, P entries
+constexpr int kOffPopUnc = 8;    // u64, P entries
+constexpr int kOffHudU64 = 16;   // 3 entries
+constexpr int kOffWcA = 0;       // f64 (W&C mode only, overlays)
+constexpr int kOffWcB = 29;
+constexpr int kOffWcInf = 24;    // u64
+
+// ------------------------------------------------------------------------------------------------
+// epilogue: statistics of one site from its tallies (lane-parallel, one site per lane)
+// ------------------------------------------------------------------------------------------------
+template <int P, int MODE, bool MISSING, bool GENERAL>
+__device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx, bool row_ok,
+                                              const SiteTally<P>& t, double hud_dot, const WcSite<P>& wc,
+                                              LaneTotals<P, MODE>& T) {
+  const bool dense = A.formula != kFormulaSparse;
+  // the reference takes the no-missing biallelic arms only on a dense matrix without a mask whose
+  // max_allele <= 1 (stats.rs:3191/3218, 4454/4485); build_dense_population_summary (1392, 1409)
+  // always uses dense_pi_from_counts
+  const bool nomiss_arm = A.formula == kFormulaDense && !MISSING && !GENERAL;
+
+  double pi[P];
+  bool pi_ok[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const uint32_t n = t.n[p];
+    pi_ok[p] = n >= 2;
+    double v = 0.0;
+    if (pi_ok[p]) {
+      const double ssq = (double)t.ssq[p];
+      if (!dense) v = pi_sparse(n, ssq);
+      else if (nomiss_arm) v = pi_dense_nomissing(n, t.alt[p], ssq);
+      else v = pi_dense(n, ssq);
+    }
+    pi[p] = v;
+    if (row_ok) {
+      if (pi_ok[p]) T.pop_pi[p] += v; else T.pop_unc[p] += 1;
+      if (t.distinct[p] >= 2) T.pop_seg[p] += 1;
+      if (p < A.n_groups) {
+        if (A.alt) A.alt[(size_t)p * A.row_count + out_idx] = t.alt[p];
+        if (A.called) A.called[(size_t)p * A.row_count + out_idx] = n;
+      }
+    }
+  }
+
+  if constexpr ((MODE & kModeDiversity) != 0) {
+    // calculate_per_site_diversity, stats.rs:4710-4725 (population 0)
+    const uint32_t n = t.n[0];
+    double pv, tv;
+    if (n < 2) { pv = f64_nan(); tv = f64_nan(); }
+    else {
+      if (t.distinct[0] > 1) { double denom = A.harmonic[n - 1]; tv = denom > 0.0 ? 1.0 / denom : 0.0; }
+      else tv = 0.0;
+      pv = pi_sparse(n, (double)t.ssq[0]);
+    }
+    if (row_ok) {
+      if (A.site_pi) A.site_pi[out_idx] = pv;
+      if (A.site_theta) A.site_theta[out_idx] = tv;
+      if (A.site_distinct) A.site_distinct[out_idx] = t.distinct[0];
+    }
+  }
+
+  if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+    const uint32_t n1 = t.n[0], n2 = t.n[1];
+    // ---- per-site record: hudson_site_from_variant 2969-3014 / dense twins 3072-3278 ----
+    bool dxy_ok = (n1 != 0) && (n2 != 0);
+    double dxy = 0.0;
+    if (dxy_ok) {
+      if (dense && !GENERAL) dxy = dxy_dense_biallelic(n1, t.alt[0], n2, t.alt[1]);
+      else dxy = clamp01(1.0 - hud_dot);  // dxy_from_counts 2933-2934 / general 3140
+    }
+    double fst = f64_nan(), numc = f64_nan(), denc = f64_nan();
+    bool comp_ok = false;
+    if (dxy_ok && pi_ok[0] && pi_ok[1]) {  // stats.rs:2984-3001 == 1741-1756 == 3143-3158
+      if (dxy > kFstEps) {
+        double num = dxy - 0.5 * (pi[0] + pi[1]);
+        fst = num / dxy; numc = num; denc = dxy; comp_ok = true;
+      } else {
+        double pi_avg = 0.5 * (pi[0] + pi[1]);
+        if (fabs(pi_avg) <= kFstEps) { numc = 0.0; denc = 0.0; comp_ok = true; }
+      }
+    }
+    if (row_ok) {
+      if (A.fst) A.fst[out_idx] = fst;
+      if (A.dxy) A.dxy[out_idx] = dxy_ok ? dxy : f64_nan();
+      if (A.pi1) A.pi1[out_idx] = pi_ok[0] ? pi[0] : f64_nan();
+      if (A.pi2) A.pi2[out_idx] = pi_ok[1] ? pi[1] : f64_nan();
+      if (A.num) A.num[out_idx] = numc;
+      if (A.den) A.den[out_idx] = denc;
+      if (comp_ok) { T.hud[5] += numc; T.hud[6] += denc; T.hud_u[1] += 1; }  // hudson_component_sums 1625-1635
+      // calculate_dxy_dense 2546-2596 / sparse fold 2476-2496 always use the frequency-dot form
+      if (dxy_ok) T.hud[7] += clamp01(1.0 - hud_dot); else T.hud_u[2] += 1;
+      // ---- aggregate_hudson_components_from_summaries, stats.rs:1565-1620 (biallelic counts) ----
+      if (n1 == 0 || n2 == 0) {
+        T.hud_u[0] += 1;
+      } else {
+        unsigned long long a1 = t.alt[0], a2 = t.alt[1];
+        unsigned long long r1 = n1 - a1, r2 = n2 - a2;
+        double denom_pairs = (double)((unsigned long long)n1 * n2);
+        if (denom_pairs != 0.0) {
+          double d = (double)(a1 * r2 + r1 * a2) / denom_pairs;
+          if (d < 0.0) d = 0.0; else if (d > 1.0) d = 1.0;
+          T.hud[4] += d;
+          if (n1 >= 2 && n2 >= 2) {
+            double denom1 = (double)((unsigned long long)n1 * (n1 - 1));
+            double denom2 = (double)((unsigned long long)n2 * (n2 - 1));
+            double p1 = denom1 > 0.0 ? 2.0 * (double)a1 * (double)r1 / denom1 : 0.0;
+            double p2 = denom2 > 0.0 ? 2.0 * (double)a2 * (double)r2 / denom2 : 0.0;
+            T.hud[2] += p1;
+            T.hud[3] += p2;
+            if (d > kFstEps) { T.hud[0] += d - 0.5 * (p1 + p2); T.hud[1] += d; }
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr ((MODE & kModeWc) != 0) {
+    constexpr int NW = 1 + (P * (P - 1)) / 2;
+    // stats.rs:1987-2031.  pop_sizes_populated == at least one allele present among ALL samples.
+    const bool any_allele = t.n_all != 0;
+    uint8_t st[NW];
+    double oa[NW], ob[NW];
+    if (!any_allele) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { st[k] = 3; oa[k] = 0.0; ob[k] = 0.0; }
+    } else {
+      st[0] = wc_classify(wc.a[0], wc.b[0]);
+      oa[0] = wc.a[0]; ob[0] = wc.b[0];
+      // a pair has an entry iff some allele pass saw both totals > 0 AND the overall pass was not
+      // skipped (valid_groups >= 2 is implied by both totals > 0)
+      int k = 1;
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int j = i + 1; j < P; ++j) {
+          if (t.n[i] != 0 && t.n[j] != 0) { st[k] = wc_classify(wc.a[k], wc.b[k]); oa[k] = wc.a[k]; ob[k] = wc.b[k]; }
+          else { st[k] = 3; oa[k] = 0.0; ob[k] = 0.0; }
+          ++k;
+        }
+      }
+    }
+    if (row_ok) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const int slot = A.wc_slot[k];
+        if (slot >= 0) {
+          if (A.wc_a) A.wc_a[(size_t)slot * A.row_count + out_idx] = oa[k];
+          if (A.wc_b) A.wc_b[(size_t)slot * A.row_count + out_idx] = ob[k];
+          if (A.wc_state) A.wc_state[(size_t)slot * A.row_count + out_idx] = st[k];
+        }
+        if (st[k] != 3) { T.wc_a[k] += oa[k]; T.wc_b[k] += ob[k]; T.wc_inf[k] += 1; }  // 2172-2203
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the sweep kernel
+// ------------------------------------------------------------------------------------------------
+template <int P, int MODE, bool MISSING, bool GENERAL>
+__global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint4* lds_mask = reinterpret_cast<uint4*>(smem);
+  const MatrixView mv = A.mv;
+  const uint32_t nvec = mv.nvec;
+
+  // stage the P membership masks into LDS (16 B per thread per step)
+  for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec; i += kBlock) {
+    const uint32_t p = i / nvec, v = i - p * nvec;
+    lds_mask[i] = load_vec(A.masks + (size_t)p * mv.pitch + (size_t)v * 16);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane >> 4;
+  const int gl = lane & 15;
+  constexpr bool NEED_ALL = (MODE & kModeWc) != 0;
+
+  LaneTotals<P, MODE> T;
+  T.clear();
+
+  const size_t ntiles = (A.row_count + kTileRows - 1) / kTileRows;
+  for (size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
+       tile += (size_t)gridDim.x * kWavesPerBlock) {
+    const size_t tile_row0 = tile * kTileRows;  // relative to row_begin
+    SiteTally<P> mine;
+    WcSite<P> wc;
+    double hud_dot = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { mine.n[p] = 0; mine.alt[p] = 0; mine.distinct[p] = 0; mine.ssq[p] = 0; }
+    mine.n_all = 0;
+    if constexpr ((MODE & kModeWc) != 0) {
+      constexpr int NW = 1 + (P * (P - 1)) / 2;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { wc.a[k] = 0.0; wc.b[k] = 0.0; }
+    }
+
+    for (int s = 0; s < 16; ++s) {
+      const size_t rel = tile_row0 + (size_t)grp * 16 + s;
+      const bool row_ok = rel < A.row_count;
+      const size_t row = A.row_begin + rel;
+      const uint8_t* row_ptr = mv.data + row * mv.pitch;
+      const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
+      const bool own = gl == s;
+
+      if constexpr (!GENERAL) {
+        uint32_t alt[P], n[P], n_all;
+        count_row_biallelic<P, MISSING, NEED_ALL>(mv, lds_mask, row_ptr, bits_ptr, row_ok, gl, alt, n, n_all);
+        if (own) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            mine.alt[p] = alt[p];
+            mine.n[p] = MISSING ? n[p] : A.group_size[p];
+          }
+          mine.n_all = MISSING ? n_all : mv.columns;
+        }
+      } else {
+        uint32_t n[P], n_all, aor;
+        count_row_called<P, MISSING>(mv, lds_mask, row_ptr, bits_ptr, row_ok, gl, n, n_all, aor);
+        if (!MISSING) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
+          n_all = mv.columns;
+        }
+        if (own) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) mine.n[p] = n[p];
+          mine.n_all = n_all;
+        }
+        // wave-uniform loop bound: OR over the four groups of this step
+        uint32_t bound = aor;
+        bound |= __shfl_xor(bound, 16, 64);
+        bound |= __shfl_xor(bound, 32, 64);
+        bound = __builtin_amdgcn_readfirstlane(bound);
+        if (bound > (uint32_t)A.max_allele) bound = (uint32_t)A.max_allele;
+        double inv1 = 0.0, inv2 = 0.0;
+        if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+          if (n[0] != 0) inv1 = 1.0 / (double)n[0];
+          if (n[1] != 0) inv2 = 1.0 / (double)n[1];
+        }
+        for (uint32_t a = 0; a <= bound; ++a) {
+          uint32_t c[P];
+          count_row_allele<P, MISSING>(mv, lds_mask, row_ptr, bits_ptr, row_ok, gl, a, c);
+          if (own) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              mine.ssq[p] += (unsigned long long)c[p] * c[p];
+              mine.distinct[p] += c[p] != 0 ? 1u : 0u;
+              if (a == 1) mine.alt[p] = c[p];
+            }
+            if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+              // dxy_from_counts 2921-2931 (ascending allele order); a zero count adds +0.0
+              if (c[0] != 0 && c[1] != 0) hud_dot += ((double)c[0] * inv1) * ((double)c[1] * inv2);
+            }
+            if constexpr ((MODE & kModeWc) != 0) {
+              // the reference iterates only alleles present among all samples; an absent allele
+              // contributes exact zeros, so iterating it is harmless
+              wc_add_allele<P>(n, c, wc);
+            }
+          }
+        }
+      }
+    }
+
+    if constexpr (!GENERAL) {
+      // biallelic: allele 0 count = n - alt, allele 1 count = alt
+      uint32_t c0[P], c1[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        c1[p] = mine.alt[p];
+        c0[p] = mine.n[p] - mine.alt[p];
+        mine.ssq[p] = (unsigned long long)c0[p] * c0[p] + (unsigned long long)c1[p] * c1[p];
+        mine.distinct[p] = (c0[p] != 0 ? 1u : 0u) + (c1[p] != 0 ? 1u : 0u);
+      }
+      if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+        if (mine.n[0] != 0 && mine.n[1] != 0) {
+          double inv1 = 1.0 / (double)mine.n[0], inv2 = 1.0 / (double)mine.n[1];
+          if (c0[0] != 0 && c0[1] != 0) hud_dot += ((double)c0[0] * inv1) * ((double)c0[1] * inv2);
+          if (c1[0] != 0 && c1[1] != 0) hud_dot += ((double)c1[0] * inv1) * ((double)c1[1] * inv2);
+        }
+      }
+      if constexpr ((MODE & kModeWc) != 0) {
+        wc_add_allele<P>(mine.n, c0, wc);
+        wc_add_allele<P>(mine.n, c1, wc);
+      }
+    }
+
+    const size_t my_rel = tile_row0 + lane;
+    site_epilogue<P, MODE, MISSING, GENERAL>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T);
+  }
+
+  // ---- block reduction of the regional accumulators (fixed order: lane tree, then waves 0..3) ----
+  __shared__ double s_f64[kWavesPerBlock][kMaxF64];
+  __shared__ unsigned long long s_u64[kWavesPerBlock][kMaxU64];
+  auto put_f64 = [&](int slot, double v) { v = wave_sum(v); if (lane == 0) s_f64[wave][slot] = v; };
+  auto put_u64 = [&](int slot, unsigned long long v) { v = wave_sum(v); if (lane == 0) s_u64[wave][slot] = v; };
+  if (lane < kMaxF64) s_f64[wave][lane] = 0.0;
+  if (lane < kMaxU64) s_u64[wave][lane] = 0;
+  __syncthreads();
+  if constexpr ((MODE & kModeWc) != 0) {
+    constexpr int NW = 1 + (P * (P - 1)) / 2;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { put_f64(kOffWcA + k, T.wc_a[k]); put_f64(kOffWcB + k, T.wc_b[k]); put_u64(kOffWcInf + k, T.wc_inf[k]); }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) { put_f64(kOffPopF64 + p, T.pop_pi[p]); put_u64(kOffPopSeg + p, T.pop_seg[p]); put_u64(kOffPopUnc + p, T.pop_unc[p]); }
+    if constexpr ((MODE & kModeHudson) != 0) {
+#pragma unroll
+      for (int i = 0; i < kHudF64; ++i) put_f64(kOffHudF64 + i, T.hud[i]);
+#pragma unroll
+      for (int i = 0; i < kHudU64; ++i) put_u64(kOffHudU64 + i, T.hud_u[i]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kMaxF64) {
+    double v = 0.0;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_f64[w][threadIdx.x];
+    A.part_f64[(size_t)blockIdx.x * kMaxF64 + threadIdx.x] = v;
+  } else if (threadIdx.x < kMaxF64 + kMaxU64) {
+    const int i = threadIdx.x - kMaxF64;
+    unsigned long long v = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_u64[w][i];
+    A.part_u64[(size_t)blockIdx.x * kMaxU64 + i] = v;
+  }
+}
+
+// Sum the per-block partials in block order (deterministic) into one vector each.
+__global__ __launch_bounds__(128) void finalize_kernel(const double* __restrict__ part_f64,
+                                                       const unsigned long long* __restrict__ part_u64,
+                                                       int nblocks, double* __restrict__ out_f64,
+                                                       unsigned long long* __restrict__ out_u64) {
+  const int i = threadIdx.x;
+  if (i < kMaxF64) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += part_f64[(size_t)b * kMaxF64 + i];
+    out_f64[i] = v;
+  } else {
+    const int j = i - kMaxF64;
+    unsigned long long v = 0;
+    for (int b = 0; b < nblocks; ++b) v += part_u64[(size_t)b * kMaxU64 + j];
+    out_u64[j] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout / generator / utility kernels
+// ------------------------------------------------------------------------------------------------
+
+// reference missing bitset (bit per linear entry, set = missing) -> called bit-rows
+__global__ void missing_to_called_rows(const unsigned long long* __restrict__ missing, size_t variants,
+                                       uint32_t columns, uint8_t* __restrict__ bits, size_t bits_pitch) {
+  const size_t total = variants * bits_pitch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = i / bits_pitch;
+    const uint32_t j = (uint32_t)(i - s * bits_pitch);
+    uint32_t out = 0;
+    for (int b = 0; b < 8; ++b) {
+      const uint32_t h = j * 8 + b;
+      if (h < columns) {
+        const size_t idx = s * columns + h;
+        const uint32_t miss = (uint32_t)((missing[idx >> 6] >> (idx & 63)) & 1ull);
+        out |= (miss ^ 1u) << b;
+      }
+    }
+    bits[i] = (uint8_t)out;
+  }
+}
+
+// called bit-rows -> reference missing bitset (one thread per output word)
+__global__ void called_rows_to_missing(const uint8_t* __restrict__ bits, size_t bits_pitch, size_t variants,
+                                       uint32_t columns, unsigned long long* __restrict__ missing, size_t words) {
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long out = 0;
+    for (int b = 0; b < 64; ++b) {
+      const size_t idx = w * 64 + b;
+      if (idx < variants * (size_t)columns) {
+        const size_t s = idx / columns;
+        const uint32_t h = (uint32_t)(idx - s * columns);
+        const uint32_t called = (bits[s * bits_pitch + (h >> 3)] >> (h & 7)) & 1u;
+        out |= (unsigned long long)(called ^ 1u) << b;
+      }
+    }
+    missing[w] = out;
+  }
+}
+
+// splitmix64 finaliser: the counter-based stream shared with oracle/dense_oracle.c
+__host__ __device__ __forceinline__ uint32_t hash24(uint64_t seed, uint64_t site, uint64_t column) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (site * 0x100000001B3ull + column + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 40);
+}
+
+// one thread writes 16 columns (one vector) of one site
+__global__ void generate_kernel(uint8_t* __restrict__ data, size_t pitch, uint8_t* __restrict__ bits,
+                                size_t bits_pitch, size_t variants, uint32_t columns, uint32_t nvec,
+                                uint64_t seed, uint64_t first_site, const uint32_t* __restrict__ thresholds,
+                                const uint8_t* __restrict__ pop_of_column, uint32_t missing_thr) {
+  const size_t total = variants * (size_t)(pitch / 16);
+  const uint32_t vec_per_row = (uint32_t)(pitch / 16);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = i / vec_per_row;
+    const uint32_t v = (uint32_t)(i - s * vec_per_row);
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t called = 0;
+    if (v < nvec) {
+      for (int b = 0; b < 16; ++b) {
+        const uint32_t h = v * 16 + b;
+        if (h < columns) {
+          const uint32_t thr = thresholds[(size_t)pop_of_column[h] * variants + s];
+          const uint32_t bit = hash24(seed, first_site + s, h) < thr ? 1u : 0u;
+          bool miss = false;
+          if (bits) miss = hash24(seed ^ 0xA5A5A5A5DEADBEEFull, first_site + s, h) < missing_thr;
+          if (!miss) { w[b >> 2] |= bit << ((b & 3) * 8); called |= 1u << b; }
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(data + s * pitch + (size_t)v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (bits && (size_t)v * 2 + 1 < bits_pitch) *reinterpret_cast<uint16_t*>(bits + s * bits_pitch + (size_t)v * 2) = (uint16_t)called;
+  }
+}
+
+// max over called entries
+__global__ void max_allele_kernel(const uint8_t* __restrict__ data, size_t pitch, const uint8_t* __restrict__ bits,
+                                  size_t bits_pitch, size_t variants, uint32_t columns, unsigned int* __restrict__ out) {
+  unsigned int best = 0;
+  const size_t total = variants * (size_t)columns;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = i / columns;
+    const uint32_t h = (uint32_t)(i - s * columns);
+    bool ok = true;
+    if (bits) ok = ((bits[s * bits_pitch + (h >> 3)] >> (h & 7)) & 1u) != 0;
+    if (ok) { unsigned int v = data[s * pitch + h]; best = v > best ? v : best; }
+  }
+  for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, best);
+}
+
+}  // namespace fmh

@@ -1,0 +1,246 @@
+/*
+ * ferromic_hip.h — C-ABI of libferromic_hip.so: the MI355X (gfx950) device layer under the
+ * ferromic per-site diversity / FST hot path.
+ *
+ * The reference (SauersML/ferromic) has no FFI for this path: PyO3 calls the Rust functions in
+ * src/stats.rs directly.  This header is the boundary a Rust (or any) host would bind instead of
+ * those functions; every entry point cites the reference code it replaces.  INTEGRATION.md shows
+ * the `extern "C"` block a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes; no C++/torch types.  Pointers named d_* are DEVICE pointers
+ *     (hipMalloc or a torch tensor's data_ptr), h_* are HOST pointers; every d_* output may be
+ *     NULL to skip that track.
+ *   - every function returns a status (FMH_OK == 0) and records a thread-local message readable
+ *     through fmh_last_error().
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls that fill host
+ *     totals synchronise that stream before returning.
+ *   - per-site f64 tracks encode the reference's Option<f64>::None as NaN.
+ *   - rows are variant sites in matrix order; a sweep over [row_begin, row_begin+row_count) writes
+ *     per-site outputs at index (row - row_begin).
+ */
+#ifndef FERROMIC_HIP_H
+#define FERROMIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMH_ABI_VERSION 1
+#define FMH_MAX_GROUPS 8 /* populations per sweep */
+#define FMH_MAX_PAIRS 28 /* FMH_MAX_GROUPS choose 2 */
+
+enum fmh_status {
+  FMH_OK = 0,
+  FMH_ERR_INVALID = 1,     /* bad argument (message says which) */
+  FMH_ERR_HIP = 2,         /* HIP runtime error */
+  FMH_ERR_NO_DEVICE = 3,   /* no usable GPU: the product path has no CPU fallback */
+  FMH_ERR_UNSUPPORTED = 4
+};
+
+/* Which of the reference's algebraically-equal formula sets a sweep reproduces bit-for-bit. */
+enum fmh_formula {
+  /* sparse Variant path: pi_from_components (stats.rs:2723-2733), dxy_from_counts (2907-2935),
+   * hudson_site_from_variant (2969-3014), compute_pi_metrics_fast (2761-2821) */
+  FMH_FORMULA_SPARSE = 0,
+  /* dense matrix path: dense_pi_from_counts (1700-1709), dense_dxy_from_biallelic_counts
+   * (1712-1733), dense_hudson_sites_{biallelic,general} (3072-3278), calculate_pi_dense
+   * (4434-4597); the no-missing biallelic arms (3218-3273, 4485-4523) are taken automatically
+   * when the matrix has no missing mask and max_allele <= 1, exactly as the reference does */
+  FMH_FORMULA_DENSE = 1,
+  /* build_dense_population_summary (1367-1470): like DENSE but per-site pi is always
+   * dense_pi_from_counts (1392, 1409), also on a mask-free matrix */
+  FMH_FORMULA_SUMMARY = 2
+};
+
+typedef struct fmh_matrix fmh_matrix; /* DenseGenotypeMatrix, stats.rs:250-331 */
+typedef struct fmh_groups fmh_groups; /* P column memberships, stats.rs:1246-1295 / 1204-1244 / 1093-1159 */
+
+const char* fmh_last_error(void);
+int fmh_abi_version(void);
+int fmh_device_count(int* h_count);
+/* name, CU count and total memory of a device (for reports) */
+int fmh_device_info(int device, char* h_name, size_t name_cap, int* h_compute_units, uint64_t* h_total_mem);
+
+/* ---- raw device memory helpers for hosts that do not bring their own allocator --------------- */
+int fmh_device_alloc(int device, size_t bytes, void** d_out);
+int fmh_device_free(int device, void* d_ptr);
+int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
+int fmh_copy_to_device(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
+int fmh_stream_synchronize(int device, void* stream);
+
+/* ---- genotype matrix (replaces DenseGenotypeMatrix::new, stats.rs:261-296) ------------------- */
+/*
+ * Upload a site-major matrix in the reference's host layout: data[site*stride + sample*ploidy + side],
+ * stride = samples*ploidy (stats.rs:293); optional missing bitset, one bit per linear entry,
+ * LSB-first in u64 words (stats.rs:1298-1302; lib.rs:1188-1189).  On the device rows are padded to
+ * a 16-byte pitch and the missing bitset is re-laid as one "called" bit-row per site.
+ */
+int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing_or_null, size_t variants,
+                      size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out);
+/* Allocate an uninitialised device matrix (filled by fmh_matrix_generate or by the caller). */
+int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, int with_missing, uint8_t max_allele,
+                     int device, fmh_matrix** out);
+/* Wrap caller-owned device memory (e.g. a torch uint8 tensor): d_data rows of `pitch` bytes
+ * (pitch % 16 == 0, pitch >= samples*ploidy); d_called_bits_or_null rows of `bits_pitch` bytes
+ * (bit h of a row set = entry h is called; bits_pitch % 4 == 0). The wrapper never frees them. */
+int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_called_bits_or_null, size_t bits_pitch,
+                    size_t variants, size_t samples, size_t ploidy, uint8_t max_allele, int device,
+                    fmh_matrix** out);
+int fmh_matrix_destroy(fmh_matrix* m);
+/* geometry: any pointer may be NULL */
+int fmh_matrix_info(const fmh_matrix* m, size_t* variants, size_t* samples, size_t* ploidy, size_t* pitch,
+                    size_t* bits_pitch, int* has_missing, uint8_t* max_allele, int* device);
+int fmh_matrix_device_ptrs(const fmh_matrix* m, void** d_data, void** d_called_bits);
+/* Copy back in the reference host layout (tests / oracle). h_missing_or_null must hold
+ * ceil(variants*stride/64) words when the matrix has a mask. */
+int fmh_matrix_download(const fmh_matrix* m, uint8_t* h_data, uint64_t* h_missing_or_null);
+/* max over called entries, computed on the device (what from_variants computes at stats.rs:490) */
+int fmh_matrix_scan_max_allele(const fmh_matrix* m, uint8_t* h_max, void* stream);
+
+/*
+ * Counter-based synthetic cohort written straight into HBM (bench + parity at sizes no host could
+ * hold): entry (site, column) = 1 iff hash24(seed, global_site, column) < threshold[pop_of_column][site],
+ * and is missing iff hash24(seed ^ K, global_site, column) < missing_threshold24.  `h_thresholds24` is
+ * [n_pops][variants] (values in [0, 2^24]); `h_pop_of_column` is [samples*ploidy] with entries < n_pops.
+ * `first_global_site` lets a rank generate its slab of a larger cohort.  oracle/dense_oracle.c holds
+ * the identical generator so CPU and GPU see the same matrix without moving it.
+ */
+int fmh_matrix_generate(fmh_matrix* m, uint64_t seed, uint64_t first_global_site,
+                        const uint32_t* h_thresholds24, const uint8_t* h_pop_of_column, int n_pops,
+                        uint32_t missing_threshold24, void* stream);
+
+/* ---- memberships --------------------------------------------------------------------------- */
+/*
+ * P populations as 0/1 column masks, h_column_mask[p*H + h], H = samples*ploidy.  A mask is what
+ * DenseMembership::build (stats.rs:1252-1284) / HapMembership::build (1212-1238) reduce a
+ * (sample, side) list to: duplicates collapse, out-of-range samples are dropped, the Right side is
+ * dropped when ploidy <= 1.  Populations may overlap.  1 <= P <= FMH_MAX_GROUPS.
+ */
+int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_column_mask, int n_groups, fmh_groups** out);
+int fmh_groups_destroy(fmh_groups* g);
+int fmh_groups_sizes(const fmh_groups* g, int* n_groups, uint64_t* h_sizes /* [n_groups] mask popcounts */);
+
+/* ---- per-population summary sweep ------------------------------------------------------------ */
+typedef struct {
+  uint64_t haplotype_capacity; /* mask popcount — DensePopulationSummary.haplotype_capacity (1466) */
+  uint64_t segregating_sites;  /* sites with >= 2 distinct called alleles inside the population
+                                  (== called>=2 && 0<alt<called when biallelic: 1389, 4049, 3891-4026, 3868-3889) */
+  uint64_t uncallable_sites;   /* sites with called < 2 (1512-1516, 4391-4393, 4464, 4586) */
+  double pi_sum;               /* sum of per-site pi over sites with called >= 2 (1392-1394, 4388-4390, ...) */
+} fmh_pop_totals;
+
+/*
+ * Replaces build_dense_population_summary (stats.rs:1367-1470) for all P populations in ONE pass,
+ * and supplies the scalars count_segregating_sites_dense (3891), calculate_pi_dense (4534),
+ * calculate_pi (4317) and count_segregating_sites_for_haplotypes (3858) reduce to.
+ * d_alt / d_called: [P][row_count] u32 (alt = number of allele-1 calls; meaningful when max_allele <= 1).
+ */
+int fmh_population_summaries(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                             int formula, uint32_t* d_alt, uint32_t* d_called, fmh_pop_totals* h_totals,
+                             void* stream);
+
+/* ---- Hudson pair sweep (groups 0 and 1 of `g`) ----------------------------------------------- */
+typedef struct {
+  /* HudsonSummaryTotals, stats.rs:1545-1552, from aggregate_hudson_components_from_summaries
+   * (1554-1623).  Only meaningful when max_allele <= 1. */
+  double numerator_sum, denominator_sum, pi1_sum, pi2_sum, dxy_sum_all;
+  uint64_t dxy_uncallable_sites;
+  /* hudson_component_sums over the per-site records (stats.rs:1625-1635) */
+  double site_num_sum, site_den_sum;
+  uint64_t sites_with_components;
+  /* sum of per-site d_xy over sites where it is Some, and the count where it is None
+   * (calculate_d_xy_hudson sparse fold 2476-2496; calculate_dxy_dense 2546-2596) */
+  double site_dxy_sum;
+  uint64_t site_dxy_skipped;
+  fmh_pop_totals pop[2];
+} fmh_hudson_totals;
+
+typedef struct { /* SiteFstHudson as structure-of-arrays, stats.rs:536-555; all nullable */
+  double* d_fst;
+  double* d_dxy;
+  double* d_pi1;
+  double* d_pi2;
+  double* d_num;
+  double* d_den;
+  uint32_t* d_alt;    /* [2][row_count] */
+  uint32_t* d_called; /* [2][row_count]  (n1_called, n2_called) */
+} fmh_hudson_sites;
+
+/*
+ * One pass over the rows yields what the reference computes in up to four passes:
+ * build_dense_population_summary x2 (1367), aggregate_hudson_components_from_summaries (1554),
+ * dense_hudson_sites (3060) or hudson_site_from_variant per site (2969), and the pi/Dxy auxiliaries
+ * of calculate_hudson_fst_for_pair_core (3435-3599).  This is the "pi + Hudson FST" sweep
+ * BASELINE.json's metric is quoted on.
+ */
+int fmh_hudson_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                     int formula, const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_totals,
+                     void* stream);
+
+/* ---- per-site diversity (population 0 of `g`) ------------------------------------------------- */
+/*
+ * Replaces the loop of calculate_per_site_diversity (stats.rs:4693-4750): d_pi / d_theta per site;
+ * called < 2 -> (NaN, NaN); theta = 1/H_{called-1} when >= 2 distinct alleles else 0 (4717-4722),
+ * with H_k summed ascending exactly like harmonic() (4234-4240).  Position filtering / masking
+ * (4731-4743) stays on the host.
+ */
+int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                        double* d_pi, double* d_theta, uint32_t* d_called, uint32_t* d_distinct,
+                        fmh_pop_totals* h_totals, void* stream);
+
+/* ---- Weir & Cockerham sweep -------------------------------------------------------------------- */
+enum fmh_wc_state { /* FstEstimate variants, stats.rs:37-126 */
+  FMH_WC_CALCULABLE = 0,
+  FMH_WC_INDETERMINATE = 1,
+  FMH_WC_NO_VARIANCE = 2,
+  FMH_WC_INSUFFICIENT = 3
+};
+
+typedef struct {
+  /* slot 0 = overall, slot 1+k = pair k in (0,1),(0,2),...,(P-2,P-1) order (stats.rs:1133-1142) */
+  double sum_a[1 + FMH_MAX_PAIRS];
+  double sum_b[1 + FMH_MAX_PAIRS];
+  uint64_t informative_sites[1 + FMH_MAX_PAIRS]; /* sites whose per-site state != insufficient (2172-2203) */
+  uint64_t sites_attempted;                      /* rows swept */
+} fmh_wc_totals;
+
+/*
+ * Replaces calculate_fst_wc_at_site_with_membership (stats.rs:1814-2032) per row and the sums of
+ * calculate_overall_fst_wc (2145-2374).  Groups are the sorted labels of SubpopulationMembership
+ * (1104-1150).  Per-site outputs, all [(1+npairs)][row_count]: a, b (summed over every allele
+ * present at the site, 1859-1985) and the FstEstimate state code; d_group_called [P][row_count]
+ * are the population_sizes (1919-1923).  Alleles are discovered over ALL columns of the row
+ * (1826-1837), not only grouped ones.
+ */
+int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                 double* d_a, double* d_b, uint8_t* d_state, uint32_t* d_group_called,
+                 fmh_wc_totals* h_totals, void* stream);
+
+/* ---- multi-GPU ---------------------------------------------------------------------------------- */
+/*
+ * The region-sharded totals are plain sums: these pack/unpack them into the f64 + u64 vectors a
+ * single all-reduce(sum) moves (RCCL via torch.distributed, or MPI/any other transport).  Integer
+ * totals are exact; f64 totals are order-dependent within 1e-9.
+ */
+#define FMH_HUDSON_PACK_F64 10
+#define FMH_HUDSON_PACK_U64 10
+int fmh_hudson_totals_pack(const fmh_hudson_totals* t, double* h_f64 /*[FMH_HUDSON_PACK_F64]*/,
+                           uint64_t* h_u64 /*[FMH_HUDSON_PACK_U64]*/);
+int fmh_hudson_totals_unpack(fmh_hudson_totals* t, const double* h_f64, const uint64_t* h_u64);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+/* Accumulated HIP-event time (ms) and launch count of the dominant sweep kernel since the last
+ * reset, measured on the stream the kernel ran on.  Timing is off unless enabled (events add
+ * ~2 us per launch). */
+int fmh_timing_enable(int on);
+int fmh_timing_reset(void);
+int fmh_timing_read(double* h_total_ms, uint64_t* h_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FERROMIC_HIP_H */

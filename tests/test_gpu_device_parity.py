@@ -1,0 +1,277 @@
+"""GPU parity proper: every sweep of libferromic_hip.so (called through the C-ABI) against the CPU
+oracle on the same seeded inputs.  Integer outputs and per-site f64 records must be bit-exact;
+regional sums within 1e-9 relative (1e-12 absolute near zero), the tolerance north_star states
+(reference sums are rayon-ordered, i.e. order-dependent themselves)."""
+
+import random
+
+import numpy as np
+import pytest
+
+from oracle import ferromic_ref as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ferromic_amd import device
+
+    return device
+
+
+def upload(dev, m: R.DenseGenotypeMatrix):
+    return dev.DeviceMatrix.from_host(np.frombuffer(m.data, dtype=np.uint8), H.missing_words_np(m), m.variant_count,
+                                      m.sample_count, m.ploidy, m.max_allele)
+
+
+SHAPES = [
+    # (sites, samples, max_allele, p_missing)
+    (300, 37, 1, 0.0),     # ragged: H = 74 (not a multiple of 16), partial last tile
+    (64, 8, 1, 0.0),       # exactly one tile, H = 16
+    (1, 3, 1, 0.0),        # single site
+    (257, 500, 1, 0.0),    # C2-like width
+    (190, 61, 1, 0.07),    # biallelic with missing
+    (130, 45, 3, 0.0),     # multi-allelic
+    (130, 45, 5, 0.1),     # multi-allelic with missing
+    (70, 2500, 1, 0.0),    # C4-like width (H = 5000)
+]
+
+
+@pytest.mark.parametrize("sites,samples,max_allele,p_missing", SHAPES)
+def test_summaries_and_hudson_dense(dev, sites, samples, max_allele, p_missing):
+    rng = np.random.default_rng(sites * 131 + samples)
+    m = H.random_dense_matrix(rng, sites, samples, 2, max_allele, p_missing)
+    dm = upload(dev, m)
+    assert dm.scan_max_allele() == m.max_allele
+    half = samples // 2
+    h1 = H.haps_for_samples(range(0, half)) + [(0, 0), (samples + 5, 1)]  # duplicate + out of range
+    h2 = H.haps_for_samples(range(half, samples - (1 if samples > 2 else 0)))  # last sample ungrouped
+    g = dev.Groups.from_haplotype_lists(dm, [h1, h2])
+    off1 = R.dense_membership_offsets(m, h1)
+    off2 = R.dense_membership_offsets(m, h2)
+    assert g.sizes == [len(off1), len(off2)]
+
+    # ---- (a3) build_dense_population_summary, stats.rs:1367-1470 ----
+    if max_allele <= 1:
+        s = dev.population_summaries(dm, g, dev.FORMULA_SUMMARY)
+        for p, hl in enumerate((h1, h2)):
+            exp = R.build_dense_population_summary(m, hl)
+            assert np.array_equal(s.alt[p], np.array(exp.alt_counts, dtype=np.uint32))
+            assert np.array_equal(s.called[p], np.array(exp.called_counts, dtype=np.uint32))
+            assert s.totals[p]["segregating_sites"] == exp.segregating_sites
+            assert s.totals[p]["haplotype_capacity"] == exp.haplotype_capacity
+            assert s.totals[p]["uncallable_sites"] == sum(1 for c in exp.called_counts if c < 2)
+            assert H.rel_close(s.totals[p]["pi_sum"], exp.pi_sum)
+
+    # ---- dense paths: count_segregating_sites_dense 3891, calculate_pi_dense 4534 ----
+    d = dev.population_summaries(dm, g, dev.FORMULA_DENSE)
+    L = 10 * sites + 7
+    for p, off in enumerate((off1, off2)):
+        assert d.totals[p]["segregating_sites"] == R.count_segregating_sites_dense(m, off)
+        exp_pi = R.calculate_pi_dense(m, off, L)
+        eff = L - d.totals[p]["uncallable_sites"]
+        assert H.rel_close(d.totals[p]["pi_sum"] / eff, exp_pi)
+
+    # ---- dense_hudson_sites 3060-3278: per-site records bit-exact ----
+    variants = [R.Variant(7 * i, None) for i in range(sites)]
+    exp_sites = R.dense_hudson_sites(m, variants, off1, off2)
+    hs = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
+    H.assert_bits_equal(hs.sites["fst"], [H.opt(x.fst) for x in exp_sites], "fst")
+    H.assert_bits_equal(hs.sites["dxy"], [H.opt(x.d_xy) for x in exp_sites], "dxy")
+    H.assert_bits_equal(hs.sites["pi1"], [H.opt(x.pi_pop1) for x in exp_sites], "pi1")
+    H.assert_bits_equal(hs.sites["pi2"], [H.opt(x.pi_pop2) for x in exp_sites], "pi2")
+    H.assert_bits_equal(hs.sites["num"], [H.opt(x.num_component) for x in exp_sites], "num")
+    H.assert_bits_equal(hs.sites["den"], [H.opt(x.den_component) for x in exp_sites], "den")
+    assert np.array_equal(hs.sites["called"][0], np.array([x.n1_called for x in exp_sites], dtype=np.uint32))
+    assert np.array_equal(hs.sites["called"][1], np.array([x.n2_called for x in exp_sites], dtype=np.uint32))
+    num_sum, den_sum = R.hudson_component_sums(exp_sites)
+    assert H.rel_close(hs.totals["site_num_sum"], num_sum)
+    assert H.rel_close(hs.totals["site_den_sum"], den_sum)
+    assert hs.totals["sites_with_components"] == sum(1 for x in exp_sites if x.num_component is not None)
+    # calculate_dxy_dense 2526-2611
+    exp_dxy = R.calculate_dxy_dense(m, off1, off2, L)
+    eff = L - hs.totals["site_dxy_skipped"]
+    assert H.rel_close(hs.totals["site_dxy_sum"] / eff, exp_dxy)
+
+    # ---- aggregate_hudson_components_from_summaries 1554-1623 ----
+    if max_allele <= 1:
+        t = R.aggregate_hudson_components_from_summaries(R.build_dense_population_summary(m, h1),
+                                                         R.build_dense_population_summary(m, h2))
+        for k in ("numerator_sum", "denominator_sum", "pi1_sum", "pi2_sum", "dxy_sum_all"):
+            assert H.rel_close(hs.totals[k], getattr(t, k)), k
+        assert hs.totals["dxy_uncallable_sites"] == t.dxy_uncallable_sites
+
+
+SPARSE_CASES = [
+    # (sites, samples, max_allele, p_missing, p_haploid, all_missing_rows)
+    (150, 20, 1, 0.0, 0.0, 0),
+    (150, 21, 1, 0.15, 0.05, 2),
+    (90, 33, 3, 0.1, 0.1, 1),
+    (40, 300, 2, 0.02, 0.0, 0),
+]
+
+
+@pytest.mark.parametrize("sites,samples,max_allele,p_missing,p_haploid,dead", SPARSE_CASES)
+def test_sparse_formulas(dev, sites, samples, max_allele, p_missing, p_haploid, dead):
+    """hudson_site_from_variant (2969), calculate_pi (4317), calculate_d_xy_hudson sparse fold (2476),
+    calculate_per_site_diversity (4628), count_segregating_sites (3808) through the dense+mask
+    representation the host layer ships to the GPU."""
+    rng = random.Random(sites * 7 + samples)
+    variants = H.random_sparse_variants(rng, sites, samples, max_allele, p_missing, p_haploid, dead)
+    m = H.dense_from_variants(variants, samples)
+    dm = upload(dev, m)
+    third = samples // 3
+    h1 = H.haps_for_samples(range(0, third))
+    h2 = H.haps_for_samples(range(third, 2 * third)) + [(2 * third, 0)]  # one half-sample
+    g = dev.Groups.from_haplotype_lists(dm, [h1, h2])
+    names = [f"s{i}" for i in range(samples)]
+    L = variants[-1].position + 10
+    p1 = R.PopulationContext(0, h1, variants, names, L)
+    p2 = R.PopulationContext(1, h2, variants, names, L)
+    region = R.QueryRegion(0, L)
+    exp_sites = R.calculate_hudson_fst_per_site(p1, p2, region)
+    hs = dev.hudson_sweep(dm, g, dev.FORMULA_SPARSE)
+    H.assert_bits_equal(hs.sites["fst"], [H.opt(x.fst) for x in exp_sites], "fst")
+    H.assert_bits_equal(hs.sites["dxy"], [H.opt(x.d_xy) for x in exp_sites], "dxy")
+    H.assert_bits_equal(hs.sites["pi1"], [H.opt(x.pi_pop1) for x in exp_sites], "pi1")
+    H.assert_bits_equal(hs.sites["pi2"], [H.opt(x.pi_pop2) for x in exp_sites], "pi2")
+    H.assert_bits_equal(hs.sites["num"], [H.opt(x.num_component) for x in exp_sites], "num")
+    H.assert_bits_equal(hs.sites["den"], [H.opt(x.den_component) for x in exp_sites], "den")
+    assert np.array_equal(hs.sites["called"][0], np.array([x.n1_called for x in exp_sites], dtype=np.uint32))
+    outcome, _ = R.calculate_hudson_fst_for_pair_with_sites(p1, p2, region)
+    fst = hs.totals["site_num_sum"] / hs.totals["site_den_sum"] if hs.totals["site_den_sum"] > 1e-12 else None
+    assert (fst is None) == (outcome.fst is None)
+    if fst is not None:
+        assert H.rel_close(fst, outcome.fst)
+    for p, hl in enumerate((h1, h2)):
+        exp_pi = R.calculate_pi(variants, hl, L)
+        assert H.rel_close(hs.pop[p]["pi_sum"] / (L - hs.pop[p]["uncallable_sites"]), exp_pi)
+        assert hs.pop[p]["segregating_sites"] == R.count_segregating_sites_for_haplotypes(variants, hl)
+    exp_dxy = R.calculate_d_xy_hudson(p1, p2)
+    assert H.rel_close(hs.totals["site_dxy_sum"] / (L - hs.totals["site_dxy_skipped"]), exp_dxy)
+
+    # per-site diversity of population 1
+    g1 = dev.Groups.from_haplotype_lists(dm, [h1])
+    dv = dev.diversity_sites(dm, g1)
+    exp_div = R.calculate_per_site_diversity(variants, h1, region)
+    H.assert_bits_equal(dv.pi, [x.pi for x in exp_div], "site pi")
+    H.assert_bits_equal(dv.theta, [x.watterson_theta for x in exp_div], "site theta")
+
+    # cohort-wide segregating sites: every column is a member (stats.rs:3808-3829)
+    gall = dev.Groups(dm, np.ones((1, dm.columns), dtype=np.uint8))
+    sall = dev.population_summaries(dm, gall, dev.FORMULA_SPARSE, want_sites=False)
+    assert sall.totals[0]["segregating_sites"] == R.count_segregating_sites(variants)
+
+
+WC_CASES = [
+    # (sites, samples, n_groups, max_allele, p_missing, p_haploid, dead_rows, ungrouped)
+    (120, 16, 2, 1, 0.0, 0.0, 0, 0),
+    (120, 18, 2, 1, 0.2, 0.1, 2, 3),
+    (100, 40, 4, 1, 0.05, 0.0, 1, 4),
+    (80, 30, 3, 3, 0.1, 0.05, 1, 2),
+    (60, 50, 5, 2, 0.05, 0.0, 0, 5),
+]
+
+
+@pytest.mark.parametrize("sites,samples,G,max_allele,p_missing,p_haploid,dead,ungrouped", WC_CASES)
+def test_wc_sweep(dev, sites, samples, G, max_allele, p_missing, p_haploid, dead, ungrouped):
+    """calculate_fst_wc_at_site_with_membership (1814-2032) + calculate_overall_fst_wc sums (2145-2374)."""
+    rng = random.Random(sites + 1000 * G)
+    variants = H.random_sparse_variants(rng, sites, samples, max_allele, p_missing, p_haploid, dead)
+    # make one group entirely missing at one site, and uneven group sizes
+    names = [f"s{i}" for i in range(samples)]
+    sample_to_group = {}
+    for i in range(samples - ungrouped):
+        left = i % G
+        right = (i // 2) % G if i % 5 == 0 else left  # some samples straddle two groups
+        sample_to_group[names[i]] = (left, right)
+    m = H.dense_from_variants(variants, samples)
+    dm = upload(dev, m)
+    hap_to_group = R.map_samples_to_haplotype_groups(names, sample_to_group)
+    mem = R.SubpopulationMembership.from_map(samples, hap_to_group)
+    assert mem.group_count() == G
+    masks = np.zeros((G, dm.columns), dtype=np.uint8)
+    for i in range(samples):
+        if mem.left[i] != R.INVALID_GROUP:
+            masks[mem.left[i], i * dm.ploidy] = 1
+        if mem.right[i] != R.INVALID_GROUP and dm.ploidy > 1:
+            masks[mem.right[i], i * dm.ploidy + 1] = 1
+    g = dev.Groups(dm, masks)
+    res = R.calculate_fst_wc_haplotype_groups(variants, names, sample_to_group, R.QueryRegion(0, 10 ** 9))
+    w = dev.wc_sweep(dm, g)
+    keys = [k for _, _, k in mem.pair_keys]
+    state_code = {s: i for i, s in enumerate(dev.WC_STATES)}
+    exp_a = [[s.variance_components[0] for s in res.site_fst]]
+    exp_b = [[s.variance_components[1] for s in res.site_fst]]
+    exp_s = [[state_code[s.overall_fst.state] for s in res.site_fst]]
+    for k in keys:
+        exp_a.append([s.pairwise_variance_components.get(k, (0.0, 0.0))[0] for s in res.site_fst])
+        exp_b.append([s.pairwise_variance_components.get(k, (0.0, 0.0))[1] for s in res.site_fst])
+        exp_s.append([state_code[s.pairwise_fst[k].state] if k in s.pairwise_fst else 3 for s in res.site_fst])
+    for slot in range(1 + len(keys)):
+        assert np.array_equal(w.state[slot], np.array(exp_s[slot], dtype=np.uint8)), f"state slot {slot}"
+        H.assert_bits_equal(w.a[slot], exp_a[slot], f"a slot {slot}")
+        H.assert_bits_equal(w.b[slot], exp_b[slot], f"b slot {slot}")
+    for gi, label in enumerate(mem.labels):
+        exp_n = [s.population_sizes.get(label, 0) for s in res.site_fst]
+        assert np.array_equal(w.group_called[gi], np.array(exp_n, dtype=np.uint32))
+    # regional: sums in site order vs GPU tree order -> 1e-9
+    est = [res.overall_fst] + [res.pairwise_fst[k] for k in keys]
+    for slot, e in enumerate(est):
+        if e.state == "insufficient_data_for_estimation":
+            assert w.informative_sites[slot] == 0
+            continue
+        assert w.informative_sites[slot] == e.sites
+        assert H.rel_close(float(w.sum_a[slot]), e.sum_a)
+        assert H.rel_close(float(w.sum_b[slot]), e.sum_b)
+
+
+def test_row_ranges_and_empty(dev):
+    rng = np.random.default_rng(5)
+    m = H.random_dense_matrix(rng, 500, 24, 2, 1, 0.0)
+    dm = upload(dev, m)
+    g = dev.Groups.from_haplotype_lists(dm, [H.haps_for_samples(range(12)), H.haps_for_samples(range(12, 24))])
+    full = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
+    a = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE, 0, 123)
+    b = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE, 123, 377)
+    H.assert_bits_equal(np.concatenate([a.sites["fst"], b.sites["fst"]]), full.sites["fst"], "fst split")
+    for k in ("numerator_sum", "denominator_sum", "site_num_sum", "dxy_sum_all"):
+        assert H.rel_close(a.totals[k] + b.totals[k], full.totals[k])
+    assert a.pop[0]["segregating_sites"] + b.pop[0]["segregating_sites"] == full.pop[0]["segregating_sites"]
+    empty = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE, 10, 0)
+    assert empty.totals["denominator_sum"] == 0.0 and empty.sites["fst"].size == 0
+    from ferromic_amd import _abi
+
+    with pytest.raises(_abi.FerromicHipError):
+        dev.hudson_sweep(dm, g, dev.FORMULA_DENSE, 400, 200)
+
+
+def test_generator_matches_host_hash(dev):
+    """The on-device synthetic cohort equals the same counter-based stream evaluated on the host."""
+    S, N = 200, 33
+    dm = dev.DeviceMatrix.alloc(S, N, 2, True)
+    rng = np.random.default_rng(1)
+    thr = (rng.random((2, S)) * (1 << 24)).astype(np.uint32)
+    poc = np.repeat(np.arange(N) >= N // 2, 2).astype(np.uint8)
+    dm.generate(1234, 77, thr, poc, missing_threshold24=int(0.05 * (1 << 24)))
+    data, words = dm.download()
+    data = data.reshape(S, 2 * N)
+
+    def hash24(seed, site, col):
+        M = (1 << 64) - 1
+        z = (seed + 0x9E3779B97F4A7C15 * ((site * 0x100000001B3 + col + 1) & M)) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z = z ^ (z >> 31)
+        return z >> 40
+
+    for s in (0, 1, 57, 199):
+        for h in (0, 1, 31, 32, 65):
+            miss = hash24(1234 ^ 0xA5A5A5A5DEADBEEF, 77 + s, h) < int(0.05 * (1 << 24))
+            bit = 1 if hash24(1234, 77 + s, h) < int(thr[poc[h], s]) else 0
+            idx = s * 2 * N + h
+            got_miss = (int(words[idx >> 6]) >> (idx & 63)) & 1
+            assert got_miss == int(miss)
+            assert data[s, h] == (0 if miss else bit)
