@@ -95,3 +95,14 @@ def rel_close(a: float, b: float, rel: float = 1e-9, abs_tol: float = 1e-12) -> 
     if math.isnan(a) or math.isnan(b):
         return math.isnan(a) and math.isnan(b)
     return math.isclose(a, b, rel_tol=rel, abs_tol=abs_tol)
+
+
+def assert_close_rel(actual: np.ndarray, expected: Sequence[float], what: str, rel: float = 1e-12):
+    exp = np.array(expected, dtype=np.float64)
+    a = np.asarray(actual, dtype=np.float64)
+    assert a.shape == exp.shape, what
+    assert np.array_equal(np.isnan(a), np.isnan(exp)), f"{what}: None pattern differs"
+    ok = np.isnan(a) | np.isclose(a, exp, rtol=rel, atol=1e-15)
+    if not ok.all():
+        i = int(np.argmin(ok))
+        raise AssertionError(f"{what}: first mismatch at {i}: gpu={a[i]!r} oracle={exp[i]!r}")
