@@ -568,7 +568,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   }
 #undef CASE
   FMH_TRY(rc);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(128), 0, st, w->part_f64, w->part_u64, grid, w->out_f64, w->out_u64);
+  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, w->part_f64, w->part_u64, grid, w->out_f64, w->out_u64);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(w->h_f64, w->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(w->h_u64, w->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));

@@ -781,21 +781,38 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   }
 }
 
-// Sum the per-block partials in block order (deterministic) into one vector each.
-__global__ __launch_bounds__(128) void finalize_kernel(const double* __restrict__ part_f64,
+// Sum the per-block partials into one vector each.  One workgroup per slot (128 slots); thread t adds
+// blocks t, t+256, ... in ascending order and the 256 thread sums are combined by a fixed LDS tree,
+// so the result is deterministic for a given grid size.
+__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ part_f64,
                                                        const unsigned long long* __restrict__ part_u64,
                                                        int nblocks, double* __restrict__ out_f64,
                                                        unsigned long long* __restrict__ out_u64) {
-  const int i = threadIdx.x;
-  if (i < kMaxF64) {
+  __shared__ double s_f[256];
+  __shared__ unsigned long long s_u[256];
+  const int slot = blockIdx.x;
+  const int t = threadIdx.x;
+  if (slot < kMaxF64) {
     double v = 0.0;
-    for (int b = 0; b < nblocks; ++b) v += part_f64[(size_t)b * kMaxF64 + i];
-    out_f64[i] = v;
+    for (int b = t; b < nblocks; b += 256) v += part_f64[(size_t)b * kMaxF64 + slot];
+    s_f[t] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) s_f[t] += s_f[t + w];
+      __syncthreads();
+    }
+    if (t == 0) out_f64[slot] = s_f[0];
   } else {
-    const int j = i - kMaxF64;
+    const int j = slot - kMaxF64;
     unsigned long long v = 0;
-    for (int b = 0; b < nblocks; ++b) v += part_u64[(size_t)b * kMaxU64 + j];
-    out_u64[j] = v;
+    for (int b = t; b < nblocks; b += 256) v += part_u64[(size_t)b * kMaxU64 + j];
+    s_u[t] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) s_u[t] += s_u[t + w];
+      __syncthreads();
+    }
+    if (t == 0) out_u64[j] = s_u[0];
   }
 }
 
