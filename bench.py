@@ -139,21 +139,14 @@ def main() -> int:
     bufs["called"] = device.DeviceBuffer(local_rank, 4 * 2 * S)
     sites = _abi.HudsonSites(None, bufs["dxy"].ptr, bufs["pi1"].ptr, bufs["pi2"].ptr, bufs["num"].ptr,
                              bufs["den"].ptr, bufs["alt"].ptr, bufs["called"].ptr)
-    totals = _abi.HudsonTotals()
-    f64 = (C.c_double * _abi.HUDSON_PACK_F64)()
-    u64 = (C.c_uint64 * _abi.HUDSON_PACK_U64)()
+    from ferromic_amd import sharding
+
+    state = {"totals": _abi.HudsonTotals()}
 
     def step():
-        _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(totals), None))
-        if dist is not None:
-            lib.fmh_hudson_totals_pack(C.byref(totals), f64, u64)
-            tf = torch.tensor(list(f64), dtype=torch.float64, device="cuda")
-            tu = torch.tensor([int(x) for x in u64], dtype=torch.int64, device="cuda")
-            dist.all_reduce(tf)
-            dist.all_reduce(tu)
-            f2 = (C.c_double * _abi.HUDSON_PACK_F64)(*tf.cpu().tolist())
-            u2 = (C.c_uint64 * _abi.HUDSON_PACK_U64)(*tu.cpu().tolist())
-            lib.fmh_hudson_totals_unpack(C.byref(totals), f2, u2)
+        local = _abi.HudsonTotals()
+        _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
+        state["totals"] = sharding.allreduce_hudson_totals(local, dist, "cuda") if dist is not None else local
 
     def fence():
         if dist is not None:
@@ -180,6 +173,7 @@ def main() -> int:
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    totals = state["totals"]
     total_sites = S * world
     value = total_sites * args.steps / elapsed
     b_site = H + W_OUT_HUDSON

@@ -1,0 +1,68 @@
+"""World-size-2 rehearsal of the region-sharded path on CPU (gloo): every rank computes the regional
+accumulators of ITS slab (here with the oracle, since no GPU exists in this container), the ranks
+combine them through ferromic_amd.sharding.allreduce_hudson_totals — the exact code bench.py runs
+over RCCL — and rank 0 checks the result against the unsharded cohort."""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+
+    from ferromic_amd import _abi, sharding
+    from oracle import dense as D
+
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    S, Hcols, seed = 3001, 64, 4242
+    rng = np.random.default_rng(seed)
+    thr = (np.clip(rng.beta(0.8, 0.8, size=(1, S)) + np.array([[0.03], [-0.03]]), 0.001, 0.999) * (1 << 24)).astype(np.uint32)
+    poc = (np.arange(Hcols) >= Hcols // 2).astype(np.uint8)
+    off1 = np.nonzero(poc == 0)[0]
+    off2 = np.nonzero(poc == 1)[0]
+
+    def totals_of(begin, end):
+        data, words = D.generate(end - begin, Hcols, seed, begin, np.ascontiguousarray(thr[:, begin:end]), poc,
+                                 int(0.03 * (1 << 24)), 2)
+        out = D.hudson_sweep(data, words, end - begin, Hcols, off1, off2, 2, want_sites=False)
+        t = _abi.HudsonTotals()
+        for k, v in out.totals.items():
+            setattr(t, k, v)
+        for p in range(2):
+            for k, v in out.pop[p].items():
+                setattr(t.pop[p], k, v)
+        return t
+
+    begin, end = sharding.slab_for_rank(S, rank, world)
+    merged = sharding.allreduce_hudson_totals(totals_of(begin, end), dist, "cpu")
+    if rank == 0:
+        whole = totals_of(0, S)
+        for k, _ in _abi.HudsonTotals._fields_:
+            if k == "pop":
+                continue
+            a, b = getattr(merged, k), getattr(whole, k)
+            if isinstance(a, int):
+                assert a == b, (k, a, b)
+            else:
+                assert abs(a - b) <= 1e-9 * max(abs(b), 1e-12), (k, a, b)
+        for p in range(2):
+            assert merged.pop[p].segregating_sites == whole.pop[p].segregating_sites
+            assert merged.pop[p].uncallable_sites == whole.pop[p].uncallable_sites
+            assert merged.pop[p].haplotype_capacity == whole.pop[p].haplotype_capacity == Hcols // 2
+            assert abs(merged.pop[p].pi_sum - whole.pop[p].pi_sum) <= 1e-9 * whole.pop[p].pi_sum
+        covered = sum(sharding.slab_for_rank(S, r, world)[1] - sharding.slab_for_rank(S, r, world)[0] for r in range(world))
+        assert covered == S
+        print(f"GLOO_SHARDING_OK world={world} fst={merged.numerator_sum / merged.denominator_sum:.12f}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
