@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libferromic_hip.so")
+LIB_PATH = os.environ.get("FMH_LIB_PATH") or os.path.join(_HERE, "lib", "libferromic_hip.so")
 
 FMH_OK = 0
 FMH_ERR_INVALID = 1

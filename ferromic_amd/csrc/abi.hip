@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -157,8 +158,9 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
   m->samples = samples;
   m->ploidy = ploidy;
   m->columns = (uint32_t)(samples * ploidy);
-  m->pitch = round_up(m->columns, 16);
-  m->nvec = (uint32_t)(m->pitch / 16);
+  static const int env_align = getenv("FMH_PITCH_ALIGN") ? atoi(getenv("FMH_PITCH_ALIGN")) : 16;
+  m->pitch = round_up(m->columns, env_align >= 16 && env_align % 16 == 0 ? env_align : 16);
+  m->nvec = (uint32_t)(round_up(m->columns, 16) / 16);
   m->bits_pitch = with_missing ? round_up(m->pitch / 8, 4) : 0;
   m->max_allele = max_allele;
   const size_t bytes = variants * m->pitch;
@@ -488,6 +490,8 @@ static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStrea
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, smem));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
+    static const int env_occ = getenv("FMH_MAX_OCC") ? atoi(getenv("FMH_MAX_OCC")) : 0;
+    if (env_occ > 0 && occ > env_occ) occ = env_occ;
     cached_occ[dev] = occ;
     cached_smem[dev] = smem;
   }
@@ -547,7 +551,10 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   const bool missing = m->bits != nullptr;
   const bool general = m->max_allele > 1;
   const int P = g->padded;
-  const size_t smem = (size_t)P * m->nvec * 16;
+  static const int env_unroll = getenv("FMH_UNROLL") ? atoi(getenv("FMH_UNROLL")) : 0;
+  a.unroll = env_unroll == 8 ? 8 : 4;
+  a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
+  const size_t smem = (size_t)P * a.nvec_pad * 16;
   if (smem > 150 * 1024) return fail(FMH_ERR_UNSUPPORTED, "P=%d masks of %u columns need %zu B of LDS (> 150 KiB)", P, m->columns, smem);
   int grid = 0;
   int rc = FMH_ERR_UNSUPPORTED;

@@ -48,6 +48,8 @@ struct SweepArgs {
   MatrixView mv;
   const uint8_t* masks;   // device [P][pitch] 0/1 bytes
   uint32_t group_size[8]; // mask popcounts
+  uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
+  int unroll;             // vectors per lane issued back to back (4 or 8)
   int n_groups;           // caller's group count (<= kernel P; padded groups are never reported)
   size_t row_begin;
   size_t row_count;
@@ -288,6 +290,9 @@ __device__ __forceinline__ void wc_add_allele(const uint32_t (&n)[P], const uint
 // ------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint4 load_vec(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// streaming (read-once) genotype loads.  Default cache policy on purpose: nontemporal loads measured
+// 4-6 % SLOWER on this sweep (profiles/r01/ab_variants.txt).
+__device__ __forceinline__ uint4 load_stream(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
 __device__ __forceinline__ uint4 called_bytes(uint32_t bits16) {
   uint4 v;
@@ -299,28 +304,40 @@ __device__ __forceinline__ uint4 called_bytes(uint32_t bits16) {
 }
 
 // Biallelic row: alt[p] = sum of allele bytes over called members, n[p] = called members.
-template <int P, bool MISSING, bool NEED_ALL>
+// The row is consumed in batches of U vectors per lane: the U global loads are issued back to back
+// (U KiB in flight per wave) before the first dot4, so memory-level parallelism does not depend on
+// occupancy alone.  LDS masks are zero-padded to nvec_pad (a multiple of 16*U) and the load address
+// is clamped to the last vector of the row, so the loop is uniform and branch-free.
+template <int P, bool MISSING, bool NEED_ALL, int U>
 __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const uint4* __restrict__ lds_mask,
-                                                    const uint8_t* __restrict__ row_ptr,
-                                                    const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
+                                                    uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
+                                                    const uint8_t* __restrict__ bits_ptr, int gl,
                                                     uint32_t (&alt)[P], uint32_t (&n)[P], uint32_t& n_all) {
 #pragma unroll
   for (int p = 0; p < P; ++p) { alt[p] = 0; n[p] = 0; }
   n_all = 0;
-  const uint32_t nvec = mv.nvec;
-  if (row_ok) {
-#pragma unroll 4
-    for (uint32_t v = gl; v < nvec; v += 16) {
-      uint4 g = load_vec(row_ptr + (size_t)v * 16);
+  const uint32_t last = mv.nvec - 1;
+  for (uint32_t v0 = gl; v0 < nvec_pad; v0 += 16 * U) {
+    uint4 g[U];
+    uint32_t bits16[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = v0 + 16 * u;
+      const uint32_t vc = v < last ? v : last;
+      g[u] = load_stream(row_ptr + (size_t)vc * 16);
+      if (MISSING) bits16[u] = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)vc * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = v0 + 16 * u;
       uint4 cb;
       if (MISSING) {
-        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)v * 2);
-        cb = called_bytes(bits16);
-        if (NEED_ALL) n_all += __builtin_popcount(bits16);
+        cb = called_bytes(bits16[u]);
+        if (NEED_ALL) n_all += v <= last ? __builtin_popcount(bits16[u]) : 0;
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        uint4 m = lds_mask[(uint32_t)p * nvec + v];
+        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
         if (MISSING) {
           m.x &= cb.x; m.y &= cb.y; m.z &= cb.z; m.w &= cb.w;
           n[p] = dot4(m.x, 0x01010101u, n[p]);
@@ -328,10 +345,10 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
           n[p] = dot4(m.z, 0x01010101u, n[p]);
           n[p] = dot4(m.w, 0x01010101u, n[p]);
         }
-        alt[p] = dot4(g.x, m.x, alt[p]);
-        alt[p] = dot4(g.y, m.y, alt[p]);
-        alt[p] = dot4(g.z, m.z, alt[p]);
-        alt[p] = dot4(g.w, m.w, alt[p]);
+        alt[p] = dot4(g[u].x, m.x, alt[p]);
+        alt[p] = dot4(g[u].y, m.y, alt[p]);
+        alt[p] = dot4(g[u].z, m.z, alt[p]);
+        alt[p] = dot4(g[u].w, m.w, alt[p]);
       }
     }
   }
@@ -346,7 +363,7 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
 // General row, pass 0: n[p], n_all and an upper bound (bitwise OR) of the called allele values.
 template <int P, bool MISSING>
 __device__ __forceinline__ void count_row_called(const MatrixView& mv, const uint4* __restrict__ lds_mask,
-                                                 const uint8_t* __restrict__ row_ptr,
+                                                 uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
                                                  const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
                                                  uint32_t (&n)[P], uint32_t& n_all, uint32_t& allele_or) {
 #pragma unroll
@@ -370,7 +387,7 @@ __device__ __forceinline__ void count_row_called(const MatrixView& mv, const uin
       if (MISSING) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          uint4 m = lds_mask[(uint32_t)p * nvec + v];
+          uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];
           n[p] = dot4(m.x & cb.x, 0x01010101u, n[p]);
           n[p] = dot4(m.y & cb.y, 0x01010101u, n[p]);
           n[p] = dot4(m.z & cb.z, 0x01010101u, n[p]);
@@ -390,7 +407,7 @@ __device__ __forceinline__ void count_row_called(const MatrixView& mv, const uin
 // General row, pass per allele value a: c[p] = called members carrying allele a.
 template <int P, bool MISSING>
 __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uint4* __restrict__ lds_mask,
-                                                 const uint8_t* __restrict__ row_ptr,
+                                                 uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
                                                  const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
                                                  uint32_t a, uint32_t (&c)[P]) {
 #pragma unroll
@@ -410,7 +427,7 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uin
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        uint4 m = lds_mask[(uint32_t)p * nvec + v];
+        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];
         c[p] = dot4(e.x, m.x, c[p]);
         c[p] = dot4(e.y, m.y, c[p]);
         c[p] = dot4(e.z, m.z, c[p]);
@@ -620,10 +637,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   const MatrixView mv = A.mv;
   const uint32_t nvec = mv.nvec;
 
-  // stage the P membership masks into LDS (16 B per thread per step)
-  for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec; i += kBlock) {
-    const uint32_t p = i / nvec, v = i - p * nvec;
-    lds_mask[i] = load_vec(A.masks + (size_t)p * mv.pitch + (size_t)v * 16);
+  // stage the P membership masks into LDS (16 B per thread per step), zero-padded to nvec_pad
+  const uint32_t nvec_pad = A.nvec_pad;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec_pad; i += kBlock) {
+    const uint32_t p = i / nvec_pad, v = i - p * nvec_pad;
+    lds_mask[i] = v < nvec ? load_vec(A.masks + (size_t)p * mv.pitch + (size_t)v * 16) : make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
 
@@ -655,14 +673,16 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
     for (int s = 0; s < 16; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * 16 + s;
       const bool row_ok = rel < A.row_count;
-      const size_t row = A.row_begin + rel;
+      const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);
       const uint8_t* row_ptr = mv.data + row * mv.pitch;
       const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
       const bool own = gl == s;
 
       if constexpr (!GENERAL) {
         uint32_t alt[P], n[P], n_all;
-        count_row_biallelic<P, MISSING, NEED_ALL>(mv, lds_mask, row_ptr, bits_ptr, row_ok, gl, alt, n, n_all);
+        // rows past the end are clamped to the last row (their results are discarded by row_ok)
+        if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+        else count_row_biallelic<P, MISSING, NEED_ALL, 4>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
         if (own) {
 #pragma unroll
           for (int p = 0; p < P; ++p) {
@@ -673,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         }
       } else {
         uint32_t n[P], n_all, aor;
-        count_row_called<P, MISSING>(mv, lds_mask, row_ptr, bits_ptr, row_ok, gl, n, n_all, aor);
+        count_row_called<P, MISSING>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, n, n_all, aor);
         if (!MISSING) {
 #pragma unroll
           for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
@@ -697,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         }
         for (uint32_t a = 0; a <= bound; ++a) {
           uint32_t c[P];
-          count_row_allele<P, MISSING>(mv, lds_mask, row_ptr, bits_ptr, row_ok, gl, a, c);
+          count_row_allele<P, MISSING>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
           if (own) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {

@@ -1,0 +1,147 @@
+"""Parity at BASELINE.json's sizes.  C2 (1 M sites x 1 000 haplotypes) is compared in full with the
+C oracle; at C4 width (5 000 haplotypes, 2 M sites = 10 GB) the checks are the size-independent
+properties the domain offers — additivity over genomic slabs, symmetry under population swap, track
+checksums against the regional accumulators — plus an oracle comparison on a slab in the middle of
+the cohort regenerated on the host from the same counter-based stream."""
+
+import numpy as np
+import pytest
+
+from oracle import dense as D
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ferromic_amd import device
+
+    return device
+
+
+def thresholds(S, seed, sigma=0.05):
+    rng = np.random.default_rng(seed)
+    base = rng.beta(0.8, 0.8, size=S)
+    div = rng.normal(0.0, sigma, size=S)
+    thr = (np.stack([np.clip(base + div, 0.001, 0.999), np.clip(base - div, 0.001, 0.999)]) * (1 << 24)).astype(np.uint32)
+    thr[0, 0], thr[1, 0] = 0, 1 << 24
+    return thr
+
+
+def two_pops(N):
+    poc = np.repeat((np.arange(N) >= N // 2).astype(np.uint8), 2)
+    return poc, np.stack([poc == 0, poc == 1]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("missing", [0.0, 0.01])
+def test_c2_full_against_c_oracle(dev, missing):
+    S, N = 1_000_000, 500
+    seed = S + N
+    thr = thresholds(S, seed)
+    poc, masks = two_pops(N)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=missing > 0)
+    mt = int(missing * (1 << 24))
+    dm.generate(seed, 0, thr, poc, mt)
+    g = dev.Groups(dm, masks)
+    got = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
+    data, words = dm.download()
+    # the host generator is the same stream
+    hdata, hwords = D.generate(S, 2 * N, seed, 0, thr, poc, mt, 16)
+    assert np.array_equal(data, hdata)
+    if missing > 0:
+        assert np.array_equal(words, hwords)
+    off1 = np.nonzero(poc == 0)[0]
+    off2 = np.nonzero(poc == 1)[0]
+    exp = D.hudson_sweep(data, words, S, 2 * N, off1, off2, 16)
+    assert np.array_equal(got.sites["alt"], exp.alt)            # bit-exact integer tracks
+    assert np.array_equal(got.sites["called"], exp.called)
+    for name in ("fst", "dxy", "pi1", "pi2", "num", "den"):        # bit-exact f64 tracks
+        H.assert_bits_equal(got.sites[name], getattr(exp, name), name)
+    for p in range(2):
+        assert got.pop[p]["segregating_sites"] == exp.pop[p]["segregating_sites"]
+        assert got.pop[p]["uncallable_sites"] == exp.pop[p]["uncallable_sites"]
+    for k in ("numerator_sum", "denominator_sum", "pi1_sum", "pi2_sum", "dxy_sum_all", "site_num_sum", "site_den_sum"):
+        assert H.rel_close(got.totals[k], exp.totals[k]), k
+    assert got.totals["dxy_uncallable_sites"] == exp.totals["dxy_uncallable_sites"]
+    assert got.totals["sites_with_components"] == exp.totals["sites_with_components"]
+    # summaries entry point agrees with the fused sweep (FORMULA_SUMMARY pi == dense_pi_from_counts)
+    s = dev.population_summaries(dm, g, dev.FORMULA_SUMMARY, want_sites=False)
+    for p in range(2):
+        assert s.totals[p]["segregating_sites"] == exp.pop[p]["segregating_sites"]
+        assert H.rel_close(s.totals[p]["pi_sum"], exp.pop[p]["pi_sum"])
+
+
+def test_c4_width_properties(dev):
+    S, N = 2_000_000, 2500
+    seed = 10_002_500
+    thr = thresholds(S, seed)
+    poc, masks = two_pops(N)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
+    dm.generate(seed, 0, thr, poc, 0)
+    g = dev.Groups(dm, masks)
+    full = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
+    t = full.totals
+
+    # (1) additivity over uneven genomic slabs (what region sharding relies on)
+    cuts = [0, 333_337, 1_250_001, S]
+    parts = [dev.hudson_sweep(dm, g, dev.FORMULA_DENSE, a, b - a, want_sites=False) for a, b in zip(cuts, cuts[1:])]
+    for k, v in t.items():
+        tot = sum(p.totals[k] for p in parts)
+        assert (tot == v) if isinstance(v, int) else H.rel_close(tot, v), k
+    for p in range(2):
+        assert sum(x.pop[p]["segregating_sites"] for x in parts) == full.pop[p]["segregating_sites"]
+
+    # (2) symmetry: swapping the populations swaps pi and leaves Dxy / FST / components bit-identical
+    sw = dev.hudson_sweep(dm, dev.Groups(dm, masks[::-1].copy()), dev.FORMULA_DENSE)
+    H.assert_bits_equal(sw.sites["pi1"], full.sites["pi2"], "pi swap")
+    H.assert_bits_equal(sw.sites["dxy"], full.sites["dxy"], "dxy swap")
+    H.assert_bits_equal(sw.sites["fst"], full.sites["fst"], "fst swap")
+    assert np.array_equal(sw.sites["alt"][0], full.sites["alt"][1])
+
+    # (3) checksums of the tracks against the regional accumulators
+    assert H.rel_close(float(np.nansum(full.sites["num"])), t["site_num_sum"])
+    assert H.rel_close(float(np.nansum(full.sites["den"])), t["site_den_sum"])
+    assert H.rel_close(float(np.nansum(full.sites["pi1"])), full.pop[0]["pi_sum"])
+    a, n = full.sites["alt"].astype(np.int64), full.sites["called"].astype(np.int64)
+    assert (n == 2500).all() and (a <= n).all()
+    assert int(((a[0] > 0) & (a[0] < n[0])).sum()) == full.pop[0]["segregating_sites"]
+    assert full.sites["fst"][0] == 1.0 and full.sites["dxy"][0] == 1.0  # forced informative first row
+    # Hudson identities per site: num == dxy - (pi1+pi2)/2 exactly as computed, fst*den == num
+    np.testing.assert_array_equal(full.sites["num"], full.sites["dxy"] - 0.5 * (full.sites["pi1"] + full.sites["pi2"]))
+
+    # (4) a slab in the middle of the cohort against the oracle (regenerated on the host)
+    b, e = 1_234_000, 1_254_000
+    hdata, _ = D.generate(e - b, 2 * N, seed, b, np.ascontiguousarray(thr[:, b:e]), poc, 0, 16)
+    exp = D.hudson_sweep(hdata, None, e - b, 2 * N, np.nonzero(poc == 0)[0], np.nonzero(poc == 1)[0], 16)
+    assert np.array_equal(full.sites["alt"][:, b:e], exp.alt)
+    for name in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+        H.assert_bits_equal(full.sites[name][b:e], getattr(exp, name), name)
+
+
+def test_c3_wc_four_populations_properties(dev):
+    """W&C at C3 width (2 500 haplotypes, 4 populations): pair (i, j) of the 4-group sweep equals a
+    2-group sweep of just those groups; regional sums equal the track sums."""
+    S, N, P = 300_000, 1250, 4
+    seed = 5_001_250
+    base = thresholds(S, seed)
+    thr = np.stack([base[p % 2] for p in range(P)])
+    pop_of_sample = np.minimum(np.arange(N) * P // N, P - 1).astype(np.uint8)
+    poc = np.repeat(pop_of_sample, 2)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=True)
+    dm.generate(seed, 0, thr, poc, int(0.02 * (1 << 24)))
+    masks = np.stack([poc == p for p in range(P)]).astype(np.uint8)
+    w4 = dev.wc_sweep(dm, dev.Groups(dm, masks))
+    pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
+    for k, (i, j) in enumerate(pairs, start=1):
+        if (i, j) not in ((0, 1), (1, 3)):
+            continue
+        w2 = dev.wc_sweep(dm, dev.Groups(dm, masks[[i, j]]))
+        H.assert_bits_equal(w4.a[k], w2.a[0], f"pair {i}{j} a")   # overall of the 2-group sweep == that pair
+        H.assert_bits_equal(w4.b[k], w2.b[1], f"pair {i}{j} b")
+        assert np.array_equal(w4.state[k], w2.state[0])
+    for slot in range(1 + len(pairs)):
+        ok = w4.state[slot] != 3
+        assert int(ok.sum()) == int(w4.informative_sites[slot])
+        assert H.rel_close(float(w4.a[slot][ok].sum()), float(w4.sum_a[slot]))
+        assert H.rel_close(float(w4.b[slot][ok].sum()), float(w4.sum_b[slot]))

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Measure the sweeps on the BASELINE configurations other than the bench default (C2, C3, C4 with
+1 % missing data, C5) and print one JSON line per configuration.  Development tool: bench.py is the
+contractual benchmark; these are the rows of the table in DESIGN.md."""
+
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from bench import synthetic_thresholds  # noqa: E402
+from ferromic_amd import _abi, device  # noqa: E402
+
+CONFIGS = {
+    # name: (sites, haplotypes, populations, kind, missing_rate)
+    "C2": (1_000_000, 1_000, 2, "hudson", 0.0),
+    "C3": (5_000_000, 2_500, 4, "wc", 0.0),
+    "C4": (10_000_000, 5_000, 2, "hudson", 0.0),
+    "C4m": (10_000_000, 5_000, 2, "hudson", 0.01),
+    "C5": (2_000_000, 10_000, 2, "hudson", 0.0),
+    "C3h": (5_000_000, 2_500, 4, "summaries", 0.0),
+}
+
+
+def main():
+    names = sys.argv[1:] or ["C2", "C3", "C4m", "C5"]
+    lib = _abi.load()
+    for name in names:
+        S, H, P, kind, miss = CONFIGS[name]
+        N = H // 2
+        seed = S + N
+        pop_of_sample = np.minimum(np.arange(N) * P // N, P - 1).astype(np.uint8)
+        poc = np.repeat(pop_of_sample, 2)
+        base = synthetic_thresholds(S, 0, S, seed)
+        thr = np.stack([base[p % 2] for p in range(P)])
+        dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=miss > 0, max_allele=1)
+        dm.generate(seed, 0, thr, poc, int(miss * (1 << 24)))
+        masks = np.stack([(poc == p) for p in range(P)]).astype(np.uint8)
+        g = device.Groups(dm, masks)
+        bufs = []
+
+        def buf(nbytes):
+            b = device.DeviceBuffer(0, nbytes)
+            bufs.append(b)
+            return b.ptr
+
+        if kind == "hudson":
+            sites = _abi.HudsonSites(None, buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S))
+            tot = _abi.HudsonTotals()
+            w_out = 56
+
+            def step():
+                _abi.check(lib.fmh_hudson_sweep(dm._h, g._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(tot), None))
+        elif kind == "wc":
+            nw = 1 + P * (P - 1) // 2
+            pa, pb, ps, pn = buf(8 * nw * S), buf(8 * nw * S), buf(nw * S), buf(4 * P * S)
+            tot = _abi.WcTotals()
+            w_out = nw * 17 + 4 * P  # a, b f64 + state u8 per slot, called u32 per group
+
+            def step():
+                _abi.check(lib.fmh_wc_sweep(dm._h, g._h, 0, S, pa, pb, ps, pn, C.byref(tot), None))
+        else:
+            pa, pc = buf(4 * P * S), buf(4 * P * S)
+            tot = (_abi.PopTotals * P)()
+            w_out = 8 * P
+
+            def step():
+                _abi.check(lib.fmh_population_summaries(dm._h, g._h, 0, S, _abi.FORMULA_SUMMARY, pa, pc, tot, None))
+
+        for _ in range(2):
+            step()
+        lib.fmh_timing_enable(1)
+        lib.fmh_timing_reset()
+        steps = 10
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        el = time.perf_counter() - t0
+        ms, n = C.c_double(), C.c_uint64()
+        lib.fmh_timing_read(C.byref(ms), C.byref(n))
+        lib.fmh_timing_enable(0)
+        b_site = H + (((H + 7) // 8) if miss > 0 else 0) + w_out
+        k_s = ms.value / 1e3 / n.value
+        print(json.dumps({"config": name, "sites": S, "haplotypes": H, "populations": P, "kind": kind, "missing": miss,
+                          "sites_per_s": S * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": k_s * 1e3,
+                          "bytes_per_site": b_site, "achieved_GBs": b_site * S / k_s / 1e9,
+                          "frac_of_8TBs": b_site * S / k_s / 8e12}), flush=True)
+        del bufs, g, dm
+
+
+if __name__ == "__main__":
+    main()
