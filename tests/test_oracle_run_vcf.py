@@ -1,0 +1,88 @@
+"""Pins the run_vcf half of the oracle (oracle/run_vcf_ref.py) against the reference's end-to-end
+tests (FALSTA zero fill, Hudson FALSTA tracks) and its output format exemplars."""
+
+import os
+
+import pytest
+
+from oracle import run_vcf_ref as V
+
+
+def write_case(tmp, k):
+    os.makedirs(tmp / "vcf", exist_ok=True)
+    (tmp / "vcf" / "chr1.vcf").write_text(k["vcf"])
+    (tmp / "reference.fa").write_text(k["fasta"])
+    (tmp / "reference.fa.fai").write_text(k["fai"])
+    (tmp / "annotations.gtf").write_text(k["gtf"])
+    (tmp / "config.tsv").write_text(k["config"])
+    return dict(vcf_folder=str(tmp / "vcf"), reference=str(tmp / "reference.fa"), gtf=str(tmp / "annotations.gtf"),
+                config_file=str(tmp / "config.tsv"), output_file=str(tmp / "out" / "results.csv"), enable_fst=k["enable_fst"])
+
+
+def track(text, header):
+    lines = text.splitlines()
+    return lines[lines.index(header) + 1].split(",")
+
+
+def test_falsta_zero_fill(tmp_path, kats):
+    k = kats["falsta_zero_fill"]
+    out = V.run(**write_case(tmp_path, k))
+    e = k["expect"]
+    for hdr in (e["pi_header"], e["theta_header"]):
+        vals = track(out["per_site_diversity_output.falsta.gz"], hdr)
+        assert len(vals) == e["length"]
+        assert all(vals[i] == "0" for i in e["zero_positions"])
+        assert all(vals[i] != "0" for i in e["nonzero_positions"])
+    csv = out["results.csv"].splitlines()
+    assert csv[0].split(",") == V.CSV_HEADER and len(V.CSV_HEADER) == 34
+    row = dict(zip(V.CSV_HEADER, csv[1].split(",")))
+    assert row["chr"] == "1" and row["region_start"] == "1" and row["region_end"] == "5"
+    assert row["0_segregating_sites"] == "1" and row["0_num_hap_no_filter"] == "2"
+    assert row["0_w_theta"] == "0.200000" and row["0_pi"] == "0.200000"   # S=1, n=2, L=5
+    assert row["hudson_fst_hap_group_0v1"] == "NA"
+    assert os.path.exists(tmp_path / "out" / "per_site_diversity_output.falsta.gz")
+
+
+def test_falsta_hudson_tracks(tmp_path, kats):
+    k = kats["falsta_hudson_tracks"]
+    out = V.run(**write_case(tmp_path, k))
+    e = k["expect"]
+    text = out["per_site_fst_output.falsta.gz"]
+    for hdr, key in ((e["fst_header"], "fst"), (e["num_header"], "num"), (e["den_header"], "den")):
+        vals = [float(x) for x in track(text, hdr)]
+        assert vals == pytest.approx(e[key], abs=e["abs_tol"])
+    hud = out["hudson_fst_results.tsv.gz"].splitlines()
+    assert hud[0].split("\t") == V.HUDSON_TSV_HEADER
+    f = hud[1].split("\t")
+    assert f[:7] == ["1", "0", "2", "HaplotypeGroup", "0", "HaplotypeGroup", "1"]
+    assert ">haplotype_overall_fst_summary_chr_1_start_1_end_3" in text
+
+
+def test_format_helpers_match_rust():
+    assert V.fmt6(0.1234565) == "0.123457" or V.fmt6(0.1234565) == "0.123456"  # exact-decimal rounding
+    assert V.fmt6(float("nan")) == "NaN" and V.fmt6(float("inf")) == "inf" and V.fmt6(-float("inf")) == "-inf"
+    assert V.format_optional_float(None) == "NA" and V.format_optional_float(float("nan")) == "NA"
+    assert V._falsta_value_fst(float("inf")) == "Infinity" and V._falsta_value_fst(-0.0) == "0"
+    assert V.fmt6(-0.0000001) == "-0.000000"
+
+
+def test_find_vcf_file_scoring(tmp_path):
+    for name in ("chr22.test.vcf", "chr2.other.vcf.gz", "chr22.vcf.gz.tbi", "x_chr22_y.vcf"):
+        (tmp_path / name).write_text("")
+    assert os.path.basename(V.find_vcf_file(str(tmp_path), "22")) == "chr22.test.vcf"
+    assert os.path.basename(V.find_vcf_file(str(tmp_path), "2")) == "chr2.other.vcf.gz"
+    with pytest.raises(Exception):
+        V.find_vcf_file(str(tmp_path), "7")
+
+
+def test_config_parsing_rules(tmp_path):
+    cfg = tmp_path / "c.tsv"
+    cfg.write_text("seqnames\tstart\tend\tPOS\torig_ID\tverdict\tcateg\tA\tB\tC\n"
+                   "chr3\t200100\t200900\t1\tid\tpass\tinv\t0|0_lowconf\t0|0_lowconf\t0|1\n"
+                   "chr1\t5\t9\t1\tid\tpass\tinv\t2|0\tx\t.\n")
+    entries = V.parse_config_file(str(cfg))
+    assert len(entries) == 1  # second row has no valid unfiltered genotype -> skipped (parse.rs:206-215)
+    e = entries[0]
+    assert e.seqname == "3" and e.interval == (200099, 200900)
+    assert e.samples_unfiltered == {"A": (0, 0), "B": (0, 0), "C": (0, 1)}
+    assert e.samples_filtered == {"C": (0, 1)}  # suffixed genotypes are not exact matches
