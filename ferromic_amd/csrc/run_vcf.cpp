@@ -1,0 +1,1252 @@
+// run_vcf — MI355X-native drop-in for the reference's `run_vcf` CLI (src/run_vcf.rs) on the
+// per-site diversity / FST path: same flags (process.rs:67-144), same output surface
+// (output.csv 34 columns, per_site_diversity_output.falsta.gz, per_site_fst_output.falsta.gz,
+// hudson_fst_results.tsv.gz).  Host C++ does text ingest (config TSV, BED/TSV regions, FASTA index,
+// VCF) and the writers; every statistic over genotype data is computed on the GPU through the
+// C-ABI of libferromic_hip.so.  PHYLIP / CDS export and PCA are outside the path.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <optional>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/ferromic_hip.h"
+
+namespace {
+
+using std::string;
+using std::vector;
+typedef std::pair<int64_t, int64_t> Interval;  // 0-based half-open unless said otherwise
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+void logmsg(const char* level, const string& m) {
+  static const bool quiet = getenv("FERROMIC_PROGRESS") && string(getenv("FERROMIC_PROGRESS")) == "0";
+  if (!quiet || string(level) != "INFO") fprintf(stderr, "[%s] %s\n", level, m.c_str());
+}
+
+void fmh_check(int status, const char* what) {
+  if (status != FMH_OK) throw Error(string(what) + ": " + fmh_last_error());
+}
+
+// ---- small string helpers ------------------------------------------------------------------------
+vector<string> split(const string& s, char d) {
+  vector<string> out;
+  size_t b = 0;
+  for (;;) {
+    size_t e = s.find(d, b);
+    if (e == string::npos) { out.push_back(s.substr(b)); break; }
+    out.push_back(s.substr(b, e - b));
+    b = e + 1;
+  }
+  return out;
+}
+vector<string> split_ws(const string& s) {
+  vector<string> out;
+  std::istringstream is(s);
+  string t;
+  while (is >> t) out.push_back(t);
+  return out;
+}
+string trim(const string& s) {
+  size_t b = 0, e = s.size();
+  while (b < e && isspace((unsigned char)s[b])) ++b;
+  while (e > b && isspace((unsigned char)s[e - 1])) --e;
+  return s.substr(b, e - b);
+}
+string trim_start_matches(string s, const string& p) {
+  while (s.compare(0, p.size(), p) == 0 && !p.empty()) s = s.substr(p.size());
+  return s;
+}
+bool ends_with(const string& s, const string& x) { return s.size() >= x.size() && s.compare(s.size() - x.size(), x.size(), x) == 0; }
+bool starts_with(const string& s, const string& x) { return s.compare(0, x.size(), x) == 0; }
+bool parse_i64(const string& s, int64_t* out) {
+  if (s.empty()) return false;
+  char* end = nullptr;
+  errno = 0;
+  long long v = strtoll(s.c_str(), &end, 10);
+  if (errno || *end) return false;
+  *out = v;
+  return true;
+}
+// Rust str::parse::<u8/u16>: optional '+', ASCII digits only
+bool parse_unsigned(const string& s, unsigned max, unsigned* out) {
+  size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
+  if (i >= s.size()) return false;
+  unsigned long v = 0;
+  for (; i < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    v = v * 10 + (s[i] - '0');
+    if (v > max) return false;
+  }
+  *out = (unsigned)v;
+  return true;
+}
+bool file_exists(const string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+bool is_dir(const string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+string dirname_of(const string& p) { size_t s = p.find_last_of('/'); return s == string::npos ? "." : (s == 0 ? "/" : p.substr(0, s)); }
+void mkdirs(const string& p) {
+  string cur;
+  for (const string& part : split(p, '/')) {
+    cur += part + "/";
+    if (!part.empty()) mkdir(cur.c_str(), 0777);
+  }
+}
+
+// ---- interval newtypes (process.rs:146-352) --------------------------------------------------------
+Interval from_1based_inclusive(int64_t s, int64_t e) {  // -> 0-based half-open (process.rs:193-206)
+  int64_t a = s < 1 ? 1 : s;
+  int64_t b = e < a ? a : e;
+  return {a - 1, b};
+}
+int64_t hal_len(const Interval& iv) { return (uint64_t)iv.second > (uint64_t)iv.first ? (int64_t)((uint64_t)iv.second - (uint64_t)iv.first) : 0; }
+bool hal_contains(const Interval& iv, int64_t pos) { return (uint64_t)pos >= (uint64_t)iv.first && (uint64_t)pos < (uint64_t)iv.second; }
+bool position_in_regions(int64_t pos, const vector<Interval>& r) {  // process.rs:738-744
+  for (auto& iv : r) if (pos >= iv.first && pos < iv.second) return true;
+  return false;
+}
+int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }  // release-build i64 wrap
+
+// ---- number formatting: Rust `{:.6}` ---------------------------------------------------------------
+string fmt6(double x) {
+  if (std::isnan(x)) return "NaN";
+  if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
+  char buf[64];
+  snprintf(buf, sizeof buf, "%.6f", x);
+  return buf;
+}
+string fmt_opt(const std::optional<double>& v) { return (!v || std::isnan(*v)) ? "NA" : fmt6(*v); }  // process.rs:3702-3713
+string falsta_div_value(double v) { return std::isnan(v) ? "NA" : (v == 0.0 ? "0" : fmt6(v)); }       // process.rs:3786-3792
+string falsta_fst_value(double v) {                                                                     // process.rs:3842-3856
+  if (std::isnan(v)) return "NA";
+  if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+  if (v == 0.0) return "0";
+  return fmt6(v);
+}
+
+// ---- data model (process.rs:397-536) --------------------------------------------------------------
+struct Variant {
+  int64_t position = 0;
+  vector<uint8_t> data;  // CompressedGenotypes: 0xFF sentinel
+  size_t stride = 0, num_samples = 0;
+  // genotype length of sample i (0 = None)
+  size_t glen(size_t i) const {
+    if (i >= num_samples || stride == 0) return 0;
+    size_t n = 0;
+    while (n < stride && data[i * stride + n] != 0xFF) ++n;
+    return n;
+  }
+};
+
+typedef vector<std::pair<string, std::pair<uint8_t, uint8_t>>> SampleMap;  // insertion-ordered, unique keys
+
+struct ConfigEntry {
+  string seqname;
+  Interval interval;  // 0-based half-open
+  SampleMap samples_unfiltered, samples_filtered;
+};
+
+enum : uint8_t { FLAG_PASS = 0, FLAG_MASK = 1, FLAG_ALLOW = 2, FLAG_LOW_GQ = 4, FLAG_MISSING = 8 };
+
+typedef std::map<string, vector<Interval>> RegionMap;
+
+// ---- parse.rs ---------------------------------------------------------------------------------------
+RegionMap parse_regions_file(const string& path) {  // parse.rs:15-88
+  std::ifstream in(path);
+  if (!in) throw Error("cannot open regions file " + path);
+  const bool is_bed = ends_with(path, ".bed");
+  RegionMap regions;
+  string line;
+  while (std::getline(in, line)) {
+    vector<string> f = split_ws(line);
+    if (f.size() < 3) continue;
+    int64_t s, e;
+    if (!parse_i64(f[1], &s) || !parse_i64(f[2], &e)) continue;
+    regions[trim_start_matches(f[0], "chr")].push_back(is_bed ? Interval{s, e} : from_1based_inclusive(s, e));
+  }
+  for (auto& kv : regions) std::stable_sort(kv.second.begin(), kv.second.end(), [](const Interval& a, const Interval& b) { return (uint64_t)a.first < (uint64_t)b.first; });
+  return regions;
+}
+
+void sample_map_set(SampleMap& m, const string& k, uint8_t l, uint8_t r) {
+  for (auto& kv : m) if (kv.first == k) { kv.second = {l, r}; return; }
+  m.push_back({k, {l, r}});
+}
+
+vector<ConfigEntry> parse_config_file(const string& path) {  // parse.rs:91-239
+  std::ifstream in(path);
+  if (!in) throw Error("cannot open config file " + path);
+  string line;
+  vector<string> headers;
+  vector<ConfigEntry> entries;
+  size_t line_no = 0;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty()) continue;
+    ++line_no;
+    vector<string> rec = split(line, '\t');
+    if (headers.empty()) {
+      headers = rec;
+      if (headers.size() <= 7) throw Error("Parse(\"No sample names found in config file header.\")");
+      continue;
+    }
+    if (rec.size() != headers.size()) throw Error("Parse(\"Mismatched number of fields in record on line " + std::to_string(line_no) + "\")");
+    ConfigEntry e;
+    e.seqname = trim_start_matches(trim(rec[0]), "chr");
+    int64_t s, en;
+    if (!parse_i64(rec[1], &s)) throw Error("Parse(\"Invalid start\")");
+    if (!parse_i64(rec[2], &en)) throw Error("Parse(\"Invalid end\")");
+    e.interval = from_1based_inclusive(s, en);
+    for (size_t i = 7; i < rec.size(); ++i) {
+      const string& field = rec[i];
+      const string& name = headers[i];
+      const string g = split(field, '_')[0];
+      if (g.size() >= 3 && g[1] == '|' && isdigit((unsigned char)g[0]) && isdigit((unsigned char)g[2])) {
+        const int l = g[0] - '0', r = g[2] - '0';
+        if (l <= 1 && r <= 1) sample_map_set(e.samples_unfiltered, name, (uint8_t)l, (uint8_t)r);
+      }
+      if (field == "0|0" || field == "0|1" || field == "1|0" || field == "1|1")
+        sample_map_set(e.samples_filtered, name, (uint8_t)(field[0] - '0'), (uint8_t)(field[2] - '0'));
+    }
+    if (e.samples_unfiltered.empty()) continue;
+    entries.push_back(std::move(e));
+  }
+  if (headers.empty()) throw Error("empty config file");
+  return entries;
+}
+
+Interval parse_region(const string& r) {  // parse.rs:241-261
+  vector<string> p = split(r, '-');
+  int64_t s, e;
+  if (p.size() != 2) throw Error("InvalidRegion(\"Invalid region format. Use start-end\")");
+  if (!parse_i64(p[0], &s)) throw Error("InvalidRegion(\"Invalid start position\")");
+  if (!parse_i64(p[1], &e)) throw Error("InvalidRegion(\"Invalid end position\")");
+  if (s >= e) throw Error("InvalidRegion(\"Start position must be less than end position\")");
+  return from_1based_inclusive(s, e);
+}
+
+string find_vcf_file(const string& folder, const string& chr) {  // parse.rs:263-515
+  if (!is_dir(folder)) throw Error("VCF folder does not exist: " + folder);
+  for (const string& pat : {"chr" + chr + ".vcf.gz", "chr" + chr + ".vcf", chr + ".vcf.gz", chr + ".vcf"})
+    if (file_exists(folder + "/" + pat)) return folder + "/" + pat;
+  auto boundary_match = [&](const string& name) {
+    for (const string& pat : {"chr" + chr, chr}) {
+      size_t from = 0;
+      for (;;) {
+        size_t idx = name.find(pat, from);
+        if (idx == string::npos) break;
+        const bool after_ok = idx + pat.size() >= name.size() || !isdigit((unsigned char)name[idx + pat.size()]);
+        const bool before_ok = idx == 0 || !isdigit((unsigned char)name[idx - 1]);
+        if (after_ok && before_ok) return true;
+        from = idx + 1;
+      }
+    }
+    return false;
+  };
+  auto prefix_boundary = [](const string& name, const string& prefix) {
+    if (!starts_with(name, prefix)) return false;
+    return name.size() == prefix.size() || !isdigit((unsigned char)name[prefix.size()]);
+  };
+  vector<std::pair<int, string>> cands;
+  DIR* d = opendir(folder.c_str());
+  if (!d) throw Error("cannot read directory " + folder);
+  while (dirent* ent = readdir(d)) {
+    const string name = ent->d_name;
+    if (!(ends_with(name, ".vcf") || ends_with(name, ".vcf.gz"))) continue;
+    bool aux = false;
+    for (const char* x : {".csi", ".tbi", ".idx", ".md5", ".bai"}) aux |= ends_with(name, x);
+    if (aux || !boundary_match(name)) continue;
+    int score = 0;
+    if (name == "chr" + chr + ".vcf.gz") score += 100;
+    else if (name == "chr" + chr + ".vcf") score += 90;
+    else if (name == chr + ".vcf.gz") score += 80;
+    else if (name == chr + ".vcf") score += 70;
+    if (ends_with(name, ".vcf.gz")) score += 15;
+    if (prefix_boundary(name, "chr" + chr)) score += 10;
+    else if (prefix_boundary(name, chr)) score += 5;
+    score -= (int)(name.size() / 5);
+    cands.push_back({-score, folder + "/" + name});
+  }
+  closedir(d);
+  if (cands.empty()) throw Error("NoVcfFiles");
+  std::sort(cands.begin(), cands.end());
+  return cands[0].second;
+}
+
+// line reader over plain or (multi-member) gzip files
+struct LineReader {
+  gzFile f;
+  explicit LineReader(const string& path) : f(gzopen(path.c_str(), "rb")) {
+    if (!f) throw Error("cannot open " + path);
+    gzbuffer(f, 1 << 20);
+  }
+  ~LineReader() { if (f) gzclose(f); }
+  bool next(string& out) {
+    out.clear();
+    char buf[1 << 16];
+    for (;;) {
+      if (!gzgets(f, buf, sizeof buf)) return !out.empty();
+      out += buf;
+      if (!out.empty() && out.back() == '\n') return true;
+    }
+  }
+};
+
+struct FaiEntry { int64_t len, offset, line_bases, line_width; };
+
+std::map<string, FaiEntry> read_fai(const string& reference) {
+  std::ifstream in(reference + ".fai");
+  if (!in) throw Error("Failed to open reference index " + reference + ".fai");
+  std::map<string, FaiEntry> out;
+  string line;
+  while (std::getline(in, line)) {
+    vector<string> f = split(line, '\t');
+    if (f.size() < 5) continue;
+    FaiEntry e;
+    if (parse_i64(f[1], &e.len) && parse_i64(f[2], &e.offset) && parse_i64(f[3], &e.line_bases) && parse_i64(f[4], &e.line_width)) out[f[0]] = e;
+  }
+  return out;
+}
+
+string read_reference_sequence(const string& reference, const string& chr) {  // process.rs:1915-1952, parse.rs:545-650
+  auto fai = read_fai(reference);
+  auto it = fai.find(chr);
+  if (it == fai.end()) it = fai.find("chr" + chr);
+  if (it == fai.end()) throw Error("Chromosome " + chr + " not found in reference");
+  const FaiEntry& e = it->second;
+  std::ifstream in(reference, std::ios::binary);
+  if (!in) throw Error("Failed to open reference file " + reference);
+  string seq;
+  seq.reserve((size_t)e.len);
+  int64_t pos = 0;
+  vector<char> buf((size_t)std::max<int64_t>(e.line_bases, 1));
+  while (pos < e.len) {
+    const int64_t line_idx = pos / e.line_bases, col = pos % e.line_bases;
+    const int64_t take = std::min(e.line_bases - col, e.len - pos);
+    in.seekg(e.offset + line_idx * e.line_width + col);
+    in.read(buf.data(), take);
+    if (in.gcount() != take) throw Error("Failed to read sequence for " + chr);
+    seq.append(buf.data(), (size_t)take);
+    pos += take;
+  }
+  return seq;
+}
+
+vector<Interval> find_n_regions(const string& seq) {  // process.rs:1849-1874
+  vector<Interval> out;
+  bool in_n = false;
+  size_t start = 0;
+  for (size_t i = 0; i < seq.size(); ++i) {
+    const bool is_n = seq[i] == 'N' || seq[i] == 'n';
+    if (is_n && !in_n) { in_n = true; start = i; }
+    else if (!is_n && in_n) { in_n = false; out.push_back({(int64_t)start, (int64_t)i}); }
+  }
+  if (in_n) out.push_back({(int64_t)start, (int64_t)seq.size()});
+  return out;
+}
+
+vector<Interval> merge_intervals(vector<Interval> v) {  // process.rs:762-783
+  if (v.empty()) return v;
+  std::stable_sort(v.begin(), v.end(), [](const Interval& a, const Interval& b) { return (uint64_t)a.first < (uint64_t)b.first; });
+  vector<Interval> out;
+  Interval cur = v[0];
+  for (size_t i = 1; i < v.size(); ++i) {
+    if ((uint64_t)v[i].first <= (uint64_t)cur.second) cur.second = (int64_t)std::max((uint64_t)cur.second, (uint64_t)v[i].second);
+    else { out.push_back(cur); cur = v[i]; }
+  }
+  out.push_back(cur);
+  return out;
+}
+
+string normalize_chr_prefix(const string& c) {
+  for (const char* p : {"chr", "Chr", "CHR"}) if (starts_with(c, p)) return c.substr(3);
+  return c;
+}
+
+// process_variant, process.rs:4471-4768.  Returns false when the line yields no variant.
+bool process_variant(const string& line_in, const string& chr, const vector<Interval>& regions, const vector<size_t>& kept,
+                     unsigned min_gq, const RegionMap* allow, const RegionMap* mask, Variant* out, uint8_t* out_flags) {
+  string line = line_in;
+  vector<string> fields = split(line, '\t');
+  if (fields.size() < 9) throw Error("Invalid VCF line format");
+  size_t max_idx = 0;
+  for (size_t k : kept) max_idx = std::max(max_idx, k);
+  if (!kept.empty() && fields.size() <= max_idx) throw Error("Invalid VCF line format: missing genotype column");
+  const string vcf_chr = normalize_chr_prefix(trim(fields[0]));
+  if (vcf_chr != normalize_chr_prefix(trim(chr))) return false;
+  int64_t pos1;
+  if (!parse_i64(fields[1], &pos1)) throw Error("Invalid position");
+  if (pos1 < 1) throw Error("Invalid 1-based pos");
+  const int64_t pos0 = pos1 - 1;
+  bool in_regions = false;
+  for (auto& r : regions) if (hal_contains(r, pos0)) { in_regions = true; break; }
+  if (!in_regions) return false;
+  uint8_t flags = FLAG_PASS;
+  if (allow) {
+    auto it = allow->find(vcf_chr);
+    if (it != allow->end()) { if (!position_in_regions(pos0, it->second)) flags |= FLAG_ALLOW; }
+    else flags |= FLAG_ALLOW;
+  }
+  if (mask) {
+    auto it = mask->find(vcf_chr);
+    if (it != mask->end())
+      for (auto& m : it->second)
+        if (std::max<uint64_t>((uint64_t)pos0, (uint64_t)m.first) < std::min<uint64_t>((uint64_t)pos0 + 1, (uint64_t)m.second)) { flags |= FLAG_MASK; break; }
+  }
+  bool indel = fields[3].size() != 1;
+  if (!indel) for (const string& a : split(fields[4], ',')) if (a.size() != 1) indel = true;
+  vector<string> fmt = split(fields[8], ':');
+  size_t gq_index = fmt.size();
+  for (size_t i = 0; i < fmt.size(); ++i) if (fmt[i] == "GQ") { gq_index = i; break; }
+  if (gq_index == fmt.size()) throw Error("GQ field not found in FORMAT");
+  // the last kept column may carry the trailing newline
+  vector<std::optional<vector<uint8_t>>> raw;
+  raw.reserve(kept.size());
+  for (size_t idx : kept) {
+    const string& gt = fields[idx];
+    const string alleles = gt.substr(0, gt.find(':'));
+    if (alleles == "." || alleles == "./." || alleles == ".|.") { raw.push_back(std::nullopt); continue; }
+    vector<uint8_t> vals;
+    bool ok = true;
+    size_t b = 0;
+    for (size_t i = 0; i <= alleles.size(); ++i) {
+      if (i == alleles.size() || alleles[i] == '|' || alleles[i] == '/') {
+        unsigned v;
+        if (!parse_unsigned(alleles.substr(b, i - b), 255, &v)) { ok = false; break; }
+        vals.push_back((uint8_t)v);
+        b = i + 1;
+      }
+    }
+    if (ok) raw.push_back(std::move(vals)); else raw.push_back(std::nullopt);
+  }
+  bool low_gq = false, missing = false;
+  for (size_t i = 0; i < kept.size(); ++i) {
+    if (!raw[i]) { missing = true; continue; }
+    vector<string> parts = split(fields[kept[i]], ':');
+    if (gq_index >= parts.size()) throw Error("GQ value missing in sample genotype field");
+    const string gq_str = trim(parts[gq_index]);
+    unsigned gq = 0;
+    if (!(gq_str == "." || gq_str.empty())) { if (!parse_unsigned(gq_str, 65535, &gq)) gq = 0; }
+    if (gq < min_gq) low_gq = true;
+  }
+  if (low_gq) flags |= FLAG_LOW_GQ;
+  if (missing) flags |= FLAG_MISSING;
+  if (indel) return false;
+  // CompressedGenotypes::new, process.rs:440-477
+  size_t max_ploidy = 0;
+  for (auto& g : raw) if (g) max_ploidy = std::max(max_ploidy, g->size());
+  if (!raw.empty()) max_ploidy = std::max<size_t>(max_ploidy, 1);
+  out->position = pos0;
+  out->num_samples = raw.size();
+  out->stride = max_ploidy;
+  out->data.assign(raw.size() * max_ploidy, 0xFF);
+  for (size_t s = 0; s < raw.size(); ++s)
+    if (raw[s]) for (size_t k = 0; k < raw[s]->size() && k < max_ploidy; ++k) out->data[s * max_ploidy + k] = (*raw[s])[k];
+  *out_flags = flags;
+  return true;
+}
+
+struct VcfData {
+  vector<Variant> variants;
+  vector<uint8_t> flags;
+  vector<string> sample_names;
+};
+
+vector<string> read_sample_names_from_vcf(const string& path) {  // run_vcf.rs:190-214
+  LineReader r(path);
+  string line;
+  while (r.next(line)) {
+    if (starts_with(line, "#CHROM")) {
+      vector<string> f = split_ws(line);
+      if (f.size() <= 9) throw Error("VCF header found, but no sample columns");
+      return vector<string>(f.begin() + 9, f.end());
+    }
+  }
+  throw Error("No #CHROM line found in VCF header");
+}
+
+VcfData process_vcf(const string& path, const string& chr, const vector<Interval>& regions, unsigned min_gq,
+                    const RegionMap* mask, const RegionMap* allow, const std::set<string>& exclusion) {  // process.rs:4092-4469
+  VcfData d;
+  vector<size_t> kept;
+  LineReader r(path);
+  string line;
+  bool header = false;
+  while (r.next(line)) {
+    if (starts_with(line, "##")) continue;
+    if (starts_with(line, "#CHROM")) {
+      string h = line;
+      vector<string> tabs = split(h, '\t');
+      static const char* req[9] = {"#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"};
+      bool ok = tabs.size() >= 9;
+      for (int i = 0; ok && i < 9; ++i) ok = tabs[i] == req[i];
+      if (!ok) throw Error("InvalidVcfFormat(\"Invalid VCF header format\")");
+      vector<string> f = split_ws(h);
+      for (size_t i = 9; i < f.size(); ++i) if (!exclusion.count(f[i])) { d.sample_names.push_back(f[i]); kept.push_back(i); }
+      header = true;
+      break;
+    }
+  }
+  if (!header || d.sample_names.empty()) throw Error("Parse(\"No samples remain after applying exclusions\")");
+  vector<std::pair<Variant, uint8_t>> items;
+  while (r.next(line)) {
+    Variant v;
+    uint8_t fl;
+    try {
+      if (process_variant(line, chr, regions, kept, min_gq, allow, mask, &v, &fl)) items.push_back({std::move(v), fl});
+    } catch (const Error& e) {
+      fprintf(stderr, "%s\n", e.what());  // the collector prints and carries on (process.rs:4358-4360)
+    }
+  }
+  std::stable_sort(items.begin(), items.end(), [](const auto& a, const auto& b) {
+    if (a.first.position != b.first.position) return a.first.position < b.first.position;
+    return a.first.data < b.first.data;  // lexicographic on the flat genotype bytes (process.rs:4397-4405)
+  });
+  for (auto& it : items) { d.variants.push_back(std::move(it.first)); d.flags.push_back(it.second); }
+  return d;
+}
+
+// ---- sample-name mapping (process.rs:1192-1333) -----------------------------------------------------
+string normalize_sample_name(const string& n) { return (ends_with(n, "_L") || ends_with(n, "_R")) ? n.substr(0, n.size() - 2) : n; }
+
+std::map<string, size_t> map_sample_names_to_indices(const vector<string>& names) {
+  std::map<string, size_t> exact;
+  std::map<string, std::optional<size_t>> alias;
+  for (size_t i = 0; i < names.size(); ++i) {
+    exact[names[i]] = i;
+    const size_t us = names[i].rfind('_');
+    if (us != string::npos) {
+      const string suffix = names[i].substr(us + 1);
+      auto it = alias.find(suffix);
+      if (it == alias.end()) alias[suffix] = i;
+      else if (!(it->second && *it->second == i)) it->second = std::nullopt;
+    }
+  }
+  for (auto& kv : alias) if (kv.second && !exact.count(kv.first)) exact[kv.first] = *kv.second;
+  return exact;
+}
+
+typedef vector<std::pair<size_t, int>> HapList;  // (sample index, side)
+
+HapList haplotypes_for_group(uint8_t group, const SampleMap& filter, const std::map<string, size_t>& index) {
+  HapList out;
+  for (auto& kv : filter) {
+    auto it = index.find(normalize_sample_name(kv.first));
+    if (it == index.end()) continue;
+    if (kv.second.first == group) out.push_back({it->second, 0});
+    if (kv.second.second == group) out.push_back({it->second, 1});
+  }
+  return out;
+}
+
+// ---- device side --------------------------------------------------------------------------------------
+struct DeviceMatrix {
+  fmh_matrix* h = nullptr;
+  size_t variants = 0, samples = 0, ploidy = 0;
+  ~DeviceMatrix() { if (h) fmh_matrix_destroy(h); }
+  size_t columns() const { return samples * ploidy; }
+};
+
+struct DevBuf {
+  int device;
+  void* p = nullptr;
+  DevBuf(int dev, size_t bytes) : device(dev) { fmh_check(fmh_device_alloc(dev, bytes, &p), "device alloc"); }
+  ~DevBuf() { if (p) fmh_device_free(device, p); }
+  template <class T> vector<T> fetch(size_t n) const {
+    vector<T> out(n);
+    if (n) fmh_check(fmh_copy_to_host(device, out.data(), p, n * sizeof(T), nullptr), "copy to host");
+    return out;
+  }
+};
+
+// DenseGenotypeMatrix::from_variants (stats.rs:339-500), uploaded.  When no genotype is called at all the
+// reference has no dense matrix; a one-allele all-missing matrix carries the same (empty) information for
+// the sparse formulas, and `has_dense` records which arm the reference would take.
+struct RegionMatrix {
+  std::unique_ptr<DeviceMatrix> dm;
+  bool has_dense = false;
+  size_t ploidy = 0;
+};
+
+RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, int device) {
+  RegionMatrix out;
+  if (vs.empty()) return out;
+  size_t max_ploidy = 0;
+  for (auto* v : vs) for (size_t s = 0; s < v->num_samples; ++s) max_ploidy = std::max(max_ploidy, v->glen(s));
+  out.has_dense = max_ploidy > 0;
+  const size_t P = std::max<size_t>(max_ploidy, 1);
+  out.ploidy = P;
+  const size_t stride = n_samples * P, total = vs.size() * stride;
+  vector<uint8_t> data(total, 0);
+  vector<uint64_t> missing((total + 63) / 64, 0);
+  bool any_missing = false;
+  uint8_t max_allele = 0;
+  for (size_t i = 0; i < vs.size(); ++i) {
+    const Variant& v = *vs[i];
+    for (size_t s = 0; s < n_samples; ++s) {
+      const size_t len = v.glen(s);
+      for (size_t k = 0; k < P; ++k) {
+        const size_t idx = i * stride + s * P + k;
+        if (k < len) { data[idx] = v.data[s * v.stride + k]; max_allele = std::max(max_allele, data[idx]); }
+        else { missing[idx >> 6] |= 1ull << (idx & 63); any_missing = true; }
+      }
+    }
+  }
+  out.dm.reset(new DeviceMatrix());
+  out.dm->variants = vs.size(); out.dm->samples = n_samples; out.dm->ploidy = P;
+  fmh_check(fmh_matrix_create(data.data(), any_missing ? missing.data() : nullptr, vs.size(), n_samples, P, max_allele, device, &out.dm->h), "matrix upload");
+  return out;
+}
+
+vector<uint8_t> mask_of(const HapList& haps, size_t n_samples, size_t ploidy, bool dense_rules) {
+  // DenseMembership::build (stats.rs:1252-1284) / HapMembership::build (1212-1238): identical as column masks
+  // except that the dense one drops Right when ploidy <= 1 (a side that does not exist is never called anyway)
+  vector<uint8_t> m(n_samples * ploidy, 0);
+  for (auto& h : haps) {
+    if (h.first >= n_samples || (size_t)h.second >= ploidy) continue;
+    (void)dense_rules;
+    m[h.first * ploidy + h.second] = 1;
+  }
+  return m;
+}
+size_t mask_count(const vector<uint8_t>& m) { size_t c = 0; for (uint8_t x : m) c += x; return c; }
+// HapMembership::total (stats.rs:1212-1238): distinct (sample, side) pairs inside sample_count, whatever the ploidy
+size_t membership_total(const HapList& haps, size_t sample_count) {
+  std::set<std::pair<size_t, int>> seen;
+  for (auto& h : haps) if (h.first < sample_count) seen.insert(h);
+  return seen.size();
+}
+
+struct Groups {
+  fmh_groups* h = nullptr;
+  Groups(const DeviceMatrix& dm, const vector<vector<uint8_t>>& masks) {
+    vector<uint8_t> flat;
+    for (auto& m : masks) flat.insert(flat.end(), m.begin(), m.end());
+    fmh_check(fmh_groups_create(dm.h, flat.data(), (int)masks.size(), &h), "groups");
+  }
+  ~Groups() { if (h) fmh_groups_destroy(h); }
+};
+
+// ---- statistics (host scalars are literal restatements; genotype work is on the GPU) ------------------
+double harmonic(size_t n) { double s = 0.0; for (size_t k = 1; k <= n; ++k) s += 1.0 / (double)k; return s; }  // stats.rs:4234
+double watterson_theta(size_t S, size_t n, int64_t L) {                                                          // stats.rs:4243-4307
+  if (n <= 1 || L <= 0) return S == 0 ? NAN : INFINITY;
+  const double h = harmonic(n - 1);
+  if (h > 0.0) return (double)S / h / (double)L;
+  return S == 0 ? NAN : INFINITY;
+}
+int64_t sat_sub(int64_t a, int64_t b) { __int128 r = (__int128)a - b; if (r < INT64_MIN) return INT64_MIN; if (r > INT64_MAX) return INT64_MAX; return (int64_t)r; }
+
+vector<Interval> subtract_regions(const vector<Interval>& intervals, const vector<Interval>* masks) {  // stats.rs:3739-3775 (1-based inclusive)
+  if (!masks) return intervals;
+  vector<Interval> out;
+  for (auto& a : intervals) {
+    vector<Interval> parts{a};
+    for (auto& m : *masks) {
+      vector<Interval> next;
+      for (auto& p : parts) {
+        if (m.second < p.first || m.first > p.second) { next.push_back(p); continue; }
+        if (m.first > p.first && m.first - 1 >= p.first) next.push_back({p.first, m.first - 1});
+        if (m.second < p.second && m.second + 1 <= p.second) next.push_back({m.second + 1, p.second});
+      }
+      parts.swap(next);
+      if (parts.empty()) break;
+    }
+    out.insert(out.end(), parts.begin(), parts.end());
+  }
+  return out;
+}
+
+int64_t adjusted_sequence_length(int64_t start1, int64_t end1, const vector<Interval>* allow, const vector<Interval>* mask) {  // stats.rs:3644-3736
+  const Interval region = from_1based_inclusive(start1, end1);
+  vector<Interval> allowed;
+  if (allow) {
+    for (auto& a : *allow) {
+      const uint64_t s = std::max((uint64_t)region.first, (uint64_t)a.first), e = std::min((uint64_t)region.second, (uint64_t)a.second);
+      if (s < e) allowed.push_back({(int64_t)s + 1, (int64_t)e});
+    }
+  } else allowed.push_back({start1, end1});
+  vector<Interval> conv;
+  if (mask) for (auto& m : *mask) conv.push_back({(int64_t)((uint64_t)m.first) + 1, (int64_t)(uint64_t)m.second});
+  int64_t total = 0;
+  for (auto& iv : subtract_regions(allowed, mask ? &conv : nullptr)) total += hal_len(from_1based_inclusive(iv.first, iv.second));
+  return total;
+}
+
+std::optional<double> inversion_allele_frequency(const SampleMap& m) {  // stats.rs:3778-3805
+  size_t ones = 0, total = 0;
+  for (auto& kv : m) for (uint8_t a : {kv.second.first, kv.second.second}) if (a == 0 || a == 1) { ++total; ones += a; }
+  if (!total) return std::nullopt;
+  return (double)ones / (double)total;
+}
+
+struct SiteDiv { int64_t pos1; double pi, theta; };
+struct GroupStats { bool present = false; size_t segsites = 0, n_hap = 0; double theta = 0.0, pi = 0.0; vector<SiteDiv> sites; };
+
+// process_variants (process.rs:821-1188), statistics only, for groups 0 and 1 of one (variant set, sample filter)
+void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
+                           const SampleMap& filter, const Interval& interval, int64_t L, const vector<Interval>* mask_intervals,
+                           int device, GroupStats out[2]) {
+  const auto index = map_sample_names_to_indices(sample_names);
+  HapList haps[2] = {haplotypes_for_group(0, filter, index), haplotypes_for_group(1, filter, index)};
+  const size_t N = sample_names.size();
+  for (int g = 0; g < 2; ++g) {
+    out[g] = GroupStats();
+    if (haps[g].empty()) continue;
+    out[g].present = true;
+    out[g].n_hap = haps[g].size();
+    if (vs.empty()) { out[g].theta = out[g].pi = out[g].n_hap < 2 ? NAN : 0.0; }
+  }
+  if (vs.empty() || (!out[0].present && !out[1].present)) return;
+  const DeviceMatrix& dm = *rm.dm;
+  const size_t S = dm.variants;
+  // one pass: segregating sites + pi of both groups.  calculate_pi_for_population picks calculate_pi_dense
+  // only for a diploid dense matrix (stats.rs:4603-4608), calculate_pi otherwise.
+  const bool dense_arm = rm.has_dense && rm.ploidy == 2;
+  vector<vector<uint8_t>> masks = {mask_of(haps[0], N, dm.ploidy, true), mask_of(haps[1], N, dm.ploidy, true)};
+  fmh_pop_totals tot[2];
+  {
+    Groups grp(dm, masks);
+    fmh_check(fmh_population_summaries(dm.h, grp.h, 0, S, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE, nullptr, nullptr, tot, nullptr), "summaries");
+  }
+  for (int g = 0; g < 2; ++g) {
+    if (!out[g].present) continue;
+    out[g].segsites = (size_t)tot[g].segregating_sites;
+    out[g].theta = watterson_theta(out[g].segsites, out[g].n_hap, L);
+    const size_t members = dense_arm ? mask_count(masks[g]) : out[g].n_hap;  // membership.len() vs haplotypes_in_group.len()
+    double pi;
+    if (members <= 1) pi = NAN;
+    else if (L < 0) pi = 0.0;
+    else if (L == 0) pi = INFINITY;
+    else if (!dense_arm && membership_total(haps[g], std::max(N, [&] { size_t m = 0; for (auto& h : haps[g]) m = std::max(m, h.first + 1); return m; }())) <= 1) pi = NAN;  // stats.rs:4353-4374
+    else {
+      const int64_t eff = sat_sub(L, (int64_t)tot[g].uncallable_sites);
+      pi = eff == 0 ? NAN : tot[g].pi_sum / (double)eff;
+    }
+    out[g].pi = pi;
+    // calculate_per_site_diversity (stats.rs:4628-4806): needs >= 2 listed haplotypes
+    if (haps[g].size() < 2 || hal_len(interval) <= 0) continue;
+    Groups one(dm, {masks[g]});
+    DevBuf dpi(device, 8 * S), dth(device, 8 * S);
+    fmh_check(fmh_diversity_sites(dm.h, one.h, 0, S, (double*)dpi.p, (double*)dth.p, nullptr, nullptr, nullptr, nullptr), "diversity");
+    vector<double> pi_v = dpi.fetch<double>(S), th_v = dth.fetch<double>(S);
+    for (size_t i = 0; i < S; ++i) {
+      const int64_t pos0 = vs[i]->position;
+      if (!hal_contains(interval, pos0)) continue;
+      SiteDiv sd{pos0 + 1, pi_v[i], th_v[i]};
+      if (mask_intervals && position_in_regions(pos0, *mask_intervals)) sd.pi = sd.theta = NAN;  // stats.rs:4731-4743
+      out[g].sites.push_back(sd);
+    }
+  }
+}
+
+struct WcSite { int64_t pos1; double overall_fst, overall_num, overall_den, pair_fst, pair_num, pair_den; };
+struct WcRegion {
+  bool computed = false;
+  // overall FstEstimate pieces for the CSV (extract_wc_fst_components, stats.rs:4860-4914)
+  std::optional<double> value; double sum_a = 0.0, sum_b = 0.0; size_t sites = 0;
+  vector<WcSite> per_site;
+};
+
+int wc_classify(double a, double b) {  // stats.rs:1781-1812 -> 0 calculable, 1 indeterminate, 2 no variance
+  const double d = a + b;
+  if (d > 1e-12) return 0;
+  if (d < -1e-12) return 1;
+  if (std::fabs(a) > 1e-12) return 0;
+  return 2;
+}
+
+// calculate_fst_wc_haplotype_groups (stats.rs:675-806) on the filtered variants of the region
+WcRegion wc_haplotype_groups(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
+                             const SampleMap& filter, int device) {
+  WcRegion out;
+  out.computed = true;
+  const size_t N = sample_names.size();
+  const auto index = map_sample_names_to_indices(sample_names);
+  // map_samples_to_haplotype_groups + SubpopulationMembership::from_map: labels are the decimal strings, sorted
+  std::map<std::pair<size_t, int>, string> hap_to_group;
+  for (auto& kv : filter) {
+    auto it = index.find(normalize_sample_name(kv.first));
+    if (it == index.end()) continue;
+    hap_to_group[{it->second, 0}] = std::to_string(kv.second.first);
+    hap_to_group[{it->second, 1}] = std::to_string(kv.second.second);
+  }
+  std::set<string> label_set;
+  for (auto& kv : hap_to_group) label_set.insert(kv.second);
+  vector<string> labels(label_set.begin(), label_set.end());
+  const size_t G = labels.size();
+  if (vs.empty()) { out.value = std::nullopt; out.sites = 0; return out; }  // InsufficientData { sites_attempted: 0 }
+  const DeviceMatrix& dm = *rm.dm;
+  const size_t S = dm.variants, P = dm.ploidy;
+  vector<vector<uint8_t>> masks(std::max<size_t>(G, 1), vector<uint8_t>(N * P, 0));
+  for (auto& kv : hap_to_group) {
+    if (kv.first.first >= N || (size_t)kv.first.second >= P) continue;
+    const size_t gi = std::find(labels.begin(), labels.end(), kv.second) - labels.begin();
+    masks[gi][kv.first.first * P + kv.first.second] = 1;
+  }
+  const bool has01 = G == 2 && labels[0] == "0" && labels[1] == "1";
+  if (G < 2) {
+    // fewer than two groups: a site with any called allele is NoInterPopulationVariance (0, 0), a site with none is
+    // InsufficientData (stats.rs:1925-1930, 1987-2003); "any called" comes from an all-columns summary sweep
+    Groups all(dm, {vector<uint8_t>(N * P, 1)});
+    DevBuf dcalled(device, 4 * S);
+    fmh_pop_totals t;
+    fmh_check(fmh_population_summaries(dm.h, all.h, 0, S, FMH_FORMULA_SPARSE, nullptr, (uint32_t*)dcalled.p, &t, nullptr), "summaries");
+    vector<uint32_t> called = dcalled.fetch<uint32_t>(S);
+    size_t informative = 0;
+    for (size_t i = 0; i < S; ++i) {
+      informative += called[i] != 0;
+      out.per_site.push_back({vs[i]->position + 1, NAN, 0.0, 0.0, NAN, NAN, NAN});
+    }
+    out.sites = informative ? informative : S;
+    out.value = std::nullopt;
+    return out;
+  }
+  if (G > FMH_MAX_GROUPS) throw Error("more than 8 haplotype groups");
+  const size_t nw = 1 + G * (G - 1) / 2;
+  Groups grp(dm, masks);
+  DevBuf da(device, 8 * nw * S), db(device, 8 * nw * S), ds(device, nw * S);
+  fmh_wc_totals tot;
+  fmh_check(fmh_wc_sweep(dm.h, grp.h, 0, S, (double*)da.p, (double*)db.p, (uint8_t*)ds.p, nullptr, &tot, nullptr), "wc sweep");
+  vector<double> a = da.fetch<double>(nw * S), b = db.fetch<double>(nw * S);
+  vector<uint8_t> st = ds.fetch<uint8_t>(nw * S);
+  for (size_t i = 0; i < S; ++i) {
+    WcSite w{vs[i]->position + 1, NAN, 0.0, 0.0, NAN, NAN, NAN};
+    if (st[i] != FMH_WC_INSUFFICIENT) {
+      w.overall_num = a[i];
+      w.overall_den = a[i] + b[i];
+      if (wc_classify(a[i], b[i]) == 0) w.overall_fst = a[i] / (a[i] + b[i]);
+      if (has01) {  // slot 1 is the only pair
+        w.pair_num = a[S + i];
+        w.pair_den = a[S + i] + b[S + i];
+        if (st[S + i] != FMH_WC_INSUFFICIENT && wc_classify(a[S + i], b[S + i]) == 0) w.pair_fst = a[S + i] / (a[S + i] + b[S + i]);
+      }
+    }
+    out.per_site.push_back(w);
+  }
+  // calculate_overall_fst_wc (stats.rs:2145-2374)
+  if (tot.informative_sites[0] == 0) { out.value = std::nullopt; out.sum_a = out.sum_b = 0.0; out.sites = S; }
+  else {
+    out.sum_a = tot.sum_a[0]; out.sum_b = tot.sum_b[0]; out.sites = (size_t)tot.informative_sites[0];
+    if (wc_classify(out.sum_a, out.sum_b) == 0) out.value = out.sum_a / (out.sum_a + out.sum_b);
+  }
+  return out;
+}
+
+struct HudsonRegion {
+  bool have_outcome = false;
+  std::optional<double> fst, dxy, pi0, pi1, avg;
+  vector<std::tuple<int64_t, double, double, double>> sites;  // (pos1, fst, num, den)
+};
+
+// calculate_hudson_fst_for_pair_with_sites (stats.rs:3619) for haplotype groups 0 / 1 of the filtered set
+HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
+                           const HapList& h0, const HapList& h1, int64_t L, const GroupStats pair_stats[2], int device) {
+  HudsonRegion out;
+  if (L <= 0) return out;  // Err(InvalidRegion) -> logged, no outcome (process.rs:3261-3271)
+  out.have_outcome = true;
+  double num_sum = 0.0, den_sum = 0.0, dxy_sum = 0.0;
+  uint64_t dxy_skipped = 0;
+  const size_t N = sample_names.size();
+  if (!vs.empty()) {
+    const DeviceMatrix& dm = *rm.dm;
+    const size_t S = dm.variants;
+    Groups grp(dm, {mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false)});
+    DevBuf dfst(device, 8 * S), dnum(device, 8 * S), dden(device, 8 * S);
+    fmh_hudson_sites sites{};
+    sites.d_fst = (double*)dfst.p; sites.d_num = (double*)dnum.p; sites.d_den = (double*)dden.p;
+    fmh_hudson_totals tot;
+    fmh_check(fmh_hudson_sweep(dm.h, grp.h, 0, S, FMH_FORMULA_SPARSE, &sites, &tot, nullptr), "hudson sweep");
+    vector<double> fst = dfst.fetch<double>(S), num = dnum.fetch<double>(S), den = dden.fetch<double>(S);
+    num_sum = tot.site_num_sum; den_sum = tot.site_den_sum; dxy_sum = tot.site_dxy_sum; dxy_skipped = tot.site_dxy_skipped;
+    size_t informative = 0;
+    for (size_t i = 0; i < S; ++i) informative += (!std::isnan(den[i]) && std::isfinite(den[i]) && den[i] > 0.0);
+    if (informative > 0) for (size_t i = 0; i < S; ++i) out.sites.push_back({vs[i]->position + 1, fst[i], num[i], den[i]});
+  }
+  if (den_sum > 1e-12) out.fst = num_sum / den_sum;
+  // auxiliaries (stats.rs:3562-3565): calculate_pi_for_population x2 == the filtered process_variants pi of the same
+  // haplotype lists and length; calculate_d_xy_hudson: dense shared / sparse fold share the frequency-dot form
+  for (int g = 0; g < 2; ++g) {
+    const double raw = pair_stats[g].pi;
+    (g == 0 ? out.pi0 : out.pi1) = std::isfinite(raw) ? std::optional<double>(raw) : std::nullopt;
+  }
+  if (!h0.empty() && !h1.empty()) {
+    const bool dense_arm = rm.has_dense && rm.ploidy == 2;
+    bool members_ok = true;
+    if (dense_arm && !vs.empty()) members_ok = mask_count(mask_of(h0, N, rm.ploidy, true)) && mask_count(mask_of(h1, N, rm.ploidy, true));
+    const int64_t eff = sat_sub(L, (int64_t)dxy_skipped);
+    if (members_ok && eff > 0) out.dxy = dxy_sum / (double)eff;
+  }
+  if (out.pi0 && out.pi1) out.avg = 0.5 * (*out.pi0 + *out.pi1);
+  return out;
+}
+
+// ---- writers --------------------------------------------------------------------------------------------
+const char* kCsvHeader[34] = {
+    "chr", "region_start", "region_end", "0_sequence_length", "1_sequence_length", "0_sequence_length_adjusted",
+    "1_sequence_length_adjusted", "0_segregating_sites", "1_segregating_sites", "0_w_theta", "1_w_theta", "0_pi", "1_pi",
+    "0_segregating_sites_filtered", "1_segregating_sites_filtered", "0_w_theta_filtered", "1_w_theta_filtered",
+    "0_pi_filtered", "1_pi_filtered", "0_num_hap_no_filter", "1_num_hap_no_filter", "0_num_hap_filter", "1_num_hap_filter",
+    "inversion_freq_no_filter", "inversion_freq_filter", "haplotype_overall_fst_wc", "haplotype_between_pop_variance_wc",
+    "haplotype_within_pop_variance_wc", "haplotype_num_informative_sites_wc", "hudson_fst_hap_group_0v1",
+    "hudson_dxy_hap_group_0v1", "hudson_pi_hap_group_0", "hudson_pi_hap_group_1", "hudson_pi_avg_hap_group_0v1"};
+
+string csv_field(const string& f) {  // csv crate default quoting: only when needed
+  if (f.find_first_of(",\"\n\r") == string::npos) return f;
+  string o = "\"";
+  for (char c : f) { if (c == '"') o += '"'; o += c; }
+  return o + "\"";
+}
+string join(const vector<string>& v, char d, bool csv_quote = false) {
+  string o;
+  for (size_t i = 0; i < v.size(); ++i) { if (i) o += d; o += csv_quote ? csv_field(v[i]) : v[i]; }
+  return o;
+}
+
+void gz_append(const string& path, const string& text) {  // open_append_compressed: one gzip member per call
+  gzFile f = gzopen(path.c_str(), "ab");
+  if (!f) throw Error("cannot open " + path);
+  if (!text.empty() && gzwrite(f, text.data(), (unsigned)text.size()) <= 0) { gzclose(f); throw Error("write failed: " + path); }
+  gzclose(f);
+}
+
+struct RegionOutput {
+  vector<string> csv_row;
+  string seqname;
+  int64_t region_start1 = 0, region_end1 = 0;
+  vector<std::tuple<int64_t, double, double, int, bool>> diversity;  // (pos1, pi, theta, group, filtered)
+  vector<WcSite> wc_sites;
+  vector<std::tuple<int64_t, double, double, double>> hudson_sites;
+  vector<vector<string>> hudson_rows;
+};
+
+string diversity_falsta(const RegionOutput& r) {  // append_diversity_falsta, process.rs:3740-3806
+  if (r.diversity.empty()) return "";
+  const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
+  const int64_t n = hal_len(region);
+  if (n > (int64_t)1 << 31) throw Error("region too long for a dense FALSTA track");
+  std::set<int> gids;
+  for (auto& d : r.diversity) gids.insert(std::get<3>(d));
+  string out;
+  struct Spec { bool filtered; bool is_pi; const char* prefix; };
+  const Spec specs[4] = {{false, true, "unfiltered_pi_"}, {false, false, "unfiltered_theta_"}, {true, true, "filtered_pi_"}, {true, false, "filtered_theta_"}};
+  for (int g : gids)
+    for (const Spec& sp : specs) {
+      vector<string> line((size_t)n, "0");
+      bool any = false;
+      for (auto& d : r.diversity) {
+        if (std::get<3>(d) != g || std::get<4>(d) != sp.filtered) continue;
+        const int64_t p = std::get<0>(d) - 1;
+        if (!hal_contains(region, p)) continue;
+        line[(size_t)(p - region.first)] = falsta_div_value(sp.is_pi ? std::get<1>(d) : std::get<2>(d));
+        any = true;
+      }
+      if (any) {
+        out += ">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1) + "_group_" + std::to_string(g) + "\n";
+        out += join(line, ',') + "\n";
+      }
+    }
+  return out;
+}
+
+string fst_falsta(const RegionOutput& r) {  // append_fst_falsta, process.rs:3809-4003
+  if (r.wc_sites.empty() && r.hudson_sites.empty()) return "";
+  const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
+  const int64_t n = hal_len(region);
+  if (n > (int64_t)1 << 31) throw Error("region too long for a dense FALSTA track");
+  const string suffix = "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1);
+  string out;
+  auto emit = [&](const string& header, auto getter, size_t count) {
+    vector<string> v((size_t)n, "NA");
+    for (size_t i = 0; i < count; ++i) {
+      std::pair<int64_t, double> pv = getter(i);
+      const int64_t p = pv.first - 1;
+      if (hal_contains(region, p)) v[(size_t)(p - region.first)] = falsta_fst_value(pv.second);
+    }
+    out += ">" + header + "_" + suffix + "\n" + join(v, ',') + "\n";
+  };
+  if (!r.wc_sites.empty()) {
+    const auto& w = r.wc_sites;
+    emit("haplotype_overall_fst_summary", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].overall_fst); }, w.size());
+    emit("haplotype_overall_fst_numerator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].overall_num); }, w.size());
+    emit("haplotype_overall_fst_denominator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].overall_den); }, w.size());
+    emit("haplotype_0v1_pairwise_fst_summary", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].pair_fst); }, w.size());
+    emit("haplotype_0v1_pairwise_fst_numerator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].pair_num); }, w.size());
+    emit("haplotype_0v1_pairwise_fst_denominator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].pair_den); }, w.size());
+  }
+  if (!r.hudson_sites.empty()) {
+    const auto& h = r.hudson_sites;
+    emit("hudson_pairwise_fst_hap_0v1", [&](size_t i) { return std::make_pair(std::get<0>(h[i]), std::get<1>(h[i])); }, h.size());
+    emit("hudson_pairwise_fst_hap_0v1_numerator", [&](size_t i) { return std::make_pair(std::get<0>(h[i]), std::get<2>(h[i])); }, h.size());
+    emit("hudson_pairwise_fst_hap_0v1_denominator", [&](size_t i) { return std::make_pair(std::get<0>(h[i]), std::get<3>(h[i])); }, h.size());
+  }
+  return out;
+}
+
+// ---- per-region driver (process.rs:2468-3653) ----------------------------------------------------------------
+struct Args {
+  string vcf_folder, chr, region, config_file, output_file = "output.csv", mask_file, allow_file, reference, gtf, fst_populations;
+  vector<string> exclude;
+  unsigned min_gq = 30;
+  bool enable_fst = false, enable_pca = false;
+  int device = 0;
+};
+
+std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry, const VcfData& vcf, const RegionMap& mask,
+                                                        const RegionMap* allow, int64_t chr_length, const string& chr, const Args& args) {
+  const Interval ext = from_1based_inclusive(std::max<int64_t>(entry.interval.first - 3000000, 0),
+                                             std::min<int64_t>(wrap_add(entry.interval.second, 3000000), chr_length));
+  const vector<Interval>* allow_chr = nullptr;
+  if (allow) { auto it = allow->find(chr); if (it != allow->end()) allow_chr = &it->second; }
+  const vector<Interval>* mask_chr = nullptr;
+  { auto it = mask.find(chr); if (it != mask.end()) mask_chr = &it->second; }
+  vector<const Variant*> unf, fil;
+  for (size_t i = 0; i < vcf.variants.size(); ++i) {
+    const Variant& v = vcf.variants[i];
+    if (!hal_contains(ext, v.position) || !hal_contains(entry.interval, v.position)) continue;
+    if ((!allow_chr || position_in_regions(v.position, *allow_chr)) && (!mask_chr || !position_in_regions(v.position, *mask_chr))) unf.push_back(&v);
+    if (vcf.flags[i] == FLAG_PASS) fil.push_back(&v);
+  }
+  const size_t N = vcf.sample_names.size();
+  RegionMatrix m_unf = build_matrix(unf, N, args.device), m_fil = build_matrix(fil, N, args.device);
+
+  WcRegion wc;
+  if (args.enable_fst) wc = wc_haplotype_groups(fil, m_fil, vcf.sample_names, entry.samples_filtered, args.device);
+
+  const int64_t sequence_length = (int64_t)((uint64_t)entry.interval.second - (uint64_t)entry.interval.first);
+  const int64_t adj = adjusted_sequence_length(entry.interval.first + 1, entry.interval.second, allow_chr, mask_chr);
+  const double callable = sequence_length > 0 ? (double)adj / (double)sequence_length : NAN;
+  const double masked_fraction = 1.0 - callable;
+  if (!std::isfinite(callable) || masked_fraction >= 0.99) {
+    logmsg("WARN", "DROPPED: Region " + entry.seqname + ":" + std::to_string(entry.interval.first) + "-" + std::to_string(entry.interval.second) + " is >= 99% masked");
+    return std::nullopt;
+  }
+  const int64_t fil_adj = adj;  // FilteringStats.filtered_positions is never filled for the slice (process.rs:2568-2571, 2677-2708)
+
+  GroupStats sf[2], su[2];
+  process_variants_pair(fil, m_fil, vcf.sample_names, entry.samples_filtered, entry.interval, fil_adj, mask_chr, args.device, sf);
+  process_variants_pair(unf, m_unf, vcf.sample_names, entry.samples_unfiltered, entry.interval, adj, mask_chr, args.device, su);
+  if (!sf[0].present && !sf[1].present && !su[0].present && !su[1].present) return std::nullopt;
+
+  const double inv_f = inversion_allele_frequency(entry.samples_filtered).value_or(-1.0);
+  const double inv_u = inversion_allele_frequency(entry.samples_unfiltered).value_or(-1.0);
+
+  RegionOutput out;
+  out.seqname = entry.seqname;
+  out.region_start1 = entry.interval.first + 1;
+  out.region_end1 = entry.interval.second;
+  HudsonRegion hud;
+  if (args.enable_fst) {
+    const auto index = map_sample_names_to_indices(vcf.sample_names);
+    const HapList h0 = haplotypes_for_group(0, entry.samples_filtered, index), h1 = haplotypes_for_group(1, entry.samples_filtered, index);
+    const bool region_valid = (uint64_t)entry.interval.second > (uint64_t)entry.interval.first;
+    if (h0.size() >= 2 && h1.size() >= 2 && region_valid) {
+      hud = hudson_groups(fil, m_fil, vcf.sample_names, h0, h1, fil_adj, sf, args.device);
+      if (hud.have_outcome) {
+        out.hudson_rows.push_back({entry.seqname, std::to_string(entry.interval.first), std::to_string(entry.interval.second - 1),
+                                   "HaplotypeGroup", "0", "HaplotypeGroup", "1", fmt_opt(hud.dxy), fmt_opt(hud.pi0), fmt_opt(hud.pi1),
+                                   fmt_opt(hud.avg), fmt_opt(hud.fst)});
+        out.hudson_sites = hud.sites;
+      }
+    }
+  }
+  // CsvRowData (process.rs:3429-3466)
+  std::optional<double> hap_a, hap_b;
+  std::optional<size_t> hap_sites;
+  if (args.enable_fst) { hap_a = wc.sum_a; hap_b = wc.sum_b; hap_sites = wc.sites; }
+  else { hap_a = 0.0; hap_b = 0.0; hap_sites = 0; }
+  out.csv_row = {entry.seqname, std::to_string(out.region_start1), std::to_string(out.region_end1), std::to_string(sequence_length),
+                 std::to_string(sequence_length), std::to_string(adj), std::to_string(adj), std::to_string(su[0].segsites),
+                 std::to_string(su[1].segsites), fmt6(su[0].theta), fmt6(su[1].theta), fmt6(su[0].pi), fmt6(su[1].pi),
+                 std::to_string(sf[0].segsites), std::to_string(sf[1].segsites), fmt6(sf[0].theta), fmt6(sf[1].theta), fmt6(sf[0].pi),
+                 fmt6(sf[1].pi), std::to_string(su[0].n_hap), std::to_string(su[1].n_hap), std::to_string(sf[0].n_hap),
+                 std::to_string(sf[1].n_hap), fmt6(inv_u), fmt6(inv_f), fmt_opt(args.enable_fst ? wc.value : std::nullopt),
+                 fmt_opt(hap_a), fmt_opt(hap_b), hap_sites ? std::to_string(*hap_sites) : "NA", fmt_opt(hud.fst), fmt_opt(hud.dxy),
+                 fmt_opt(hud.pi0), fmt_opt(hud.pi1), fmt_opt(hud.avg)};
+  for (auto& s : su[0].sites) out.diversity.push_back({s.pos1, s.pi, s.theta, 0, false});
+  for (auto& s : su[1].sites) out.diversity.push_back({s.pos1, s.pi, s.theta, 1, false});
+  for (auto& s : sf[0].sites) out.diversity.push_back({s.pos1, s.pi, s.theta, 0, true});
+  for (auto& s : sf[1].sites) out.diversity.push_back({s.pos1, s.pi, s.theta, 1, true});
+  if (args.enable_fst) out.wc_sites = wc.per_site;
+  return out;
+}
+
+// resolve_sample_exclusions, run_vcf.rs:24-187
+std::set<string> resolve_exclusions(const Args& args, const string& chr, const vector<ConfigEntry>* entries) {
+  std::set<string> requested(args.exclude.begin(), args.exclude.end());
+  if (requested.empty()) return {};
+  std::set<string> vcf_ids, cfg_ids;
+  try { for (auto& n : read_sample_names_from_vcf(find_vcf_file(args.vcf_folder, chr))) vcf_ids.insert(n); } catch (const Error&) {}
+  if (entries) for (auto& e : *entries) { for (auto& kv : e.samples_unfiltered) cfg_ids.insert(kv.first); for (auto& kv : e.samples_filtered) cfg_ids.insert(kv.first); }
+  if (vcf_ids.empty() && cfg_ids.empty()) return requested;
+  std::set<string> resolved;
+  for (const string& req : requested) {
+    const string t = trim(req);
+    for (const std::set<string>* ids : {&vcf_ids, &cfg_ids}) {
+      if (ids->count(t)) resolved.insert(t);
+      else for (auto& s : *ids) if (s.find(t) != string::npos) resolved.insert(s);
+    }
+  }
+  return resolved;
+}
+
+void erase_excluded(SampleMap& m, const std::set<string>& ex) {
+  m.erase(std::remove_if(m.begin(), m.end(), [&](const auto& kv) { return ex.count(kv.first) > 0; }), m.end());
+}
+
+int run(const Args& args) {
+  std::optional<RegionMap> mask_regions, allow_regions;
+  if (!args.mask_file.empty()) mask_regions = parse_regions_file(args.mask_file);
+  if (!args.allow_file.empty()) allow_regions = parse_regions_file(args.allow_file);
+  vector<ConfigEntry> entries;
+  std::set<string> exclusion;
+  if (!args.config_file.empty()) {
+    entries = parse_config_file(args.config_file);
+    if (!entries.empty()) exclusion = resolve_exclusions(args, entries[0].seqname, &entries);
+    else exclusion = std::set<string>(args.exclude.begin(), args.exclude.end());
+    for (auto& e : entries) { erase_excluded(e.samples_unfiltered, exclusion); erase_excluded(e.samples_filtered, exclusion); }
+  } else if (!args.chr.empty()) {
+    exclusion = resolve_exclusions(args, args.chr, nullptr);
+    ConfigEntry e;
+    e.seqname = args.chr;
+    e.interval = args.region.empty() ? from_1based_inclusive(1, INT64_MAX) : parse_region(args.region);
+    for (auto& n : read_sample_names_from_vcf(find_vcf_file(args.vcf_folder, args.chr)))
+      if (!exclusion.count(n)) { sample_map_set(e.samples_unfiltered, n, 0, 0); sample_map_set(e.samples_filtered, n, 0, 0); }
+    if (e.samples_unfiltered.empty()) throw Error("Parse(\"No samples remain after applying exclusions\")");
+    entries.push_back(e);
+  } else {
+    throw Error("Parse(\"Either --config_file or --chr must be specified\")");
+  }
+  if (args.enable_pca) logmsg("WARN", "--pca is outside the accelerated path and is ignored (DESIGN.md section 8)");
+  if (!args.fst_populations.empty()) logmsg("WARN", "--fst_populations (CSV-defined populations) is not built yet; haplotype-group FST only");
+
+  const string out_dir = dirname_of(args.output_file);
+  mkdirs(out_dir);
+  const string div_path = out_dir + "/per_site_diversity_output.falsta.gz", fst_path = out_dir + "/per_site_fst_output.falsta.gz";
+  const string hudson_path = out_dir + "/hudson_fst_results.tsv.gz";
+  remove(div_path.c_str());
+  remove(fst_path.c_str());
+  std::ofstream csv(args.output_file);
+  if (!csv) throw Error("cannot create " + args.output_file);
+  { vector<string> h(kCsvHeader, kCsvHeader + 34); csv << join(h, ',', true) << "\n"; csv.flush(); }
+
+  std::map<string, vector<const ConfigEntry*>> by_chr;
+  for (auto& e : entries) by_chr[e.seqname].push_back(&e);
+  vector<vector<string>> hudson_rows;
+  for (auto& kv : by_chr) {
+    const string& chr = kv.first;
+    try {
+      const string ref_seq = read_reference_sequence(args.reference, chr);
+      const int64_t chr_length = (int64_t)ref_seq.size();
+      RegionMap final_mask = mask_regions ? *mask_regions : RegionMap();
+      auto& chr_mask = final_mask[chr];
+      for (auto& n : find_n_regions(ref_seq)) chr_mask.push_back(n);
+      if (!file_exists(args.gtf)) throw Error("cannot open GTF " + args.gtf);
+      string vcf_path;
+      try { vcf_path = find_vcf_file(args.vcf_folder, chr); }
+      catch (const Error& e) { logmsg("ERROR", "Error finding VCF file for chr" + chr + ": " + e.what()); continue; }
+      vector<Interval> hulls;
+      for (auto* e : kv.second)
+        hulls.push_back({std::max<int64_t>(e->interval.first - 3000000, 0), std::min<int64_t>(wrap_add(e->interval.second, 3000000), chr_length)});
+      VcfData vcf;
+      try { vcf = process_vcf(vcf_path, chr, merge_intervals(hulls), args.min_gq, &final_mask, allow_regions ? &*allow_regions : nullptr, exclusion); }
+      catch (const Error& e) { logmsg("ERROR", "Error processing VCF for " + chr + ": " + e.what()); continue; }
+      for (auto* e : kv.second) {
+        std::optional<RegionOutput> res;
+        try { res = process_single_config_entry(*e, vcf, final_mask, allow_regions ? &*allow_regions : nullptr, chr_length, chr, args); }
+        catch (const Error& err) { logmsg("ERROR", string("DROPPED: Error processing region: ") + err.what()); continue; }
+        if (!res) continue;
+        csv << join(res->csv_row, ',', true) << "\n";
+        const string d = diversity_falsta(*res), f = fst_falsta(*res);
+        if (!d.empty()) gz_append(div_path, d);
+        if (!f.empty()) gz_append(fst_path, f);
+        for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
+      }
+    } catch (const Error& e) {
+      fprintf(stderr, "Error processing chromosome %s: %s\n", chr.c_str(), e.what());
+      continue;
+    }
+  }
+  csv.flush();
+  if (args.enable_fst) {  // final rewrite with header (process.rs:1557-1625)
+    remove(hudson_path.c_str());
+    string text = "chr\tregion_start_0based\tregion_end_0based\tpop1_id_type\tpop1_id_name\tpop2_id_type\tpop2_id_name\tDxy\tpi_pop1\tpi_pop2\tpi_xy_avg\tFST\n";
+    for (auto& r : hudson_rows) text += join(r, '\t') + "\n";
+    gz_append(hudson_path, text);
+  }
+  printf("Wrote FASTA-style per-site diversity data to per_site_diversity_output.falsta.gz\n");
+  printf("Wrote FASTA-style per-site FST data to per_site_fst_output.falsta.gz\n");
+  printf("Processing complete. Check the output file: \"%s\"\n", args.output_file.c_str());
+  return 0;
+}
+
+Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
+  Args a;
+  bool have_vcf = false, have_ref = false, have_gtf = false;
+  for (int i = 1; i < argc; ++i) {
+    string k = argv[i], v;
+    const size_t eq = k.find('=');
+    bool has_inline = false;
+    if (starts_with(k, "--") && eq != string::npos) { v = k.substr(eq + 1); k = k.substr(0, eq); has_inline = true; }
+    auto value = [&]() -> string {
+      if (has_inline) return v;
+      if (i + 1 >= argc) throw Error("missing value for " + k);
+      return argv[++i];
+    };
+    if (k == "--vcf_folder" || k == "-v") { a.vcf_folder = value(); have_vcf = true; }
+    else if (k == "--chr" || k == "-c") a.chr = value();
+    else if (k == "--region" || k == "-r") a.region = value();
+    else if (k == "--config_file") a.config_file = value();
+    else if (k == "--output_file" || k == "-o") a.output_file = value();
+    else if (k == "--min_gq") { unsigned g; if (!parse_unsigned(value(), 65535, &g)) throw Error("invalid --min_gq"); a.min_gq = g; }
+    else if (k == "--mask_file") a.mask_file = value();
+    else if (k == "--allow_file") a.allow_file = value();
+    else if (k == "--exclude") { for (auto& s : split(value(), ',')) if (!s.empty()) a.exclude.push_back(s); }
+    else if (k == "--reference") { a.reference = value(); have_ref = true; }
+    else if (k == "--gtf") { a.gtf = value(); have_gtf = true; }
+    else if (k == "--pca") a.enable_pca = true;
+    else if (k == "--pca_components" || k == "--pca_output") (void)value();
+    else if (k == "--fst") a.enable_fst = true;
+    else if (k == "--fst_populations") a.fst_populations = value();
+    else if (k == "--device") a.device = atoi(value().c_str());
+    else if (k == "--help" || k == "-h") {
+      printf("run_vcf --vcf_folder DIR --reference FA --gtf GTF [--config_file TSV | --chr C [--region S-E]] [--output_file CSV]\n"
+             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--device N]\n");
+      exit(0);
+    } else throw Error("unexpected argument '" + k + "'");
+  }
+  if (!have_vcf || !have_ref || !have_gtf) throw Error("the following required arguments were not provided: --vcf_folder --reference --gtf");
+  if (getenv("FERROMIC_HIP_DEVICES") && a.device == 0) a.device = atoi(getenv("FERROMIC_HIP_DEVICES"));
+  return a;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    const Args args = parse_args(argc, argv);
+    int n = 0;
+    fmh_check(fmh_device_count(&n), "GPU required (run_vcf has no CPU fallback)");
+    return run(args);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "Error: %s\n", e.what());
+    return 1;
+  }
+}

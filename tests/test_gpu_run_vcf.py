@@ -1,0 +1,215 @@
+"""run_vcf CLI parity: the C++ binary (text ingest + GPU statistics + writers) against the oracle's
+literal restatement of the reference pipeline, on the reference's own end-to-end cases and on a
+synthetic multi-chromosome cohort with missing calls, low GQ, indels, multi-allelic sites, masks,
+allow lists, N runs in the reference, suffix-tagged config genotypes and sample exclusions."""
+
+import gzip
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import run_vcf_ref as V
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")
+
+
+def run_binary(out_csv, **kw):
+    cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--output_file", out_csv]
+    for key in ("config_file", "mask_file", "allow_file"):
+        if kw.get(key):
+            cmd += [f"--{key}", kw[key]]
+    if kw.get("chrom"):
+        cmd += ["--chr", kw["chrom"]]
+    if kw.get("region"):
+        cmd += ["--region", kw["region"]]
+    if kw.get("min_gq") is not None:
+        cmd += ["--min_gq", str(kw["min_gq"])]
+    if kw.get("exclude"):
+        cmd += ["--exclude", ",".join(kw["exclude"])]
+    if kw.get("enable_fst"):
+        cmd += ["--fst"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_PROGRESS="0"), timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = {}
+    d = os.path.dirname(out_csv)
+    out[os.path.basename(out_csv)] = open(out_csv).read()
+    for name in ("per_site_diversity_output.falsta.gz", "per_site_fst_output.falsta.gz", "hudson_fst_results.tsv.gz"):
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            out[name] = gzip.open(p, "rt").read()
+    return out
+
+
+def assert_tables_close(got: str, exp: str, sep: str, what: str):
+    g, e = got.splitlines(), exp.splitlines()
+    assert len(g) == len(e), f"{what}: {len(g)} rows vs {len(e)}"
+    for i, (gl, el) in enumerate(zip(g, e)):
+        gf, ef = gl.split(sep), el.split(sep)
+        assert len(gf) == len(ef), f"{what} row {i}"
+        for a, b in zip(gf, ef):
+            if a == b:
+                continue
+            try:
+                fa, fb = float(a), float(b)
+            except ValueError:
+                raise AssertionError(f"{what} row {i}: {a!r} != {b!r}\n{gl}\n{el}") from None
+            assert abs(fa - fb) <= 1.5e-6, f"{what} row {i}: {a} vs {b}"  # a last-digit flip of {:.6} from sum order
+
+
+def compare(got, exp):
+    assert set(got) == set(exp), (sorted(got), sorted(exp))
+    for name in exp:
+        if name.endswith(".csv"):
+            assert_tables_close(got[name], exp[name], ",", name)
+        elif name.startswith("hudson"):
+            assert_tables_close(got[name], exp[name], "\t", name)
+        else:
+            assert got[name] == exp[name], f"{name} differs"  # per-site tracks are bit-exact -> identical text
+
+
+def write_case(tmp, k):
+    os.makedirs(tmp / "vcf", exist_ok=True)
+    (tmp / "vcf" / "chr1.vcf").write_text(k["vcf"])
+    (tmp / "reference.fa").write_text(k["fasta"])
+    (tmp / "reference.fa.fai").write_text(k["fai"])
+    (tmp / "annotations.gtf").write_text(k["gtf"])
+    (tmp / "config.tsv").write_text(k["config"])
+    return dict(vcf_folder=str(tmp / "vcf"), reference=str(tmp / "reference.fa"), gtf=str(tmp / "annotations.gtf"),
+                config_file=str(tmp / "config.tsv"), enable_fst=k["enable_fst"])
+
+
+@pytest.mark.parametrize("case", ["falsta_zero_fill", "falsta_hudson_tracks"])
+def test_reference_end_to_end_cases(tmp_path, kats, case):
+    kw = write_case(tmp_path, kats[case])
+    exp = V.run(output_file=str(tmp_path / "oracle" / "results.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "results.csv"), **kw)
+    compare(got, exp)
+    if case == "falsta_hudson_tracks":
+        e = kats[case]["expect"]
+        lines = got["per_site_fst_output.falsta.gz"].splitlines()
+        vals = [float(x) for x in lines[lines.index(e["fst_header"]) + 1].split(",")]
+        assert vals == pytest.approx(e["fst"], abs=1e-6)
+
+
+def make_cohort(tmp, seed, n_samples=14, gz=False):
+    rng = random.Random(seed)
+    names = [f"POP_{'ABC'[i % 3]}_HG{i:05d}" for i in range(n_samples)]
+    chroms = {"1": 6000, "7": 4000, "X": 3000}
+    fasta, fai, off = "", "", 0
+    for c, ln in chroms.items():
+        seq = "".join(rng.choice("ACGT") for _ in range(ln))
+        if c == "7":
+            seq = seq[:1500] + "N" * 120 + seq[1620:]
+        hdr = f">chr{c}\n"
+        body = "\n".join(seq[i:i + 60] for i in range(0, ln, 60)) + "\n"
+        fai += f"chr{c}\t{ln}\t{off + len(hdr)}\t60\t61\n"
+        fasta += hdr + body
+        off += len(hdr) + len(body)
+    (tmp / "ref.fa").write_text(fasta)
+    (tmp / "ref.fa.fai").write_text(fai)
+    (tmp / "ann.gtf").write_text('chr1\t.\tCDS\t1\t100\t.\t+\t0\tgene_id "g"; transcript_id "t";\n')
+    os.makedirs(tmp / "vcfs", exist_ok=True)
+    header = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"
+    for c, ln in chroms.items():
+        lines = []
+        pos = 0
+        while True:
+            pos += rng.randint(1, 9)
+            if pos > ln:
+                break
+            kind = rng.random()
+            ref, alt = rng.choice("ACGT"), rng.choice("ACGT")
+            if kind < 0.05:
+                ref = "AT"            # REF indel -> discarded
+            elif kind < 0.10:
+                alt = "GG"            # MNP -> discarded
+            elif kind < 0.18:
+                alt = alt + "," + rng.choice("ACGT")  # multi-allelic
+            f = rng.betavariate(0.8, 0.8)
+            cells = []
+            for i in range(n_samples):
+                r = rng.random()
+                if r < 0.03:
+                    cells.append("./.:.")
+                    continue
+                if r < 0.04:
+                    cells.append(".:.")
+                    continue
+                amax = 2 if "," in alt else 1
+                bias = 0.25 if i % 2 else -0.2
+                a = [(rng.randint(1, amax) if rng.random() < min(max(f + bias, 0.02), 0.98) else 0) for _ in range(2)]
+                gq = rng.choice([99, 60, 45, 31, 30]) if rng.random() > 0.04 else rng.choice([5, 29, "."])
+                sep = "|" if rng.random() > 0.1 else "/"
+                cells.append(f"{a[0]}{sep}{a[1]}:{gq}")
+            prefix = "chr" if c != "7" else ""
+            lines.append(f"{prefix}{c}\t{pos}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT:GQ\t" + "\t".join(cells) + "\n")
+        name = {"1": "chr1.vcf", "7": "cohort.chr7.phased.vcf", "X": "chrX.vcf"}[c]
+        text = header + "".join(lines)
+        if gz and c == "1":
+            with gzip.open(tmp / "vcfs" / "chr1.vcf.gz", "wt") as fh:
+                fh.write(text)
+        else:
+            (tmp / "vcfs" / name).write_text(text)
+    cfg = "seqnames\tstart\tend\tPOS\torig_ID\tverdict\tcateg\t" + "\t".join(names) + "\n"
+
+    def row(c, s, e):
+        cells = []
+        for i in range(n_samples):
+            g = rng.choice(["0|0", "0|1", "1|0", "1|1"])
+            if rng.random() < 0.15:
+                g += "_lowconf"
+            if rng.random() < 0.03:
+                g = "."
+            cells.append(g)
+        return f"chr{c}\t{s}\t{e}\t{s}\tid\tpass\tinv\t" + "\t".join(cells) + "\n"
+
+    cfg += row("1", 100, 2500) + row("1", 2000, 5900) + row("7", 1400, 1800) + row("7", 10, 3900) + row("X", 1, 3000)
+    cfg += row("7", 1510, 1610)   # >= 99 % masked by the N run -> dropped
+    cfg += row("9", 1, 100)       # chromosome absent from the reference -> skipped
+    (tmp / "config.tsv").write_text(cfg)
+    (tmp / "mask.bed").write_text("chr1\t300\t420\n1\t4000\t4100\nchrX\t0\t50\n")
+    (tmp / "allow.tsv").write_text("chr1\t1\t5000\nchr7\t1\t4000\nchrX\t100\t2900\n")
+    return dict(vcf_folder=str(tmp / "vcfs"), reference=str(tmp / "ref.fa"), gtf=str(tmp / "ann.gtf"),
+                config_file=str(tmp / "config.tsv")), names
+
+
+@pytest.mark.parametrize("variant", ["plain", "fst", "fst_mask_allow_exclude", "gz_min_gq"])
+def test_synthetic_cohort(tmp_path, variant):
+    kw, names = make_cohort(tmp_path, seed={"plain": 11, "fst": 12, "fst_mask_allow_exclude": 13, "gz_min_gq": 14}[variant], gz=variant == "gz_min_gq")
+    if variant in ("fst", "fst_mask_allow_exclude", "gz_min_gq"):
+        kw["enable_fst"] = True
+    if variant == "fst_mask_allow_exclude":
+        kw.update(mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"), exclude=[names[3], "HG00007"])
+    if variant == "gz_min_gq":
+        kw["min_gq"] = 50
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), **kw)
+    compare(got, exp)
+    rows = exp["out.csv"].splitlines()
+    assert len(rows) == 6  # header + 5 surviving regions
+    assert any(",NA," not in r for r in rows[1:])
+
+
+def test_single_chromosome_mode(tmp_path):
+    kw, _ = make_cohort(tmp_path, seed=5)
+    kw.pop("config_file")
+    kw.update(chrom="1", region="200-3000", enable_fst=True)
+    exp = V.run(output_file=str(tmp_path / "oracle" / "o.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "o.csv"), **kw)
+    compare(got, exp)
+    row = dict(zip(V.CSV_HEADER, got["o.csv"].splitlines()[1].split(",")))
+    assert row["1_num_hap_no_filter"] == "0" and row["hudson_fst_hap_group_0v1"] == "NA"  # everything is group 0
+
+
+def test_cli_errors(tmp_path):
+    res = subprocess.run([BIN, "--vcf_folder", "x"], capture_output=True, text=True)
+    assert res.returncode != 0 and "required arguments" in res.stderr
+    kw, _ = make_cohort(tmp_path, seed=6)
+    res = subprocess.run([BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"]],
+                         capture_output=True, text=True)
+    assert res.returncode != 0 and "Either --config_file or --chr must be specified" in res.stderr
