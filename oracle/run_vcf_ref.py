@@ -682,6 +682,36 @@ def process_single_config_entry(entry: ConfigEntry, all_variants, all_flags, sam
     return RegionResult(row, entry.seqname, rs1, re1, diversity, wc_sites, hudson_sites, hudson_rows)
 
 
+def resolve_sample_exclusions(vcf_folder, chrom, requested, config_entries):
+    """run_vcf.rs:24-187: exact name, else every known sample containing the request as a substring."""
+    if not requested:
+        return set()
+    vcf_ids, cfg_ids = set(), set()
+    try:
+        with open_text(find_vcf_file(vcf_folder, chrom)) as fh:
+            for line in fh:
+                if line.startswith("#CHROM"):
+                    vcf_ids.update(line.split()[9:])
+                    break
+    except (R.VcfError, OSError):
+        pass
+    if config_entries is not None:
+        for e in config_entries:
+            cfg_ids.update(e.samples_unfiltered)
+            cfg_ids.update(e.samples_filtered)
+    if not vcf_ids and not cfg_ids:
+        return set(requested)
+    resolved = set()
+    for req in sorted(requested):
+        t = req.strip()
+        for ids in (vcf_ids, cfg_ids):
+            if t in ids:
+                resolved.add(t)
+            else:
+                resolved.update(s for s in ids if t in s)
+    return resolved
+
+
 def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file: Optional[str] = None,
         chrom: Optional[str] = None, region: Optional[str] = None, min_gq: int = 30, mask_file: Optional[str] = None,
         allow_file: Optional[str] = None, exclude: Sequence[str] = (), enable_fst: bool = False) -> Dict[str, str]:
@@ -692,6 +722,8 @@ def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file
     exclusion = set(exclude)
     if config_file:
         entries = parse_config_file(config_file)
+        if entries:
+            exclusion = resolve_sample_exclusions(vcf_folder, entries[0].seqname, exclusion, entries)
         for e in entries:
             for name in list(e.samples_unfiltered):
                 if name in exclusion:
@@ -700,6 +732,7 @@ def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file
                 if name in exclusion:
                     del e.samples_filtered[name]
     elif chrom:
+        exclusion = resolve_sample_exclusions(vcf_folder, chrom, exclusion, None)
         interval = parse_region(region) if region else R._hal_from_1based_inclusive(1, (1 << 63) - 1)
         path = find_vcf_file(vcf_folder, chrom)
         names = []

@@ -192,7 +192,8 @@ def test_synthetic_cohort(tmp_path, variant):
     compare(got, exp)
     rows = exp["out.csv"].splitlines()
     assert len(rows) == 6  # header + 5 surviving regions
-    assert any(",NA," not in r for r in rows[1:])
+    if variant in ("fst", "fst_mask_allow_exclude"):
+        assert any("NA" not in r.split(",")[25:30] for r in rows[1:])  # some region has a calculable W&C FST
 
 
 def test_single_chromosome_mode(tmp_path):
