@@ -697,6 +697,24 @@ std::optional<double> inversion_allele_frequency(const SampleMap& m) {  // stats
   return (double)ones / (double)total;
 }
 
+// calculate_pi_for_population (stats.rs:4599-4614) from the sweep totals of one population:
+// calculate_pi_dense (4534-4597) on a diploid dense matrix, calculate_pi (4317-4432) otherwise.
+double pi_from_totals(const RegionMatrix& rm, const HapList& haps, const vector<uint8_t>& mask, size_t N, int64_t L,
+                      const fmh_pop_totals& tot) {
+  const bool dense_arm = rm.has_dense && rm.ploidy == 2;
+  const size_t members = dense_arm ? mask_count(mask) : haps.size();  // membership.len() vs haplotypes_in_group.len()
+  if (members <= 1) return NAN;
+  if (L < 0) return 0.0;
+  if (L == 0) return INFINITY;
+  if (!dense_arm) {  // stats.rs:4353-4374
+    size_t hap_samples = 0;
+    for (auto& h : haps) hap_samples = std::max(hap_samples, h.first + 1);
+    if (membership_total(haps, std::max(N, hap_samples)) <= 1) return NAN;
+  }
+  const int64_t eff = sat_sub(L, (int64_t)tot.uncallable_sites);
+  return eff == 0 ? NAN : tot.pi_sum / (double)eff;
+}
+
 struct SiteDiv { int64_t pos1; double pi, theta; };
 struct GroupStats { bool present = false; size_t segsites = 0, n_hap = 0; double theta = 0.0, pi = 0.0; vector<SiteDiv> sites; };
 
@@ -730,17 +748,7 @@ void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix&
     if (!out[g].present) continue;
     out[g].segsites = (size_t)tot[g].segregating_sites;
     out[g].theta = watterson_theta(out[g].segsites, out[g].n_hap, L);
-    const size_t members = dense_arm ? mask_count(masks[g]) : out[g].n_hap;  // membership.len() vs haplotypes_in_group.len()
-    double pi;
-    if (members <= 1) pi = NAN;
-    else if (L < 0) pi = 0.0;
-    else if (L == 0) pi = INFINITY;
-    else if (!dense_arm && membership_total(haps[g], std::max(N, [&] { size_t m = 0; for (auto& h : haps[g]) m = std::max(m, h.first + 1); return m; }())) <= 1) pi = NAN;  // stats.rs:4353-4374
-    else {
-      const int64_t eff = sat_sub(L, (int64_t)tot[g].uncallable_sites);
-      pi = eff == 0 ? NAN : tot[g].pi_sum / (double)eff;
-    }
-    out[g].pi = pi;
+    out[g].pi = pi_from_totals(rm, haps[g], masks[g], N, L, tot[g]);
     // calculate_per_site_diversity (stats.rs:4628-4806): needs >= 2 listed haplotypes
     if (haps[g].size() < 2 || hal_len(interval) <= 0) continue;
     Groups one(dm, {masks[g]});
@@ -850,6 +858,108 @@ WcRegion wc_haplotype_groups(const vector<const Variant*>& vs, const RegionMatri
   return out;
 }
 
+// ---- CSV-defined populations (stats.rs:816-1078, process.rs:3301-3392, 4054-4089) ---------------------------
+typedef std::map<string, vector<string>> PopulationCsv;
+
+PopulationCsv parse_population_csv(const string& path) {  // stats.rs:951-1007
+  std::ifstream in(path);
+  if (!in) throw Error("Failed to open population CSV file " + path);
+  PopulationCsv out;
+  string line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (trim(line).empty() || starts_with(line, "#")) continue;
+    vector<string> parts = split(line, ',');
+    for (auto& x : parts) x = trim(x);
+    if (parts.empty() || parts[0].empty()) continue;
+    vector<string> samples;
+    for (size_t i = 1; i < parts.size(); ++i) if (!parts[i].empty()) samples.push_back(parts[i]);
+    if (!samples.empty()) out[parts[0]] = samples;
+  }
+  if (out.empty()) throw Error("Population CSV file '" + path + "' contains no valid population data after parsing.");
+  return out;
+}
+
+struct WcEstimate { int state = 3; std::optional<double> value; double sum_a = 0.0, sum_b = 0.0; size_t sites = 0; };
+
+WcEstimate wc_estimate(double a, double b, size_t sites) {
+  WcEstimate e;
+  e.state = wc_classify(a, b);
+  e.sum_a = a; e.sum_b = b; e.sites = sites;
+  if (e.state == 0) e.value = a / (a + b);
+  return e;
+}
+
+// calculate_fst_wc_csv_populations (stats.rs:816-934): regional overall + pairwise estimates as TSV rows
+vector<vector<string>> wc_csv_population_rows(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
+                                              const PopulationCsv& csv, const ConfigEntry& entry, int device) {
+  const size_t N = sample_names.size();
+  const auto index = map_sample_names_to_indices(sample_names);
+  std::map<string, string> sample_to_pop;  // later populations overwrite earlier ones (stats.rs:1062-1067)
+  for (auto& kv : csv) for (auto& sid : kv.second) sample_to_pop[sid] = kv.first;
+  std::map<size_t, string> idx_to_pop;
+  for (auto& kv : sample_to_pop) {
+    auto it = index.find(normalize_sample_name(kv.first));
+    if (it != index.end()) idx_to_pop[it->second] = kv.second;
+  }
+  std::set<string> label_set;
+  for (auto& kv : idx_to_pop) label_set.insert(kv.second);
+  vector<string> labels(label_set.begin(), label_set.end());
+  const size_t G = labels.size();
+  const string rs = std::to_string(entry.interval.first + 1), re = std::to_string(entry.interval.second);
+  auto row = [&](const string& kind, const string& p1, const string& p2, const WcEstimate& e) {
+    return vector<string>{entry.seqname, rs, re, kind, p1, p2, fmt_opt(e.value), fmt_opt(e.sum_a), fmt_opt(e.sum_a + e.sum_b), std::to_string(e.sites)};
+  };
+  vector<vector<string>> rows;
+  WcEstimate insufficient;
+  if (vs.empty()) { rows.push_back(row("overall", "ALL", "ALL", insufficient)); return rows; }  // sites_attempted 0, no pair keys
+  const DeviceMatrix& dm = *rm.dm;
+  const size_t S = dm.variants, P = dm.ploidy;
+  if (G > FMH_MAX_GROUPS) throw Error("--fst_populations: more than 8 populations present in the VCF are not supported on the device yet");
+  if (G < 2) {
+    Groups all(dm, {vector<uint8_t>(N * P, 1)});
+    DevBuf dcalled(device, 4 * S);
+    fmh_pop_totals t;
+    fmh_check(fmh_population_summaries(dm.h, all.h, 0, S, FMH_FORMULA_SPARSE, nullptr, (uint32_t*)dcalled.p, &t, nullptr), "summaries");
+    size_t informative = 0;
+    for (uint32_t c : dcalled.fetch<uint32_t>(S)) informative += c != 0;
+    WcEstimate e;
+    if (informative) { e = wc_estimate(0.0, 0.0, informative); } else { e.sites = S; }
+    rows.push_back(row("overall", "ALL", "ALL", e));
+    return rows;
+  }
+  vector<vector<uint8_t>> masks(G, vector<uint8_t>(N * P, 0));
+  for (auto& kv : idx_to_pop) {
+    const size_t gi = std::find(labels.begin(), labels.end(), kv.second) - labels.begin();
+    for (size_t k = 0; k < std::min<size_t>(P, 2); ++k) if (kv.first < N) masks[gi][kv.first * P + k] = 1;
+  }
+  Groups grp(dm, masks);
+  fmh_wc_totals tot;
+  fmh_check(fmh_wc_sweep(dm.h, grp.h, 0, S, nullptr, nullptr, nullptr, nullptr, &tot, nullptr), "wc sweep");
+  WcEstimate overall;
+  if (tot.informative_sites[0] == 0) overall.sites = S; else overall = wc_estimate(tot.sum_a[0], tot.sum_b[0], (size_t)tot.informative_sites[0]);
+  rows.push_back(row("overall", "ALL", "ALL", overall));
+  if (tot.informative_sites[0] != 0) {  // pair keys exist only if some site had any called allele
+    std::map<string, WcEstimate> pairs;
+    size_t k = 1;
+    for (size_t i = 0; i < G; ++i)
+      for (size_t j = i + 1; j < G; ++j, ++k) {
+        WcEstimate e;
+        if (tot.informative_sites[k] != 0) e = wc_estimate(tot.sum_a[k], tot.sum_b[k], (size_t)tot.informative_sites[k]);
+        else e.sites = (size_t)tot.informative_sites[0];
+        pairs[labels[i] + "_vs_" + labels[j]] = e;
+      }
+    for (auto& kv : pairs) {
+      vector<string> parts;
+      size_t b = 0;
+      for (;;) { size_t e = kv.first.find("_vs_", b); if (e == string::npos) { parts.push_back(kv.first.substr(b)); break; } parts.push_back(kv.first.substr(b, e - b)); b = e + 4; }
+      if (parts.size() == 2) rows.push_back(row("pairwise", parts[0], parts[1], kv.second));
+      else rows.push_back(row("pairwise", "unknown", "unknown", kv.second));
+    }
+  }
+  return rows;
+}
+
 struct HudsonRegion {
   bool have_outcome = false;
   std::optional<double> fst, dxy, pi0, pi1, avg;
@@ -858,7 +968,7 @@ struct HudsonRegion {
 
 // calculate_hudson_fst_for_pair_with_sites (stats.rs:3619) for haplotype groups 0 / 1 of the filtered set
 HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
-                           const HapList& h0, const HapList& h1, int64_t L, const GroupStats pair_stats[2], int device) {
+                           const HapList& h0, const HapList& h1, int64_t L, const double pi_raw[2], int device) {
   HudsonRegion out;
   if (L <= 0) return out;  // Err(InvalidRegion) -> logged, no outcome (process.rs:3261-3271)
   out.have_outcome = true;
@@ -884,7 +994,7 @@ HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix&
   // auxiliaries (stats.rs:3562-3565): calculate_pi_for_population x2 == the filtered process_variants pi of the same
   // haplotype lists and length; calculate_d_xy_hudson: dense shared / sparse fold share the frequency-dot form
   for (int g = 0; g < 2; ++g) {
-    const double raw = pair_stats[g].pi;
+    const double raw = pi_raw[g];
     (g == 0 ? out.pi0 : out.pi1) = std::isfinite(raw) ? std::optional<double>(raw) : std::nullopt;
   }
   if (!h0.empty() && !h1.empty()) {
@@ -935,6 +1045,7 @@ struct RegionOutput {
   vector<WcSite> wc_sites;
   vector<std::tuple<int64_t, double, double, double>> hudson_sites;
   vector<vector<string>> hudson_rows;
+  vector<vector<string>> wc_rows;
 };
 
 string diversity_falsta(const RegionOutput& r) {  // append_diversity_falsta, process.rs:3740-3806
@@ -1010,7 +1121,8 @@ struct Args {
 };
 
 std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry, const VcfData& vcf, const RegionMap& mask,
-                                                        const RegionMap* allow, int64_t chr_length, const string& chr, const Args& args) {
+                                                        const RegionMap* allow, int64_t chr_length, const string& chr, const Args& args,
+                                                        const PopulationCsv* csv_for_hudson) {
   const Interval ext = from_1based_inclusive(std::max<int64_t>(entry.interval.first - 3000000, 0),
                                              std::min<int64_t>(wrap_add(entry.interval.second, 3000000), chr_length));
   const vector<Interval>* allow_chr = nullptr;
@@ -1028,7 +1140,14 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
   RegionMatrix m_unf = build_matrix(unf, N, args.device), m_fil = build_matrix(fil, N, args.device);
 
   WcRegion wc;
-  if (args.enable_fst) wc = wc_haplotype_groups(fil, m_fil, vcf.sample_names, entry.samples_filtered, args.device);
+  vector<vector<string>> wc_rows;
+  if (args.enable_fst) {
+    wc = wc_haplotype_groups(fil, m_fil, vcf.sample_names, entry.samples_filtered, args.device);
+    if (!args.fst_populations.empty()) {  // process.rs:2769-2802: the CSV is re-read here, without exclusions
+      try { wc_rows = wc_csv_population_rows(fil, m_fil, vcf.sample_names, parse_population_csv(args.fst_populations), entry, args.device); }
+      catch (const Error& e) { logmsg("ERROR", string("Error calculating population FST: ") + e.what()); }
+    }
+  }
 
   const int64_t sequence_length = (int64_t)((uint64_t)entry.interval.second - (uint64_t)entry.interval.first);
   const int64_t adj = adjusted_sequence_length(entry.interval.first + 1, entry.interval.second, allow_chr, mask_chr);
@@ -1058,7 +1177,8 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
     const HapList h0 = haplotypes_for_group(0, entry.samples_filtered, index), h1 = haplotypes_for_group(1, entry.samples_filtered, index);
     const bool region_valid = (uint64_t)entry.interval.second > (uint64_t)entry.interval.first;
     if (h0.size() >= 2 && h1.size() >= 2 && region_valid) {
-      hud = hudson_groups(fil, m_fil, vcf.sample_names, h0, h1, fil_adj, sf, args.device);
+      const double pis[2] = {sf[0].pi, sf[1].pi};
+      hud = hudson_groups(fil, m_fil, vcf.sample_names, h0, h1, fil_adj, pis, args.device);
       if (hud.have_outcome) {
         out.hudson_rows.push_back({entry.seqname, std::to_string(entry.interval.first), std::to_string(entry.interval.second - 1),
                                    "HaplotypeGroup", "0", "HaplotypeGroup", "1", fmt_opt(hud.dxy), fmt_opt(hud.pi0), fmt_opt(hud.pi1),
@@ -1067,6 +1187,46 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
       }
     }
   }
+  if (args.enable_fst && csv_for_hudson) {  // process.rs:3301-3392
+    const auto index = map_sample_names_to_indices(vcf.sample_names);
+    std::map<string, HapList> pop_haps;
+    for (auto& kv : *csv_for_hudson) {
+      HapList hl;
+      for (auto& sid : kv.second) { auto it = index.find(sid); if (it != index.end()) { hl.push_back({it->second, 0}); hl.push_back({it->second, 1}); } }
+      if (!hl.empty()) pop_haps[kv.first] = hl;
+    }
+    // pi of every population present (calculate_pi_for_population), eight populations per sweep
+    std::map<string, double> pop_pi;
+    vector<string> names;
+    for (auto& kv : pop_haps) names.push_back(kv.first);
+    if (!fil.empty()) {
+      const bool dense_arm = m_fil.has_dense && m_fil.ploidy == 2;
+      for (size_t b = 0; b < names.size(); b += FMH_MAX_GROUPS) {
+        const size_t cnt = std::min<size_t>(FMH_MAX_GROUPS, names.size() - b);
+        vector<vector<uint8_t>> masks;
+        for (size_t i = 0; i < cnt; ++i) masks.push_back(mask_of(pop_haps[names[b + i]], N, m_fil.dm->ploidy, true));
+        Groups grp(*m_fil.dm, masks);
+        fmh_pop_totals tot[FMH_MAX_GROUPS];
+        fmh_check(fmh_population_summaries(m_fil.dm->h, grp.h, 0, m_fil.dm->variants, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE, nullptr, nullptr, tot, nullptr), "summaries");
+        for (size_t i = 0; i < cnt; ++i) pop_pi[names[b + i]] = pi_from_totals(m_fil, pop_haps[names[b + i]], masks[i], N, fil_adj, tot[i]);
+      }
+    } else {
+      for (auto& n : names) pop_pi[n] = pop_haps[n].size() <= 1 ? NAN : (fil_adj < 0 ? 0.0 : (fil_adj == 0 ? INFINITY : 0.0 / (double)fil_adj));
+    }
+    const bool region_valid = (uint64_t)entry.interval.second > (uint64_t)entry.interval.first;
+    for (size_t i = 0; i < names.size(); ++i)
+      for (size_t j = i + 1; j < names.size(); ++j) {
+        const HapList &ha = pop_haps[names[i]], &hb = pop_haps[names[j]];
+        if (ha.size() < 2 || hb.size() < 2 || !region_valid) continue;
+        const double pis[2] = {pop_pi[names[i]], pop_pi[names[j]]};
+        HudsonRegion h = hudson_groups(fil, m_fil, vcf.sample_names, ha, hb, fil_adj, pis, args.device);
+        if (!h.have_outcome) continue;
+        out.hudson_rows.push_back({entry.seqname, std::to_string(entry.interval.first), std::to_string(entry.interval.second - 1),
+                                   "NamedPopulation", names[i], "NamedPopulation", names[j], fmt_opt(h.dxy), fmt_opt(h.pi0), fmt_opt(h.pi1),
+                                   fmt_opt(h.avg), fmt_opt(h.fst)});
+      }
+  }
+  out.wc_rows = wc_rows;
   // CsvRowData (process.rs:3429-3466)
   std::optional<double> hap_a, hap_b;
   std::optional<size_t> hap_sites;
@@ -1135,7 +1295,13 @@ int run(const Args& args) {
     throw Error("Parse(\"Either --config_file or --chr must be specified\")");
   }
   if (args.enable_pca) logmsg("WARN", "--pca is outside the accelerated path and is ignored (DESIGN.md section 8)");
-  if (!args.fst_populations.empty()) logmsg("WARN", "--fst_populations (CSV-defined populations) is not built yet; haplotype-group FST only");
+  std::optional<PopulationCsv> csv_for_hudson;  // process.rs:1394-1426: parsed once, exclusions removed
+  if (args.enable_fst && !args.fst_populations.empty()) {
+    try {
+      csv_for_hudson = parse_population_csv(args.fst_populations);
+      for (auto& kv : *csv_for_hudson) kv.second.erase(std::remove_if(kv.second.begin(), kv.second.end(), [&](const string& x) { return exclusion.count(x) > 0; }), kv.second.end());
+    } catch (const Error& e) { logmsg("ERROR", string("Failed to parse population CSV: ") + e.what()); }
+  }
 
   const string out_dir = dirname_of(args.output_file);
   mkdirs(out_dir);
@@ -1149,7 +1315,8 @@ int run(const Args& args) {
 
   std::map<string, vector<const ConfigEntry*>> by_chr;
   for (auto& e : entries) by_chr[e.seqname].push_back(&e);
-  vector<vector<string>> hudson_rows;
+  vector<vector<string>> hudson_rows, wc_rows;
+  const string wc_path = out_dir + "/wc_fst_results.tsv.gz";
   for (auto& kv : by_chr) {
     const string& chr = kv.first;
     try {
@@ -1170,7 +1337,8 @@ int run(const Args& args) {
       catch (const Error& e) { logmsg("ERROR", "Error processing VCF for " + chr + ": " + e.what()); continue; }
       for (auto* e : kv.second) {
         std::optional<RegionOutput> res;
-        try { res = process_single_config_entry(*e, vcf, final_mask, allow_regions ? &*allow_regions : nullptr, chr_length, chr, args); }
+        try { res = process_single_config_entry(*e, vcf, final_mask, allow_regions ? &*allow_regions : nullptr, chr_length, chr, args,
+                                                  csv_for_hudson ? &*csv_for_hudson : nullptr); }
         catch (const Error& err) { logmsg("ERROR", string("DROPPED: Error processing region: ") + err.what()); continue; }
         if (!res) continue;
         csv << join(res->csv_row, ',', true) << "\n";
@@ -1178,6 +1346,7 @@ int run(const Args& args) {
         if (!d.empty()) gz_append(div_path, d);
         if (!f.empty()) gz_append(fst_path, f);
         for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
+        for (auto& r : res->wc_rows) wc_rows.push_back(r);
       }
     } catch (const Error& e) {
       fprintf(stderr, "Error processing chromosome %s: %s\n", chr.c_str(), e.what());
@@ -1190,6 +1359,12 @@ int run(const Args& args) {
     string text = "chr\tregion_start_0based\tregion_end_0based\tpop1_id_type\tpop1_id_name\tpop2_id_type\tpop2_id_name\tDxy\tpi_pop1\tpi_pop2\tpi_xy_avg\tFST\n";
     for (auto& r : hudson_rows) text += join(r, '\t') + "\n";
     gz_append(hudson_path, text);
+    if (!wc_rows.empty()) {  // process.rs:1628-1726
+      remove(wc_path.c_str());
+      string wt = "chr\tregion_start_1based\tregion_end_1based\tcomparison_type\tpop1\tpop2\tfst\tnumerator_a\tdenominator_a_plus_b\tinformative_sites\n";
+      for (auto& r : wc_rows) wt += join(r, '\t') + "\n";
+      gz_append(wc_path, wt);
+    }
   }
   printf("Wrote FASTA-style per-site diversity data to per_site_diversity_output.falsta.gz\n");
   printf("Wrote FASTA-style per-site FST data to per_site_fst_output.falsta.gz\n");

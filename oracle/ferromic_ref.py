@@ -726,6 +726,55 @@ def calculate_fst_wc_haplotype_groups(variants, sample_names, sample_to_group_ma
     return FstWcResults(overall, pw, agg, sites, "haplotype_groups")
 
 
+def parse_population_csv(csv_path: str) -> Dict[str, List[str]]:
+    """stats.rs:951-1007: population label, then its sample IDs; '#' comments and blank lines skipped."""
+    population_map: Dict[str, List[str]] = {}
+    with open(csv_path) as fh:
+        for line in fh:
+            line = line.rstrip("\n").rstrip("\r")
+            if line.strip() == "" or line.startswith("#"):
+                continue
+            parts = [x.strip() for x in line.split(",")]
+            if not parts or parts[0] == "":
+                continue
+            samples = [x for x in parts[1:] if x != ""]
+            if samples:
+                population_map[parts[0]] = samples
+    if not population_map:
+        raise VcfError("Parse", f"Population CSV file '{csv_path}' contains no valid population data after parsing.")
+    return population_map
+
+
+def map_samples_to_populations(sample_names, population_assignments) -> Dict[Tuple[int, int], str]:
+    # stats.rs:1054-1078
+    out: Dict[Tuple[int, int], str] = {}
+    idx_of = map_sample_names_to_indices(sample_names)
+    csv_sample_to_pop: Dict[str, str] = {}
+    for pop_name, samples in population_assignments.items():
+        for sid in samples:
+            csv_sample_to_pop[sid] = pop_name
+    for csv_name, pop_name in csv_sample_to_pop.items():
+        vcf_idx = idx_of.get(normalize_sample_name_for_lookup(csv_name))
+        if vcf_idx is not None:
+            out[(vcf_idx, LEFT)] = pop_name
+            out[(vcf_idx, RIGHT)] = pop_name
+    return out
+
+
+def calculate_fst_wc_csv_populations(variants, sample_names, csv_path: str, region: QueryRegion) -> FstWcResults:
+    # stats.rs:816-934
+    assignments = parse_population_csv(csv_path)
+    membership = SubpopulationMembership.from_map(len(sample_names), map_samples_to_populations(sample_names, assignments))
+    sites = []
+    for variant in variants:
+        if not region.contains(variant.position):
+            continue
+        overall, pw, comps, sizes, pw_comps = calculate_fst_wc_at_site_with_membership(variant, membership)
+        sites.append(SiteFstWc(variant.position + 1, overall, pw, comps, sizes, pw_comps))
+    overall, pw, agg = calculate_overall_fst_wc(sites)
+    return FstWcResults(overall, pw, agg, sites, "population_groups")
+
+
 def extract_wc_fst_components(e: FstEstimate):  # stats.rs:4860-4914
     return e.value, e.sum_a, e.sum_b, e.sites
 

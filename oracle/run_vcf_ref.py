@@ -550,7 +550,7 @@ WC_TSV_HEADER = ["chr", "region_start_1based", "region_end_1based", "comparison_
 
 
 def process_single_config_entry(entry: ConfigEntry, all_variants, all_flags, sample_names, mask, allow, chr_length,
-                                chrom, enable_fst, csv_populations=None) -> Optional[RegionResult]:
+                                chrom, enable_fst, csv_populations=None, csv_path=None) -> Optional[RegionResult]:
     """process.rs:2468-3653 (statistics and records only)."""
     ext = R._hal_from_1based_inclusive(max(entry.interval[0] - 3_000_000, 0), min(_wrap_i64(entry.interval[1] + 3_000_000), chr_length))
     sl = [(v, f) for v, f in zip(all_variants, all_flags) if ext[0] <= v.position < ext[1]]
@@ -571,9 +571,15 @@ def process_single_config_entry(entry: ConfigEntry, all_variants, all_flags, sam
     index_map = R.map_sample_names_to_indices(sample_names)
 
     wc = None
+    pop_wc = None
     if enable_fst:
         qr = R.QueryRegion(entry.interval[0], entry.interval[1] - 1 if entry.interval[1] > 0 else -1)
         wc = R.calculate_fst_wc_haplotype_groups(fil, sample_names, entry.samples_filtered, qr)
+        if csv_path is not None:  # process.rs:2769-2802
+            try:
+                pop_wc = R.calculate_fst_wc_csv_populations(fil, sample_names, csv_path, qr)
+            except (R.VcfError, OSError):
+                pop_wc = None
     sequence_length = entry.interval[1] - entry.interval[0]
     adj = R.calculate_adjusted_sequence_length(entry.interval[0] + 1, entry.interval[1], allow_chr, mask_chr)
     callable_fraction = adj / sequence_length if sequence_length > 0 else R.NAN
@@ -679,7 +685,18 @@ def process_single_config_entry(entry: ConfigEntry, all_variants, all_flags, sam
             on, ow = s.variance_components
             pn, pw = s.pairwise_variance_components.get("0_vs_1", (R.NAN, R.NAN))
             wc_sites.append((s.position, ov, on, on + ow, pv, pn, pn + pw))
-    return RegionResult(row, entry.seqname, rs1, re1, diversity, wc_sites, hudson_sites, hudson_rows)
+    wc_rows: List[List[str]] = []
+    if pop_wc is not None:  # RegionalWcFSTOutcome rows, process.rs:1662-1716
+        def wc_row(kind, p1, p2, est):
+            denom = est.sum_a + est.sum_b
+            return [entry.seqname, str(rs1), str(re1), kind, p1, p2, format_optional_float(est.value),
+                    format_optional_float(est.sum_a), format_optional_float(denom), format_optional_usize(est.sites)]
+        wc_rows.append(wc_row("overall", "ALL", "ALL", pop_wc.overall_fst))
+        for key in sorted(pop_wc.pairwise_fst):
+            parts = key.split("_vs_")
+            p1, p2 = (parts[0], parts[1]) if len(parts) == 2 else ("unknown", "unknown")
+            wc_rows.append(wc_row("pairwise", p1, p2, pop_wc.pairwise_fst[key]))
+    return RegionResult(row, entry.seqname, rs1, re1, diversity, wc_sites, hudson_sites, hudson_rows, wc_rows)
 
 
 def resolve_sample_exclusions(vcf_folder, chrom, requested, config_entries):
@@ -714,7 +731,8 @@ def resolve_sample_exclusions(vcf_folder, chrom, requested, config_entries):
 
 def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file: Optional[str] = None,
         chrom: Optional[str] = None, region: Optional[str] = None, min_gq: int = 30, mask_file: Optional[str] = None,
-        allow_file: Optional[str] = None, exclude: Sequence[str] = (), enable_fst: bool = False) -> Dict[str, str]:
+        allow_file: Optional[str] = None, exclude: Sequence[str] = (), enable_fst: bool = False,
+        fst_populations: Optional[str] = None) -> Dict[str, str]:
     """run_vcf.rs:216-486 + process_config_entries (process.rs:1335-1730).  Writes the output files
     next to `output_file` and returns their decompressed text by name."""
     mask = parse_regions_file(mask_file) if mask_file else None
@@ -748,6 +766,13 @@ def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file
     else:
         raise R.VcfError("Parse", "Either --config_file or --chr must be specified")
 
+    csv_populations = None
+    if enable_fst and fst_populations:  # process.rs:1394-1426
+        try:
+            csv_populations = {k: [x for x in v if x not in exclusion] for k, v in R.parse_population_csv(fst_populations).items()}
+        except (R.VcfError, OSError):
+            csv_populations = None
+    wc_rows: List[List[str]] = []
     by_chr: Dict[str, List[ConfigEntry]] = {}
     for e in entries:
         by_chr.setdefault(e.seqname, []).append(e)
@@ -779,7 +804,8 @@ def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file
             continue
         for e in chr_entries:
             try:
-                res = process_single_config_entry(e, variants, flags, sample_names, gmask, allow, chr_length, chrom_name, enable_fst)
+                res = process_single_config_entry(e, variants, flags, sample_names, gmask, allow, chr_length, chrom_name, enable_fst,
+                                                  csv_populations, fst_populations if enable_fst else None)
             except R.VcfError:
                 continue
             if res is None:
@@ -788,6 +814,7 @@ def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file
             div_text.append(diversity_falsta_text(res))
             fst_text.append(fst_falsta_text(res))
             hudson_rows += res.hudson_rows
+            wc_rows += res.wc_rows
     outputs = {os.path.basename(output_file): "".join(x + "\n" for x in csv_lines)}
     with open(output_file, "w") as fh:
         fh.write(outputs[os.path.basename(output_file)])
@@ -802,4 +829,9 @@ def run(vcf_folder: str, reference: str, gtf: str, output_file: str, config_file
         outputs["hudson_fst_results.tsv.gz"] = text
         with gzip.open(os.path.join(out_dir, "hudson_fst_results.tsv.gz"), "wt") as fh:
             fh.write(text)
+        if wc_rows:  # process.rs:1628-1726
+            text = "".join("\t".join(r) + "\n" for r in [WC_TSV_HEADER] + wc_rows)
+            outputs["wc_fst_results.tsv.gz"] = text
+            with gzip.open(os.path.join(out_dir, "wc_fst_results.tsv.gz"), "wt") as fh:
+                fh.write(text)
     return outputs

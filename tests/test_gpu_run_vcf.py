@@ -20,7 +20,7 @@ BIN = os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")
 
 def run_binary(out_csv, **kw):
     cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--output_file", out_csv]
-    for key in ("config_file", "mask_file", "allow_file"):
+    for key in ("config_file", "mask_file", "allow_file", "fst_populations"):
         if kw.get(key):
             cmd += [f"--{key}", kw[key]]
     if kw.get("chrom"):
@@ -38,7 +38,8 @@ def run_binary(out_csv, **kw):
     out = {}
     d = os.path.dirname(out_csv)
     out[os.path.basename(out_csv)] = open(out_csv).read()
-    for name in ("per_site_diversity_output.falsta.gz", "per_site_fst_output.falsta.gz", "hudson_fst_results.tsv.gz"):
+    for name in ("per_site_diversity_output.falsta.gz", "per_site_fst_output.falsta.gz", "hudson_fst_results.tsv.gz",
+                 "wc_fst_results.tsv.gz"):
         p = os.path.join(d, name)
         if os.path.exists(p):
             out[name] = gzip.open(p, "rt").read()
@@ -66,7 +67,7 @@ def compare(got, exp):
     for name in exp:
         if name.endswith(".csv"):
             assert_tables_close(got[name], exp[name], ",", name)
-        elif name.startswith("hudson"):
+        elif name.startswith("hudson") or name.startswith("wc_fst"):
             assert_tables_close(got[name], exp[name], "\t", name)
         else:
             assert got[name] == exp[name], f"{name} differs"  # per-site tracks are bit-exact -> identical text
@@ -194,6 +195,25 @@ def test_synthetic_cohort(tmp_path, variant):
     assert len(rows) == 6  # header + 5 surviving regions
     if variant in ("fst", "fst_mask_allow_exclude"):
         assert any("NA" not in r.split(",")[25:30] for r in rows[1:])  # some region has a calculable W&C FST
+
+
+def test_csv_defined_populations(tmp_path):
+    """--fst_populations: W&C + Hudson between CSV-defined populations (stats.rs:816-1078, process.rs:3301-3392)
+    and the fifth output file, wc_fst_results.tsv.gz."""
+    kw, names = make_cohort(tmp_path, seed=21, n_samples=18)
+    pops = {"AFR": [n for n in names if "_A_" in n], "EUR": [n for n in names if "_B_" in n] + ["NOT_IN_VCF"],
+            "EAS": [n for n in names if "_C_" in n]}
+    text = "# population,samples...\n\n" + "".join(f"{k}, " + " , ".join(v) + "\n" for k, v in pops.items()) + "EMPTY\n"
+    (tmp_path / "pops.csv").write_text(text)
+    kw.update(enable_fst=True, fst_populations=str(tmp_path / "pops.csv"), exclude=[names[4]])
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), **kw)
+    compare(got, exp)
+    wc = got["wc_fst_results.tsv.gz"].splitlines()
+    assert wc[0].split("\t") == V.WC_TSV_HEADER
+    assert sum(1 for r in wc if "\tpairwise\t" in r) == 3 * 5 and sum(1 for r in wc if "\toverall\tALL\tALL\t" in r) == 5
+    hud = got["hudson_fst_results.tsv.gz"]
+    assert "NamedPopulation\tAFR\tNamedPopulation\tEAS" in hud and "HaplotypeGroup\t0\tHaplotypeGroup\t1" in hud
 
 
 def test_single_chromosome_mode(tmp_path):
