@@ -123,6 +123,7 @@ SYMBOLS = {
     "fmh_hudson_sweep": (_i, [_vp, _vp, _sz, _sz, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_diversity_sites": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(PopTotals), _vp]),
     "fmh_wc_sweep": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(WcTotals), _vp]),
+    "fmh_pairwise_differences": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "fmh_hudson_totals_pack": (_i, [_P(HudsonTotals), _P(_d), _P(_u64)]),
     "fmh_hudson_totals_unpack": (_i, [_P(HudsonTotals), _P(_d), _P(_u64)]),
     "fmh_timing_enable": (_i, [_i]),
@@ -131,6 +132,32 @@ SYMBOLS = {
 }
 
 _lib: Optional[C.CDLL] = None
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One process must hold ONE HIP runtime.  A PyTorch-ROCm wheel bundles its own libamdhip64.so; if
+    libferromic_hip.so pulled in /opt/rocm's copy first, a later `import torch` would load a second
+    runtime and see no GPUs.  When a torch wheel with a bundled runtime is installed (found without
+    importing torch), map that copy first so both sides bind to it."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch already loaded its runtime; the dynamic linker reuses it by SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for base in spec.submodule_search_locations:
+        cand = os.path.join(base, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
 
 
 def load() -> C.CDLL:
@@ -143,6 +170,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ferromic_amd/csrc`). ferromic_amd has no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

@@ -957,10 +957,44 @@ def watterson_theta(segregating_sites, sample_count, sequence_length) -> float:
     return math.nan if segregating_sites == 0 else math.inf
 
 
-def pairwise_differences(variants, sample_count, sequence_length):
-    raise NotImplementedError(
-        "pairwise_differences (stats.rs:4106-4231) is not part of the per-site sweep this build accelerates "
-        "(SURVEY.md section 8 row f-4)")
+def pairwise_differences(variants, sample_count, sequence_length) -> List[PairwiseDifference]:
+    """pairwise_differences_py (lib.rs:1620-1636) -> calculate_pairwise_differences (stats.rs:4106-4231).
+    The all-vs-all allele comparison of every sample pair is a Gram product over sites on the GPU
+    (fmh_pairwise_differences); ploidy detection and the comparable-site arithmetic are host scalars."""
+    if sequence_length <= 0:
+        raise ValueError("sequence_length must be a positive integer")
+    if sample_count < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    store = _Store.from_python(variants)
+    n = int(sample_count)
+    S = store.count
+    N = store.data.shape[1] if S else 0
+    # haplotype_counts: length of the first Some genotype of each sample (stats.rs:4124-4137)
+    hap_counts = [0] * n
+    if S:
+        some = store.called[:, :, 0]                       # [S, N]
+        lens = store.called.sum(axis=2)                    # prefix property -> genotype length
+        for idx in range(min(n, N)):
+            rows = np.nonzero(some[:, idx] & (idx < store.num_samples))[0]
+            if rows.size:
+                hap_counts[idx] = int(lens[rows[0], idx])
+    m = min(n, N)
+    diff = both = None
+    if S and m >= 2:
+        diff, both = dev.pairwise_differences(store.device_matrix(), m)
+    out = []
+    L = int(sequence_length)
+    for i in range(n):
+        for j in range(i + 1, n):
+            hi, hj = hap_counts[i], hap_counts[j]
+            if hi == 0 or hj == 0:
+                out.append(PairwiseDifference(i, j, 0, 0))
+                continue
+            product = hi * hj
+            d = int(diff[i, j])
+            missing_sites = S - int(both[i, j])
+            out.append(PairwiseDifference(i, j, d, max(L * product - missing_sites * product, 0)))
+    return out
 
 
 def per_site_diversity(variants, haplotypes, region=None) -> List[DiversitySite]:

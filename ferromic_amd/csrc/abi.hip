@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -717,6 +718,43 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
       h_totals->informative_sites[slot_of[k]] = r.u64[kOffWcInf + k];
     }
   }
+  return FMH_OK;
+}
+
+extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
+                                        unsigned long long* d_both, void* stream) {
+  if (!m || !d_diff || !d_both) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n_samples > m->samples) return fail(FMH_ERR_INVALID, "n_samples %zu exceeds the matrix's %zu samples", n_samples, m->samples);
+  if (m->max_allele > 15) return fail(FMH_ERR_UNSUPPORTED, "pairwise differences support max_allele <= 15 (got %u)", m->max_allele);
+  FMH_TRY(use_device(m->device));
+  if (n_samples < 2 || m->variants == 0) return FMH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_alleles = (int)m->max_allele + 1;
+  const int n_planes = n_alleles + 2;
+  const size_t n_pad = round_up(n_samples, kPdTile), s_pad = round_up(m->variants, kPdTile);
+  uint8_t* planes = nullptr;
+  const size_t bytes = (size_t)n_planes * n_pad * s_pad;
+  HIP_TRY(hipMalloc((void**)&planes, bytes));
+  hipError_t e = hipMemsetAsync(planes, 0, bytes, st);
+  if (e == hipSuccess) {
+    MatrixView mv{m->data, m->bits, m->pitch, m->bits_pitch, m->columns, m->nvec};
+    hipLaunchKernelGGL(pd_planes_kernel, dim3((unsigned)(s_pad / kPdTile), (unsigned)(n_pad / kPdTile)), dim3(256), 0, st, mv,
+                       m->variants, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, planes, n_pad, s_pad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    const size_t nt = n_pad / kPdTile, tiles = nt * (nt + 1) / 2;
+    // split K so that an i32 partial cannot overflow (<= 81 per site at ploidy 9) and the grid fills the chip
+    size_t k_chunk = round_up(std::min<size_t>(s_pad, (size_t)1 << 20), kPdTile);
+    while (tiles * ((s_pad + k_chunk - 1) / k_chunk) < 2048 && k_chunk > 4096) k_chunk = round_up(k_chunk / 2, kPdTile);
+    const size_t ksplit = (s_pad + k_chunk - 1) / k_chunk;
+    hipLaunchKernelGGL(pd_gram_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, st, planes, n_pad, s_pad, n_alleles,
+                       k_chunk, (uint32_t)n_samples, d_diff, d_both);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(planes);
+  if (e != hipSuccess) return fail(FMH_ERR_HIP, "pairwise differences failed: %s", hipGetErrorString(e));
   return FMH_OK;
 }
 

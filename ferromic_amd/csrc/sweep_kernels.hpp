@@ -932,4 +932,127 @@ __global__ void max_allele_kernel(const uint8_t* __restrict__ data, size_t pitch
   if ((threadIdx.x & 63) == 0) atomicMax(out, best);
 }
 
+// ------------------------------------------------------------------------------------------------
+// pairwise differences (calculate_pairwise_differences, stats.rs:4106-4231)
+//   diff(i, j) = sum over sites where both genotypes are Some of  len_i*len_j - sum_a cnt_i(a)*cnt_j(a)
+//   both(i, j) = number of sites where both genotypes are Some
+// Step 1 turns the site-major matrix into sample-major int8 planes (K = sites contiguous); step 2 is a
+// tiled Gram product on v_dot4_u32_u8 with split-K and exact integer atomics.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPdTile = 64;
+
+// planes[p][sample][s_pad]: p = 0..A allele counts, A+1 = genotype length, A+2 = valid (length > 0)
+__global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, size_t row_count, uint32_t samples,
+                                                        uint32_t ploidy, int n_alleles, uint8_t* __restrict__ planes,
+                                                        size_t n_pad, size_t s_pad) {
+  __shared__ uint8_t tile[kPdTile][kPdTile + 4];  // [sample][site]
+  const size_t site0 = (size_t)blockIdx.x * kPdTile;
+  const uint32_t samp0 = blockIdx.y * kPdTile;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const int n_planes = n_alleles + 2;
+  for (int p = 0; p < n_planes; ++p) {
+    for (int r = ty; r < kPdTile; r += 4) {  // r = site in tile, tx = sample in tile (coalesced along samples)
+      const size_t site = site0 + r;
+      const uint32_t smp = samp0 + tx;
+      uint8_t v = 0;
+      if (site < row_count && smp < samples) {
+        const uint8_t* row = mv.data + site * mv.pitch;
+        uint32_t len = 0;
+        uint32_t cnt = 0;
+        bool open = true;
+        for (uint32_t k = 0; k < ploidy; ++k) {
+          const uint32_t h = smp * ploidy + k;
+          bool called = true;
+          if (mv.bits) called = ((mv.bits[site * mv.bits_pitch + (h >> 3)] >> (h & 7)) & 1u) != 0;
+          open = open && called;  // CompressedGenotypes::get stops at the first missing allele
+          if (open) { ++len; if (p < n_alleles && row[h] == (uint8_t)p) ++cnt; }
+        }
+        v = p < n_alleles ? (uint8_t)cnt : (p == n_alleles ? (uint8_t)len : (uint8_t)(len > 0));
+      }
+      tile[tx][r] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < kPdTile; r += 4) {  // r = sample in tile, tx = site in tile (coalesced along sites)
+      planes[((size_t)p * n_pad + samp0 + r) * s_pad + site0 + tx] = tile[r][tx];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void pd_gram_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad,
+                                                      int n_alleles, size_t k_chunk, uint32_t n_samples,
+                                                      unsigned long long* __restrict__ diff,
+                                                      unsigned long long* __restrict__ both) {
+  // upper-triangular tile index -> (bi, bj), bi <= bj
+  const uint32_t nt = (uint32_t)(n_pad / kPdTile);
+  uint32_t t = blockIdx.x, bi = 0;
+  while (t >= nt - bi) { t -= nt - bi; ++bi; }
+  const uint32_t bj = bi + t;
+  __shared__ __align__(16) uint8_t sa[kPdTile][kPdTile + 16];
+  __shared__ __align__(16) uint8_t sb[kPdTile][kPdTile + 16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+  int32_t acc_d[4][4], acc_v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { acc_d[a][b] = 0; acc_v[a][b] = 0; }
+  const size_t k0 = (size_t)blockIdx.y * k_chunk;
+  const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
+  const int n_planes = n_alleles + 2;
+  for (size_t k = k0; k < k1; k += kPdTile) {
+    for (int p = 0; p < n_planes; ++p) {
+      // stage 64 rows x 64 bytes of both operands (one uint4 per thread per operand)
+      {
+        const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) * 16;
+        *reinterpret_cast<uint4*>(&sa[r][c]) = *reinterpret_cast<const uint4*>(planes + ((size_t)p * n_pad + (size_t)bi * kPdTile + r) * s_pad + k + c);
+        *reinterpret_cast<uint4*>(&sb[r][c]) = *reinterpret_cast<const uint4*>(planes + ((size_t)p * n_pad + (size_t)bj * kPdTile + r) * s_pad + k + c);
+      }
+      __syncthreads();
+      uint32_t part[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) part[a][b] = 0;
+#pragma unroll
+      for (int c = 0; c < kPdTile; c += 16) {
+        uint4 va[4], vb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) va[a] = *reinterpret_cast<const uint4*>(&sa[ty * 4 + a][c]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) vb[b] = *reinterpret_cast<const uint4*>(&sb[tx * 4 + b][c]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            uint32_t x = part[a][b];
+            x = dot4(va[a].x, vb[b].x, x); x = dot4(va[a].y, vb[b].y, x);
+            x = dot4(va[a].z, vb[b].z, x); x = dot4(va[a].w, vb[b].w, x);
+            part[a][b] = x;
+          }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (p < n_alleles) acc_d[a][b] -= (int32_t)part[a][b];
+          else if (p == n_alleles) acc_d[a][b] += (int32_t)part[a][b];
+          else acc_v[a][b] += (int32_t)part[a][b];
+        }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t i = bi * kPdTile + ty * 4 + a, j = bj * kPdTile + tx * 4 + b;
+      if (i < j && j < n_samples) {
+        // within one K chunk the per-site contributions sum to a non-negative value only over the whole
+        // range, so add as two's-complement 64-bit (exact, order-independent)
+        atomicAdd(&diff[(size_t)i * n_samples + j], (unsigned long long)(long long)acc_d[a][b]);
+        atomicAdd(&both[(size_t)i * n_samples + j], (unsigned long long)acc_v[a][b]);
+      }
+    }
+}
+
 }  // namespace fmh

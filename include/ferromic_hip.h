@@ -220,6 +220,20 @@ int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, siz
                  double* d_a, double* d_b, uint8_t* d_state, uint32_t* d_group_called,
                  fmh_wc_totals* h_totals, void* stream);
 
+/* ---- pairwise differences ------------------------------------------------------------------------- */
+/*
+ * Replaces the nested sample-pair loops of calculate_pairwise_differences (stats.rs:4158-4221) for the first
+ * n_samples samples of the matrix (sparse model: a genotype is Some iff its first allele is called, and ends
+ * at its first missing allele).  Row-major [n_samples][n_samples] device outputs, filled for i < j only:
+ *   d_diff[i*n + j] = sum over sites where both genotypes are Some of the all-vs-all allele mismatches
+ *                     (len_i*len_j - sum_a cnt_i(a)*cnt_j(a)),
+ *   d_both[i*n + j] = number of sites where both genotypes are Some
+ * (comparable sites = L*h_i*h_j - (variants - both)*h_i*h_j is host arithmetic, stats.rs:4182-4208).
+ * Both buffers must be zeroed by the caller.  Needs max_allele <= 15.
+ */
+int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
+                             unsigned long long* d_both, void* stream);
+
 /* ---- multi-GPU ---------------------------------------------------------------------------------- */
 /*
  * The region-sharded totals are plain sums: these pack/unpack them into the f64 + u64 vectors a

@@ -26,6 +26,8 @@ def test_module_surface_matches_reference():
         assert hasattr(fm, attr)
     with pytest.raises(NotImplementedError):
         fm.global_pca({}, [], "out")
+    with pytest.raises(ValueError, match="sequence_length"):
+        fm.pairwise_differences([], 3, 0)
 
 
 def test_watterson_theta_matches_rust_implementation(kats):

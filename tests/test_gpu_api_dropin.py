@@ -324,3 +324,34 @@ def test_wc_analytic_through_api(kats):
         assert site.overall_fst.state == c["state"] == res.overall_fst.state
         if c["fst"] is not None:
             assert res.pairwise_fst["0_vs_1"].value == pytest.approx(c["fst"], rel=1e-12)
+
+
+# ---- pairwise differences (stats_tests.rs:368-470 cases + random cohorts) -----------------------------
+
+
+@pytest.mark.parametrize("N,S,max_allele,p_missing,p_haploid", [(3, 3, 1, 0.0, 0.0), (9, 150, 1, 0.1, 0.1), (70, 300, 3, 0.05, 0.05),
+                                                                 (130, 64, 2, 0.0, 0.0)])
+def test_pairwise_differences(N, S, max_allele, p_missing, p_haploid):
+    rng = random.Random(N * 31 + S)
+    variants = H.random_sparse_variants(rng, S, N, max_allele, p_missing, p_haploid, 1 if p_missing else 0)
+    py_variants = [build_variant(v.position, [g for g in v.genotypes]) for v in variants]
+    L = variants[-1].position + 5
+    for n in (N, N + 2, max(N - 1, 2)):
+        got = fm.pairwise_differences(py_variants, n, L)
+        exp = R.calculate_pairwise_differences(variants, n, L)
+        assert len(got) == len(exp) == n * (n - 1) // 2
+        for g, ((i, j), d, c) in zip(got, exp):
+            assert (g.sample_i, g.sample_j, g.differences, g.comparable_sites) == (i, j, d, c)
+    assert fm.pairwise_differences([], 3, 10)[0].comparable_sites == 0
+    with pytest.raises(ValueError, match="sequence_length"):
+        fm.pairwise_differences(py_variants, N, 0)
+
+
+def test_pairwise_differences_reference_kat():
+    """src/tests/stats_tests.rs:368-470: three samples, three variants."""
+    variants = [build_variant(1, [[0, 0], [0, 1], [1, 1]]), build_variant(2, [[0, 0], [0, 0], [0, 0]]),
+                build_variant(3, [[0, 1], [1, 1], None])]
+    res = {(p.sample_i, p.sample_j): (p.differences, p.comparable_sites) for p in fm.pairwise_differences(variants, 3, 10)}
+    exp = {k: (d, c) for k, d, c in R.calculate_pairwise_differences([R.make_variant(v["position"], v["genotypes"]) for v in variants], 3, 10)}
+    assert res == exp
+    assert res[(0, 1)] == (4, 40) and res[(0, 2)][1] == 36  # one variant lacks sample 2 -> 4 comparisons removed
