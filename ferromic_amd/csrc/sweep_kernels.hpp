@@ -404,6 +404,70 @@ __device__ __forceinline__ void count_row_called(const MatrixView& mv, const uin
   allele_or = row16_or(allele_or);
 }
 
+// General row, single pass for alleles 0..3 by bit planes: with s0 = #(bit0 set), s1 = #(bit1 set),
+// s01 = #(both) over the called members, and every called allele < 4 (checked through allele_or),
+//   c3 = s01, c1 = s0 - s01, c2 = s1 - s01, c0 = n - c1 - c2 - c3.
+// Also returns n[p], n_all and the OR of the called allele values.  Loads are batched like the
+// biallelic core (U vectors in flight per lane).
+template <int P, bool MISSING, int U>
+__device__ __forceinline__ void count_row_planes(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+                                                 uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
+                                                 const uint8_t* __restrict__ bits_ptr, int gl, uint32_t (&n)[P],
+                                                 uint32_t& n_all, uint32_t& allele_or, uint32_t (&s0)[P],
+                                                 uint32_t (&s1)[P], uint32_t (&s01)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) { n[p] = 0; s0[p] = 0; s1[p] = 0; s01[p] = 0; }
+  n_all = 0;
+  allele_or = 0;
+  const uint32_t last = mv.nvec - 1;
+  for (uint32_t v0 = gl; v0 < nvec_pad; v0 += 16 * U) {
+    uint4 g[U];
+    uint32_t bits16[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = v0 + 16 * u;
+      const uint32_t vc = v < last ? v : last;
+      g[u] = load_stream(row_ptr + (size_t)vc * 16);
+      if (MISSING) bits16[u] = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)vc * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = v0 + 16 * u;
+      const bool inside = v <= last;
+      uint4 x = g[u];
+      uint4 cb = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+      if (MISSING) {
+        cb = called_bytes(bits16[u]);
+        n_all += inside ? __builtin_popcount(bits16[u]) : 0;
+        x.x &= cb.x * 0xFFu; x.y &= cb.y * 0xFFu; x.z &= cb.z * 0xFFu; x.w &= cb.w * 0xFFu;
+      }
+      allele_or |= inside ? or_bytes(x.x | x.y | x.z | x.w) : 0u;
+      const uint4 b0 = make_uint4(x.x & 0x01010101u, x.y & 0x01010101u, x.z & 0x01010101u, x.w & 0x01010101u);
+      const uint4 b1 = make_uint4((x.x >> 1) & 0x01010101u, (x.y >> 1) & 0x01010101u, (x.z >> 1) & 0x01010101u, (x.w >> 1) & 0x01010101u);
+      const uint4 bb = make_uint4(b0.x & b1.x, b0.y & b1.y, b0.z & b1.z, b0.w & b1.w);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
+        if (MISSING) {
+          m.x &= cb.x; m.y &= cb.y; m.z &= cb.z; m.w &= cb.w;
+          n[p] = dot4(m.x, 0x01010101u, n[p]); n[p] = dot4(m.y, 0x01010101u, n[p]);
+          n[p] = dot4(m.z, 0x01010101u, n[p]); n[p] = dot4(m.w, 0x01010101u, n[p]);
+        }
+        s0[p] = dot4(b0.x, m.x, s0[p]); s0[p] = dot4(b0.y, m.y, s0[p]); s0[p] = dot4(b0.z, m.z, s0[p]); s0[p] = dot4(b0.w, m.w, s0[p]);
+        s1[p] = dot4(b1.x, m.x, s1[p]); s1[p] = dot4(b1.y, m.y, s1[p]); s1[p] = dot4(b1.z, m.z, s1[p]); s1[p] = dot4(b1.w, m.w, s1[p]);
+        s01[p] = dot4(bb.x, m.x, s01[p]); s01[p] = dot4(bb.y, m.y, s01[p]); s01[p] = dot4(bb.z, m.z, s01[p]); s01[p] = dot4(bb.w, m.w, s01[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (MISSING) n[p] = row16_sum(n[p]);
+    s0[p] = row16_sum(s0[p]); s1[p] = row16_sum(s1[p]); s01[p] = row16_sum(s01[p]);
+  }
+  if (MISSING) n_all = row16_sum(n_all);
+  allele_or = row16_or(allele_or);
+}
+
 // General row, pass per allele value a: c[p] = called members carrying allele a.
 template <int P, bool MISSING>
 __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uint4* __restrict__ lds_mask,
@@ -692,8 +756,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
           mine.n_all = MISSING ? n_all : mv.columns;
         }
       } else {
-        uint32_t n[P], n_all, aor;
-        count_row_called<P, MISSING>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, n, n_all, aor);
+        uint32_t n[P], n_all, aor, s0[P], s1[P], s01[P];
+        count_row_planes<P, MISSING, 4>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
         if (!MISSING) {
 #pragma unroll
           for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
@@ -704,7 +768,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
           for (int p = 0; p < P; ++p) mine.n[p] = n[p];
           mine.n_all = n_all;
         }
-        // wave-uniform loop bound: OR over the four groups of this step
+        // wave-uniform bound: OR of the called allele values over the four rows of this step
         uint32_t bound = aor;
         bound |= __shfl_xor(bound, 16, 64);
         bound |= __shfl_xor(bound, 32, 64);
@@ -715,25 +779,41 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
           if (n[0] != 0) inv1 = 1.0 / (double)n[0];
           if (n[1] != 0) inv2 = 1.0 / (double)n[1];
         }
-        for (uint32_t a = 0; a <= bound; ++a) {
-          uint32_t c[P];
-          count_row_allele<P, MISSING>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
-          if (own) {
+        auto consume = [&](uint32_t a, const uint32_t (&c)[P]) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-              mine.ssq[p] += (unsigned long long)c[p] * c[p];
-              mine.distinct[p] += c[p] != 0 ? 1u : 0u;
-              if (a == 1) mine.alt[p] = c[p];
+          for (int p = 0; p < P; ++p) {
+            mine.ssq[p] += (unsigned long long)c[p] * c[p];
+            mine.distinct[p] += c[p] != 0 ? 1u : 0u;
+            if (a == 1) mine.alt[p] = c[p];
+          }
+          if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+            // dxy_from_counts 2921-2931 (ascending allele order); a zero count adds +0.0
+            if (c[0] != 0 && c[1] != 0) hud_dot += ((double)c[0] * inv1) * ((double)c[1] * inv2);
+          }
+          if constexpr ((MODE & kModeWc) != 0) {
+            // the reference iterates only alleles present among all samples; an absent allele
+            // contributes exact zeros, so iterating it is harmless
+            wc_add_allele<P>(n, c, wc);
+          }
+        };
+        if (bound <= 3) {
+          // every called allele of the four rows is < 4: the counts follow from the bit planes
+          if (own) {
+            uint32_t c[P];
+            for (uint32_t a = 0; a <= bound; ++a) {
+#pragma unroll
+              for (int p = 0; p < P; ++p) {
+                const uint32_t c3 = s01[p], c1 = s0[p] - s01[p], c2 = s1[p] - s01[p];
+                c[p] = a == 0 ? n[p] - c1 - c2 - c3 : (a == 1 ? c1 : (a == 2 ? c2 : c3));
+              }
+              consume(a, c);
             }
-            if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
-              // dxy_from_counts 2921-2931 (ascending allele order); a zero count adds +0.0
-              if (c[0] != 0 && c[1] != 0) hud_dot += ((double)c[0] * inv1) * ((double)c[1] * inv2);
-            }
-            if constexpr ((MODE & kModeWc) != 0) {
-              // the reference iterates only alleles present among all samples; an absent allele
-              // contributes exact zeros, so iterating it is harmless
-              wc_add_allele<P>(n, c, wc);
-            }
+          }
+        } else {
+          for (uint32_t a = 0; a <= bound; ++a) {
+            uint32_t c[P];
+            count_row_allele<P, MISSING>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
+            if (own) consume(a, c);
           }
         }
       }
