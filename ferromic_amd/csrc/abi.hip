@@ -418,6 +418,7 @@ struct Workspace {
   double* harmonic = nullptr;
   size_t harmonic_len = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::mutex in_use;  // one sweep at a time per device: concurrent callers share the partials and the pinned staging
 };
 static Workspace g_ws[64];
 static std::mutex g_ws_mutex;
@@ -530,6 +531,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   FMH_TRY(use_device(m->device));
   Workspace* w = nullptr;
   FMH_TRY(workspace(m->device, &w));
+  std::lock_guard<std::mutex> busy(w->in_use);
   hipStream_t st = (hipStream_t)stream;
   a.mv.data = m->data;
   a.mv.bits = m->bits;
@@ -586,6 +588,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   if (g_timing) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
     g_timing_ms += ms;
     g_timing_launches += 1;
   }

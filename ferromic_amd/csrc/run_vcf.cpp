@@ -7,6 +7,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cinttypes>
 #include <cmath>
 #include <cstdint>
@@ -23,6 +24,8 @@
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ferromic_hip.h"
@@ -1118,6 +1121,7 @@ struct Args {
   unsigned min_gq = 30;
   bool enable_fst = false, enable_pca = false;
   int device = 0;
+  vector<int> devices;  // --devices: one worker thread per entry, config regions dealt out dynamically
 };
 
 std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry, const VcfData& vcf, const RegionMap& mask,
@@ -1335,18 +1339,51 @@ int run(const Args& args) {
       VcfData vcf;
       try { vcf = process_vcf(vcf_path, chr, merge_intervals(hulls), args.min_gq, &final_mask, allow_regions ? &*allow_regions : nullptr, exclusion); }
       catch (const Error& e) { logmsg("ERROR", "Error processing VCF for " + chr + ": " + e.what()); continue; }
-      for (auto* e : kv.second) {
-        std::optional<RegionOutput> res;
-        try { res = process_single_config_entry(*e, vcf, final_mask, allow_regions ? &*allow_regions : nullptr, chr_length, chr, args,
-                                                  csv_for_hudson ? &*csv_for_hudson : nullptr); }
-        catch (const Error& err) { logmsg("ERROR", string("DROPPED: Error processing region: ") + err.what()); continue; }
-        if (!res) continue;
-        csv << join(res->csv_row, ',', true) << "\n";
-        const string d = diversity_falsta(*res), f = fst_falsta(*res);
-        if (!d.empty()) gz_append(div_path, d);
-        if (!f.empty()) gz_append(fst_path, f);
-        for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
-        for (auto& r : res->wc_rows) wc_rows.push_back(r);
+      // Regions are independent units: one worker per GPU pulls the next config entry; rows and
+      // tracks are emitted in config order whatever the completion order, so the files match a 1-GPU run.
+      const vector<const ConfigEntry*>& todo = kv.second;
+      vector<std::optional<RegionOutput>> done(todo.size());
+      vector<char> finished(todo.size(), 0);
+      std::atomic<size_t> next{0};
+      std::mutex emit_mutex;
+      size_t emitted = 0;
+      auto emit_ready = [&]() {  // caller holds emit_mutex
+        while (emitted < todo.size() && finished[emitted]) {
+          std::optional<RegionOutput>& res = done[emitted];
+          if (res) {
+            csv << join(res->csv_row, ',', true) << "\n";
+            const string d = diversity_falsta(*res), f = fst_falsta(*res);
+            if (!d.empty()) gz_append(div_path, d);
+            if (!f.empty()) gz_append(fst_path, f);
+            for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
+            for (auto& r : res->wc_rows) wc_rows.push_back(r);
+            res.reset();
+          }
+          ++emitted;
+        }
+      };
+      auto worker = [&](int device) {
+        Args mine = args;
+        mine.device = device;
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= todo.size()) break;
+          std::optional<RegionOutput> res;
+          try { res = process_single_config_entry(*todo[i], vcf, final_mask, allow_regions ? &*allow_regions : nullptr, chr_length, chr, mine,
+                                                    csv_for_hudson ? &*csv_for_hudson : nullptr); }
+          catch (const std::exception& err) { logmsg("ERROR", string("DROPPED: Error processing region: ") + err.what()); }
+          std::lock_guard<std::mutex> lock(emit_mutex);
+          done[i] = std::move(res);
+          finished[i] = 1;
+          emit_ready();
+        }
+      };
+      if (args.devices.size() <= 1) {
+        worker(args.devices.empty() ? args.device : args.devices[0]);
+      } else {
+        vector<std::thread> pool;
+        for (int d : args.devices) pool.emplace_back(worker, d);
+        for (auto& t : pool) t.join();
       }
     } catch (const Error& e) {
       fprintf(stderr, "Error processing chromosome %s: %s\n", chr.c_str(), e.what());
@@ -1401,9 +1438,15 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--fst") a.enable_fst = true;
     else if (k == "--fst_populations") a.fst_populations = value();
     else if (k == "--device") a.device = atoi(value().c_str());
+    else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)
+      const string v2 = value();
+      if (v2.find(',') == string::npos) { for (int d = 0; d < atoi(v2.c_str()); ++d) a.devices.push_back(d); }
+      else for (auto& t : split(v2, ',')) if (!t.empty()) a.devices.push_back(atoi(t.c_str()));
+      if (a.devices.empty()) throw Error("invalid --devices");
+    }
     else if (k == "--help" || k == "-h") {
       printf("run_vcf --vcf_folder DIR --reference FA --gtf GTF [--config_file TSV | --chr C [--region S-E]] [--output_file CSV]\n"
-             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--device N]\n");
+             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--fst_populations CSV] [--device N | --devices N|a,b,c]\n");
       exit(0);
     } else throw Error("unexpected argument '" + k + "'");
   }

@@ -8,6 +8,7 @@ import os
 import random
 import subprocess
 
+import numpy as np
 import pytest
 
 from oracle import run_vcf_ref as V
@@ -33,6 +34,8 @@ def run_binary(out_csv, **kw):
         cmd += ["--exclude", ",".join(kw["exclude"])]
     if kw.get("enable_fst"):
         cmd += ["--fst"]
+    if kw.get("devices"):
+        cmd += ["--devices", kw["devices"]]
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_PROGRESS="0"), timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
     out = {}
@@ -197,6 +200,58 @@ def test_synthetic_cohort(tmp_path, variant):
         assert any("NA" not in r.split(",")[25:30] for r in rows[1:])  # some region has a calculable W&C FST
 
 
+def make_big_cohort(tmp, seed, n_sites, n_samples, length):
+    rng = np.random.default_rng(seed)
+    names = [f"S{i:04d}" for i in range(n_samples)]
+    seq = "".join(rng.choice(list("ACGT"), size=length))
+    hdr = ">chr1\n"
+    body = "\n".join(seq[i:i + 60] for i in range(0, length, 60)) + "\n"
+    (tmp / "ref.fa").write_text(hdr + body)
+    (tmp / "ref.fa.fai").write_text(f"chr1\t{length}\t{len(hdr)}\t60\t61\n")
+    (tmp / "ann.gtf").write_text('chr1\t.\tCDS\t1\t100\t.\t+\t0\tgene_id "g"; transcript_id "t";\n')
+    os.makedirs(tmp / "vcfs", exist_ok=True)
+    pos = np.sort(rng.choice(np.arange(1, length + 1), size=n_sites, replace=False))
+    f = rng.beta(0.8, 0.8, size=(n_sites, 1))
+    shift = np.where(np.arange(n_samples) % 2 == 0, 0.15, -0.15)[None, :, None]
+    g = (rng.random((n_sites, n_samples, 2)) < np.clip(f[:, :, None] + shift, 0.01, 0.99)).astype(np.uint8)
+    multi = rng.random(n_sites) < 0.05
+    g[multi] *= rng.integers(1, 3, size=(int(multi.sum()), n_samples, 2), dtype=np.uint8)
+    miss = rng.random((n_sites, n_samples)) < 0.01
+    lowgq = rng.random((n_sites, n_samples)) < 0.0005
+    bases = np.array(list("ACGT"))
+    ref = bases[rng.integers(0, 4, n_sites)]
+    alt = bases[rng.integers(0, 4, n_sites)]
+    lines = ["##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"]
+    gt_txt = np.char.add(np.char.add(g[:, :, 0].astype(str), "|"), g[:, :, 1].astype(str))
+    gt_txt = np.where(lowgq, np.char.add(gt_txt, ":12"), np.char.add(gt_txt, ":60"))
+    gt_txt = np.where(miss, "./.:.", gt_txt)
+    for s in range(n_sites):
+        a = alt[s] + (",T" if multi[s] else "")
+        lines.append(f"chr1\t{pos[s]}\t.\t{ref[s]}\t{a}\t.\tPASS\t.\tGT:GQ\t" + "\t".join(gt_txt[s]) + "\n")
+    (tmp / "vcfs" / "chr1.vcf").write_text("".join(lines))
+    cfg = "seqnames\tstart\tend\tPOS\torig_ID\tverdict\tcateg\t" + "\t".join(names) + "\n"
+    r = random.Random(seed)
+    for (s, e) in ((1, length), (length // 4, length // 2), (length // 2, length - 10)):
+        cells = [r.choice(["0|0", "0|1", "1|0", "1|1", "0|1_lowconf"]) for _ in range(n_samples)]
+        cfg += f"chr1\t{s}\t{e}\t{s}\tid\tpass\tinv\t" + "\t".join(cells) + "\n"
+    (tmp / "config.tsv").write_text(cfg)
+    return dict(vcf_folder=str(tmp / "vcfs"), reference=str(tmp / "ref.fa"), gtf=str(tmp / "ann.gtf"),
+                config_file=str(tmp / "config.tsv"), enable_fst=True)
+
+
+def test_large_single_chromosome(tmp_path):
+    """SURVEY 8(d) honesty note: a real synthetic VCF at reduced scale through text -> matrix -> all outputs.
+    30 000 sites x 80 haplotypes, 3 overlapping regions (the first spans the chromosome), 5 % multi-allelic
+    sites, 1 % missing calls, a few low-GQ cells, W&C + Hudson tracks; every file compared with the oracle."""
+    n_sites = 30_000
+    kw = make_big_cohort(tmp_path, 3, n_sites, 40, n_sites * 6)
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), **kw)
+    compare(got, exp)
+    row = dict(zip(V.CSV_HEADER, got["out.csv"].splitlines()[1].split(",")))
+    assert int(row["0_segregating_sites"]) > 20_000 and row["haplotype_overall_fst_wc"] != "NA"
+
+
 def test_csv_defined_populations(tmp_path):
     """--fst_populations: W&C + Hudson between CSV-defined populations (stats.rs:816-1078, process.rs:3301-3392)
     and the fifth output file, wc_fst_results.tsv.gz."""
@@ -214,6 +269,19 @@ def test_csv_defined_populations(tmp_path):
     assert sum(1 for r in wc if "\tpairwise\t" in r) == 3 * 5 and sum(1 for r in wc if "\toverall\tALL\tALL\t" in r) == 5
     hud = got["hudson_fst_results.tsv.gz"]
     assert "NamedPopulation\tAFR\tNamedPopulation\tEAS" in hud and "HaplotypeGroup\t0\tHaplotypeGroup\t1" in hud
+
+
+def test_region_workers_match_single_worker(tmp_path):
+    """--devices: config regions dealt out to one worker thread per GPU ("whole config regions").
+    A one-GPU box can only alias device 0, which still exercises the dynamic work queue, the ordered emit
+    and the per-device sweep lock: the files must be identical to the single-worker run and to the oracle."""
+    kw, names = make_cohort(tmp_path, seed=31, n_samples=16)
+    kw.update(enable_fst=True, mask_file=str(tmp_path / "mask.bed"))
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    one = run_binary(str(tmp_path / "one" / "out.csv"), **kw)
+    many = run_binary(str(tmp_path / "many" / "out.csv"), devices="0,0,0", **kw)
+    assert many == one
+    compare(many, exp)
 
 
 def test_single_chromosome_mode(tmp_path):
