@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <cstdint>
@@ -23,6 +24,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <sys/stat.h>
 #include <thread>
 #include <mutex>
@@ -45,8 +47,41 @@ void logmsg(const char* level, const string& m) {
   if (!quiet || string(level) != "INFO") fprintf(stderr, "[%s] %s\n", level, m.c_str());
 }
 
+// FERROMIC_TIMING=1: stage wall times on stderr as "[TIMING] stage seconds"
+struct StageTimer {
+  const char* stage;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit StageTimer(const char* s) : stage(s) {}
+  ~StageTimer() {
+    static const bool on = getenv("FERROMIC_TIMING") && string(getenv("FERROMIC_TIMING")) == "1";
+    if (on) fprintf(stderr, "[TIMING] %s %.3f\n", stage, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+
 void fmh_check(int status, const char* what) {
   if (status != FMH_OK) throw Error(string(what) + ": " + fmh_last_error());
+}
+
+// ---- host thread pool in its simplest form: T short-lived threads per parallel stage -----------------------
+unsigned worker_threads() {
+  static const unsigned n = [] {
+    if (const char* e = getenv("FERROMIC_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 256); }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hw ? hw : 1u, 64u));
+  }();
+  return n;
+}
+template <class F> void parallel_for(unsigned tasks, F&& fn) {
+  if (tasks <= 1) { if (tasks) fn(0u); return; }
+  vector<std::thread> pool;
+  std::exception_ptr failure;
+  std::mutex m;
+  for (unsigned t = 0; t < tasks; ++t)
+    pool.emplace_back([&, t] {
+      try { fn(t); } catch (...) { std::lock_guard<std::mutex> lock(m); if (!failure) failure = std::current_exception(); }
+    });
+  for (auto& th : pool) th.join();
+  if (failure) std::rethrow_exception(failure);
 }
 
 // ---- small string helpers ------------------------------------------------------------------------
@@ -149,6 +184,7 @@ struct Variant {
   int64_t position = 0;
   vector<uint8_t> data;  // CompressedGenotypes: 0xFF sentinel
   size_t stride = 0, num_samples = 0;
+  size_t max_len = 0;  // longest genotype in the row before the sentinel (0 = every sample None)
   // genotype length of sample i (0 = None)
   size_t glen(size_t i) const {
     if (i >= num_samples || stride == 0) return 0;
@@ -301,6 +337,15 @@ struct LineReader {
     gzbuffer(f, 1 << 20);
   }
   ~LineReader() { if (f) gzclose(f); }
+  size_t read(char* dst, size_t n) {  // raw bytes following whatever next() consumed
+    size_t total = 0;
+    while (total < n) {
+      const int got = gzread(f, dst + total, (unsigned)std::min<size_t>(n - total, 1u << 30));
+      if (got <= 0) break;
+      total += (size_t)got;
+    }
+    return total;
+  }
   bool next(string& out) {
     out.clear();
     char buf[1 << 16];
@@ -383,19 +428,66 @@ string normalize_chr_prefix(const string& c) {
   return c;
 }
 
-// process_variant, process.rs:4471-4768.  Returns false when the line yields no variant.
-bool process_variant(const string& line_in, const string& chr, const vector<Interval>& regions, const vector<size_t>& kept,
-                     unsigned min_gq, const RegionMap* allow, const RegionMap* mask, Variant* out, uint8_t* out_flags) {
-  string line = line_in;
-  vector<string> fields = split(line, '\t');
+// ---- string_view twins of the helpers above for the per-cell hot loop (no allocation per genotype cell) ------
+typedef std::string_view sv;
+sv trim_sv(sv s) {
+  size_t b = 0, e = s.size();
+  while (b < e && isspace((unsigned char)s[b])) ++b;
+  while (e > b && isspace((unsigned char)s[e - 1])) --e;
+  return s.substr(b, e - b);
+}
+bool parse_unsigned_sv(sv s, unsigned max, unsigned* out) {  // Rust str::parse::<u8/u16>: optional '+', ASCII digits only
+  size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
+  if (i >= s.size()) return false;
+  unsigned long v = 0;
+  for (; i < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    v = v * 10 + (unsigned long)(s[i] - '0');
+    if (v > max) return false;
+  }
+  *out = (unsigned)v;
+  return true;
+}
+// the k-th ':'-separated part of a cell; false when the cell has fewer parts
+bool colon_part(sv cell, size_t k, sv* out) {
+  size_t b = 0;
+  for (size_t i = 0;; ++i) {
+    const size_t e = cell.find(':', b);
+    if (i == k) { *out = cell.substr(b, e == sv::npos ? sv::npos : e - b); return true; }
+    if (e == sv::npos) return false;
+    b = e + 1;
+  }
+}
+
+// per-thread scratch reused across lines
+struct VariantScratch {
+  vector<sv> fields;
+  vector<uint32_t> off;   // start of sample s in vals
+  vector<uint16_t> len;   // parsed alleles of sample s
+  vector<uint8_t> none;   // 1 = genotype is None
+  vector<uint8_t> vals;
+};
+
+// process_variant, process.rs:4471-4768.  Returns false when the line yields no variant.  `line` keeps its
+// trailing newline exactly as the reference's read_line buffer does.
+bool process_variant(sv line, const string& chr, const vector<Interval>& regions, const vector<size_t>& kept,
+                     unsigned min_gq, const RegionMap* allow, const RegionMap* mask, VariantScratch& scr, Variant* out, uint8_t* out_flags) {
+  vector<sv>& fields = scr.fields;
+  fields.clear();
+  for (size_t b = 0;;) {
+    const size_t e = line.find('\t', b);
+    if (e == sv::npos) { fields.push_back(line.substr(b)); break; }
+    fields.push_back(line.substr(b, e - b));
+    b = e + 1;
+  }
   if (fields.size() < 9) throw Error("Invalid VCF line format");
   size_t max_idx = 0;
   for (size_t k : kept) max_idx = std::max(max_idx, k);
   if (!kept.empty() && fields.size() <= max_idx) throw Error("Invalid VCF line format: missing genotype column");
-  const string vcf_chr = normalize_chr_prefix(trim(fields[0]));
+  const string vcf_chr = normalize_chr_prefix(string(trim_sv(fields[0])));
   if (vcf_chr != normalize_chr_prefix(trim(chr))) return false;
   int64_t pos1;
-  if (!parse_i64(fields[1], &pos1)) throw Error("Invalid position");
+  if (!parse_i64(string(fields[1]), &pos1)) throw Error("Invalid position");
   if (pos1 < 1) throw Error("Invalid 1-based pos");
   const int64_t pos0 = pos1 - 1;
   bool in_regions = false;
@@ -414,54 +506,77 @@ bool process_variant(const string& line_in, const string& chr, const vector<Inte
         if (std::max<uint64_t>((uint64_t)pos0, (uint64_t)m.first) < std::min<uint64_t>((uint64_t)pos0 + 1, (uint64_t)m.second)) { flags |= FLAG_MASK; break; }
   }
   bool indel = fields[3].size() != 1;
-  if (!indel) for (const string& a : split(fields[4], ',')) if (a.size() != 1) indel = true;
-  vector<string> fmt = split(fields[8], ':');
-  size_t gq_index = fmt.size();
-  for (size_t i = 0; i < fmt.size(); ++i) if (fmt[i] == "GQ") { gq_index = i; break; }
-  if (gq_index == fmt.size()) throw Error("GQ field not found in FORMAT");
-  // the last kept column may carry the trailing newline
-  vector<std::optional<vector<uint8_t>>> raw;
-  raw.reserve(kept.size());
-  for (size_t idx : kept) {
-    const string& gt = fields[idx];
-    const string alleles = gt.substr(0, gt.find(':'));
-    if (alleles == "." || alleles == "./." || alleles == ".|.") { raw.push_back(std::nullopt); continue; }
-    vector<uint8_t> vals;
-    bool ok = true;
+  if (!indel) {
+    const sv alts = fields[4];
+    for (size_t b = 0;;) {
+      const size_t e = alts.find(',', b);
+      if ((e == sv::npos ? alts.size() : e) - b != 1) indel = true;
+      if (e == sv::npos) break;
+      b = e + 1;
+    }
+  }
+  size_t gq_index = SIZE_MAX;
+  {
+    const sv fmt = fields[8];
     size_t b = 0;
-    for (size_t i = 0; i <= alleles.size(); ++i) {
-      if (i == alleles.size() || alleles[i] == '|' || alleles[i] == '/') {
+    for (size_t i = 0;; ++i) {
+      const size_t e = fmt.find(':', b);
+      if (fmt.substr(b, e == sv::npos ? sv::npos : e - b) == "GQ") { gq_index = i; break; }
+      if (e == sv::npos) break;
+      b = e + 1;
+    }
+  }
+  if (gq_index == SIZE_MAX) throw Error("GQ field not found in FORMAT");
+  const size_t n = kept.size();
+  scr.off.resize(n); scr.len.resize(n); scr.none.resize(n);
+  scr.vals.clear();
+  bool low_gq = false, missing = false;
+  size_t max_len = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const sv cell = fields[kept[i]];
+    const sv alleles = cell.substr(0, cell.find(':'));
+    scr.off[i] = (uint32_t)scr.vals.size();
+    scr.len[i] = 0;
+    scr.none[i] = 1;
+    if (alleles == "." || alleles == "./." || alleles == ".|.") continue;
+    bool ok = true;
+    size_t b = 0, cnt = 0;
+    for (size_t j = 0; j <= alleles.size(); ++j) {
+      if (j == alleles.size() || alleles[j] == '|' || alleles[j] == '/') {
         unsigned v;
-        if (!parse_unsigned(alleles.substr(b, i - b), 255, &v)) { ok = false; break; }
-        vals.push_back((uint8_t)v);
-        b = i + 1;
+        if (!parse_unsigned_sv(alleles.substr(b, j - b), 255, &v)) { ok = false; break; }
+        scr.vals.push_back((uint8_t)v);
+        ++cnt;
+        b = j + 1;
       }
     }
-    if (ok) raw.push_back(std::move(vals)); else raw.push_back(std::nullopt);
+    if (!ok) { scr.vals.resize(scr.off[i]); continue; }
+    scr.none[i] = 0;
+    scr.len[i] = (uint16_t)std::min<size_t>(cnt, 65535);
+    max_len = std::max(max_len, cnt);
   }
-  bool low_gq = false, missing = false;
-  for (size_t i = 0; i < kept.size(); ++i) {
-    if (!raw[i]) { missing = true; continue; }
-    vector<string> parts = split(fields[kept[i]], ':');
-    if (gq_index >= parts.size()) throw Error("GQ value missing in sample genotype field");
-    const string gq_str = trim(parts[gq_index]);
+  for (size_t i = 0; i < n; ++i) {
+    if (scr.none[i]) { missing = true; continue; }
+    sv part;
+    if (!colon_part(fields[kept[i]], gq_index, &part)) throw Error("GQ value missing in sample genotype field");
+    const sv gq_str = trim_sv(part);
     unsigned gq = 0;
-    if (!(gq_str == "." || gq_str.empty())) { if (!parse_unsigned(gq_str, 65535, &gq)) gq = 0; }
+    if (!(gq_str == "." || gq_str.empty())) { if (!parse_unsigned_sv(gq_str, 65535, &gq)) gq = 0; }
     if (gq < min_gq) low_gq = true;
   }
   if (low_gq) flags |= FLAG_LOW_GQ;
   if (missing) flags |= FLAG_MISSING;
   if (indel) return false;
   // CompressedGenotypes::new, process.rs:440-477
-  size_t max_ploidy = 0;
-  for (auto& g : raw) if (g) max_ploidy = std::max(max_ploidy, g->size());
-  if (!raw.empty()) max_ploidy = std::max<size_t>(max_ploidy, 1);
+  size_t max_ploidy = max_len;
+  if (n) max_ploidy = std::max<size_t>(max_ploidy, 1);
   out->position = pos0;
-  out->num_samples = raw.size();
+  out->num_samples = n;
   out->stride = max_ploidy;
-  out->data.assign(raw.size() * max_ploidy, 0xFF);
-  for (size_t s = 0; s < raw.size(); ++s)
-    if (raw[s]) for (size_t k = 0; k < raw[s]->size() && k < max_ploidy; ++k) out->data[s * max_ploidy + k] = (*raw[s])[k];
+  out->max_len = max_len;
+  out->data.assign(n * max_ploidy, 0xFF);
+  for (size_t s2 = 0; s2 < n; ++s2)
+    if (!scr.none[s2]) memcpy(&out->data[s2 * max_ploidy], &scr.vals[scr.off[s2]], std::min<size_t>(scr.len[s2], max_ploidy));
   *out_flags = flags;
   return true;
 }
@@ -508,14 +623,60 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
     }
   }
   if (!header || d.sample_names.empty()) throw Error("Parse(\"No samples remain after applying exclusions\")");
+  // Body: blocks of whole lines are cut from the (gunzipped) stream and parsed by a pool of threads, each on a
+  // contiguous run of lines; results are concatenated in file order, so the outcome equals a serial read
+  // (the reference runs the same stage as a reader thread + rayon consumers, process.rs:4274-4392).
   vector<std::pair<Variant, uint8_t>> items;
-  while (r.next(line)) {
-    Variant v;
-    uint8_t fl;
-    try {
-      if (process_variant(line, chr, regions, kept, min_gq, allow, mask, &v, &fl)) items.push_back({std::move(v), fl});
-    } catch (const Error& e) {
-      fprintf(stderr, "%s\n", e.what());  // the collector prints and carries on (process.rs:4358-4360)
+  const unsigned T = worker_threads();
+  string block, carry;
+  const size_t kBlock = (size_t)64 << 20;
+  bool eof = false;
+  while (!eof) {
+    block = carry;
+    carry.clear();
+    const size_t had = block.size();
+    block.resize(had + kBlock);
+    const size_t got = r.read(&block[had], kBlock);
+    block.resize(had + got);
+    if (got < kBlock) eof = true;
+    size_t usable = block.size();
+    if (!eof) {
+      const size_t nl = block.rfind('\n');
+      if (nl == string::npos) { carry.swap(block); continue; }
+      usable = nl + 1;
+      carry.assign(block, usable, string::npos);
+    }
+    if (usable == 0) continue;
+    // line-aligned cut points
+    vector<size_t> cut(T + 1, usable);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) {
+      size_t p = std::max(cut[t - 1], usable * t / T);
+      if (p < usable) { const void* q = memchr(block.data() + p, '\n', usable - p); p = q ? (size_t)((const char*)q - block.data()) + 1 : usable; }
+      cut[t] = p;
+    }
+    vector<vector<std::pair<Variant, uint8_t>>> parts(T);
+    vector<string> complaints(T);
+    parallel_for(T, [&](unsigned t) {
+      VariantScratch scr;
+      size_t b = cut[t];
+      const size_t end = cut[t + 1];
+      while (b < end) {
+        const void* q = memchr(block.data() + b, '\n', end - b);
+        const size_t e = q ? (size_t)((const char*)q - block.data()) + 1 : end;
+        Variant v;
+        uint8_t fl;
+        try {
+          if (process_variant(sv(block.data() + b, e - b), chr, regions, kept, min_gq, allow, mask, scr, &v, &fl)) parts[t].push_back({std::move(v), fl});
+        } catch (const Error& err) {
+          complaints[t] += string(err.what()) + "\n";  // the collector prints and carries on (process.rs:4358-4360)
+        }
+        b = e;
+      }
+    });
+    for (unsigned t = 0; t < T; ++t) {
+      if (!complaints[t].empty()) fputs(complaints[t].c_str(), stderr);
+      for (auto& it : parts[t]) items.push_back(std::move(it));
     }
   }
   std::stable_sort(items.begin(), items.end(), [](const auto& a, const auto& b) {
@@ -592,26 +753,45 @@ RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, in
   RegionMatrix out;
   if (vs.empty()) return out;
   size_t max_ploidy = 0;
-  for (auto* v : vs) for (size_t s = 0; s < v->num_samples; ++s) max_ploidy = std::max(max_ploidy, v->glen(s));
+  for (auto* v : vs) max_ploidy = std::max(max_ploidy, v->max_len);
   out.has_dense = max_ploidy > 0;
   const size_t P = std::max<size_t>(max_ploidy, 1);
   out.ploidy = P;
   const size_t stride = n_samples * P, total = vs.size() * stride;
   vector<uint8_t> data(total, 0);
   vector<uint64_t> missing((total + 63) / 64, 0);
-  bool any_missing = false;
-  uint8_t max_allele = 0;
-  for (size_t i = 0; i < vs.size(); ++i) {
-    const Variant& v = *vs[i];
-    for (size_t s = 0; s < n_samples; ++s) {
-      const size_t len = v.glen(s);
-      for (size_t k = 0; k < P; ++k) {
-        const size_t idx = i * stride + s * P + k;
-        if (k < len) { data[idx] = v.data[s * v.stride + k]; max_allele = std::max(max_allele, data[idx]); }
-        else { missing[idx >> 6] |= 1ull << (idx & 63); any_missing = true; }
+  // rows are dealt out in runs of 64 so that no two threads share a 64-bit word of the missing mask
+  const size_t runs = (vs.size() + 63) / 64;
+  const unsigned T = (unsigned)std::min<size_t>(worker_threads(), runs);
+  vector<uint8_t> t_max(T, 0), t_missing(T, 0);
+  parallel_for(T, [&](unsigned t) {
+    const size_t r0 = runs * t / T * 64, r1 = std::min(vs.size(), runs * (t + 1) / T * 64);
+    uint8_t mx = 0;
+    bool any = false;
+    for (size_t i = r0; i < r1; ++i) {
+      const Variant& v = *vs[i];
+      uint8_t* row = &data[i * stride];
+      const size_t vs_stride = v.stride, ns = std::min(n_samples, v.num_samples);
+      for (size_t s = 0; s < n_samples; ++s) {
+        size_t k = 0;
+        if (s < ns) {
+          const uint8_t* g = &v.data[s * vs_stride];
+          const size_t lim = std::min(P, vs_stride);
+          for (; k < lim && g[k] != 0xFF; ++k) { row[s * P + k] = g[k]; mx = std::max(mx, g[k]); }
+        }
+        for (; k < P; ++k) {
+          const size_t idx = i * stride + s * P + k;
+          missing[idx >> 6] |= 1ull << (idx & 63);
+          any = true;
+        }
       }
     }
-  }
+    t_max[t] = mx;
+    t_missing[t] = any;
+  });
+  bool any_missing = false;
+  uint8_t max_allele = 0;
+  for (unsigned t = 0; t < T; ++t) { any_missing |= t_missing[t] != 0; max_allele = std::max(max_allele, t_max[t]); }
   out.dm.reset(new DeviceMatrix());
   out.dm->variants = vs.size(); out.dm->samples = n_samples; out.dm->ploidy = P;
   fmh_check(fmh_matrix_create(data.data(), any_missing ? missing.data() : nullptr, vs.size(), n_samples, P, max_allele, device, &out.dm->h), "matrix upload");
@@ -1141,7 +1321,10 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
     if (vcf.flags[i] == FLAG_PASS) fil.push_back(&v);
   }
   const size_t N = vcf.sample_names.size();
+  std::optional<StageTimer> tm;
+  tm.emplace("  region:pack_and_upload_matrices");
   RegionMatrix m_unf = build_matrix(unf, N, args.device), m_fil = build_matrix(fil, N, args.device);
+  tm.emplace("  region:gpu_sweeps_and_host_statistics");
 
   WcRegion wc;
   vector<vector<string>> wc_rows;
@@ -1324,6 +1507,8 @@ int run(const Args& args) {
   for (auto& kv : by_chr) {
     const string& chr = kv.first;
     try {
+      std::optional<StageTimer> tm;
+      tm.emplace("reference_fasta");
       const string ref_seq = read_reference_sequence(args.reference, chr);
       const int64_t chr_length = (int64_t)ref_seq.size();
       RegionMap final_mask = mask_regions ? *mask_regions : RegionMap();
@@ -1337,8 +1522,10 @@ int run(const Args& args) {
       for (auto* e : kv.second)
         hulls.push_back({std::max<int64_t>(e->interval.first - 3000000, 0), std::min<int64_t>(wrap_add(e->interval.second, 3000000), chr_length)});
       VcfData vcf;
+      tm.emplace("vcf_ingest");
       try { vcf = process_vcf(vcf_path, chr, merge_intervals(hulls), args.min_gq, &final_mask, allow_regions ? &*allow_regions : nullptr, exclusion); }
       catch (const Error& e) { logmsg("ERROR", "Error processing VCF for " + chr + ": " + e.what()); continue; }
+      tm.emplace("regions_statistics_and_writers");
       // Regions are independent units: one worker per GPU pulls the next config entry; rows and
       // tracks are emitted in config order whatever the completion order, so the files match a 1-GPU run.
       const vector<const ConfigEntry*>& todo = kv.second;
