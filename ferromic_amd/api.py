@@ -170,12 +170,30 @@ class _Store:
     called iff the sample's genotype is Some and has more than k alleles (CompressedGenotypes::get,
     process.rs:479-496: a leading 0xFF byte means None, a later 0xFF truncates)."""
 
-    def __init__(self, positions: np.ndarray, data: np.ndarray, called: np.ndarray, num_samples: np.ndarray):
+    def __init__(self, positions: np.ndarray, data: Optional[np.ndarray], called: Optional[np.ndarray],
+                 num_samples: np.ndarray, shape: Optional[Tuple[int, int, int]] = None, lazy=None):
         self.positions = positions            # int64 [S]
-        self.data = data                      # u8 [S, N, P]
-        self.called = called                  # bool [S, N, P]
+        self._data = data                     # u8 [S, N, P]
+        self._called = called                 # bool [S, N, P]
+        self._lazy = lazy                     # () -> (data, called): from_numpy defers its full-array passes
+        self.shape = tuple(data.shape) if data is not None else shape
         self.num_samples = num_samples        # int64 [S]: genotypes.len() of every variant
         self._device: Dict[int, dev.DeviceMatrix] = {}
+
+    def _materialise(self):
+        if self._data is None:
+            self._data, self._called = self._lazy()
+            self._lazy = None
+
+    @property
+    def data(self) -> np.ndarray:
+        self._materialise()
+        return self._data
+
+    @property
+    def called(self) -> np.ndarray:
+        self._materialise()
+        return self._called
 
     @property
     def count(self) -> int:
@@ -216,16 +234,21 @@ class _Store:
         """The sparse half of convert_numeric_array (lib.rs:1165-1206): a sample with ANY missing
         allele is None as a whole."""
         S, N, P = g.shape
-        sample_ok = np.ones((S, N), dtype=bool) if neg is None else ~neg.any(axis=2)
-        # 0xFF sentinel semantics of CompressedGenotypes (allele 255 is indistinguishable from missing)
-        not_ff = g != 0xFF
-        prefix_ok = np.logical_and.accumulate(not_ff, axis=2)
-        called = prefix_ok & sample_ok[:, :, None]
-        data = np.where(called, g, 0).astype(np.uint8)
-        if N == 0:
-            data = np.zeros((S, 1, max(P, 1)), dtype=np.uint8)
-            called = np.zeros((S, 1, max(P, 1)), dtype=bool)
-        return cls(np.asarray(positions, dtype=np.int64), data, called, np.full(S, N, dtype=np.int64))
+
+        def build():
+            if N == 0:
+                return np.zeros((S, 1, max(P, 1)), dtype=np.uint8), np.zeros((S, 1, max(P, 1)), dtype=bool)
+            sample_ok = np.ones((S, N), dtype=bool) if neg is None else ~neg.any(axis=2)
+            # 0xFF sentinel semantics of CompressedGenotypes (allele 255 is indistinguishable from missing)
+            not_ff = g != 0xFF
+            prefix_ok = np.logical_and.accumulate(not_ff, axis=2)
+            called = prefix_ok & sample_ok[:, :, None]
+            return np.where(called, g, 0).astype(np.uint8), called
+
+        # the reference builds this sparse copy eagerly (lib.rs:1165-1206); the statistics only touch it on the
+        # paths that leave the dense matrix (ploidy != 2, incompatible variant sets), so it is built on first use
+        shape = (S, 1, max(P, 1)) if N == 0 else (S, N, P)
+        return cls(np.asarray(positions, dtype=np.int64), None, None, np.full(S, N, dtype=np.int64), shape=shape, lazy=build)
 
     def subset(self, idx: np.ndarray) -> "_Store":
         return _Store(self.positions[idx], self.data[idx], self.called[idx], self.num_samples[idx])
@@ -246,7 +269,7 @@ class _Store:
     def mask_for(self, haplotypes: Sequence[Tuple[int, int]], sample_count: Optional[int]) -> np.ndarray:
         """HapMembership::build (stats.rs:1212-1238) as a column mask; `sample_count` is the
         function-specific bound the reference passes (None = no bound beyond the data)."""
-        _, N, P = self.data.shape
+        _, N, P = self.shape
         mask = np.zeros(N * P, dtype=np.uint8)
         limit = N if sample_count is None else min(sample_count, N)
         for sample_idx, side in haplotypes:
@@ -925,7 +948,7 @@ def segregating_sites(variants) -> int:
     store = _Store.from_python(variants)
     if store.count == 0:
         return 0
-    mask = np.ones((1, store.data.shape[1] * store.data.shape[2]), dtype=np.uint8)
+    mask = np.ones((1, store.shape[1] * store.shape[2]), dtype=np.uint8)
     return int(_sparse_pop_sweep(store, mask)[0]["segregating_sites"])
 
 
@@ -968,7 +991,7 @@ def pairwise_differences(variants, sample_count, sequence_length) -> List[Pairwi
     store = _Store.from_python(variants)
     n = int(sample_count)
     S = store.count
-    N = store.data.shape[1] if S else 0
+    N = store.shape[1] if S else 0
     # haplotype_counts: length of the first Some genotype of each sample (stats.rs:4124-4137)
     hap_counts = [0] * n
     if S:
@@ -1128,7 +1151,7 @@ def wc_fst(variants, sample_names, sample_to_group, region) -> WcFstResult:
     if rows.size == 0:
         return WcFstResult(_insufficient(0), {}, {}, [], "haplotype_groups")  # stats.rs:2152-2159
     sub = store.subset(rows)
-    _, N, P = sub.data.shape
+    _, N, P = sub.shape
     if G > dev._abi.MAX_GROUPS:
         raise ValueError(f"wc_fst supports at most {dev._abi.MAX_GROUPS} haplotype groups on the device")
     masks = np.zeros((max(G, 1), N * P), dtype=np.uint8)

@@ -16,7 +16,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <dirent.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <memory>
 #include <optional>
@@ -332,12 +335,29 @@ string find_vcf_file(const string& folder, const string& chr) {  // parse.rs:263
 // line reader over plain or (multi-member) gzip files
 struct LineReader {
   gzFile f;
-  explicit LineReader(const string& path) : f(gzopen(path.c_str(), "rb")) {
+  explicit LineReader(const string& path) : f(gzopen(path.c_str(), "rb")), path_(path) {
     if (!f) throw Error("cannot open " + path);
     gzbuffer(f, 1 << 20);
   }
-  ~LineReader() { if (f) gzclose(f); }
+  ~LineReader() { if (f) gzclose(f); if (raw_fd >= 0) close(raw_fd); }
+  int raw_fd = -1;
+  int64_t raw_off = 0;
+  string path_;
   size_t read(char* dst, size_t n) {  // raw bytes following whatever next() consumed
+    if (raw_fd < 0 && gzdirect(f)) {  // plain text: skip zlib's copy and read the file itself from here on
+      raw_off = (int64_t)gztell(f);
+      raw_fd = open(path_.c_str(), O_RDONLY);
+    }
+    if (raw_fd >= 0) {
+      size_t total = 0;
+      while (total < n) {
+        const ssize_t got = pread(raw_fd, dst + total, n - total, raw_off);
+        if (got <= 0) break;
+        total += (size_t)got;
+        raw_off += got;
+      }
+      return total;
+    }
     size_t total = 0;
     while (total < n) {
       const int got = gzread(f, dst + total, (unsigned)std::min<size_t>(n - total, 1u << 30));
@@ -474,11 +494,13 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
                      unsigned min_gq, const RegionMap* allow, const RegionMap* mask, VariantScratch& scr, Variant* out, uint8_t* out_flags) {
   vector<sv>& fields = scr.fields;
   fields.clear();
-  for (size_t b = 0;;) {
-    const size_t e = line.find('\t', b);
-    if (e == sv::npos) { fields.push_back(line.substr(b)); break; }
-    fields.push_back(line.substr(b, e - b));
-    b = e + 1;
+  {
+    const char* p = line.data();
+    const size_t L = line.size();
+    size_t b = 0;
+    for (size_t i = 0; i < L; ++i)
+      if (p[i] == '\t') { fields.push_back(sv(p + b, i - b)); b = i + 1; }
+    fields.push_back(sv(p + b, L - b));
   }
   if (fields.size() < 9) throw Error("Invalid VCF line format");
   size_t max_idx = 0;
@@ -534,8 +556,26 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
   size_t max_len = 0;
   for (size_t i = 0; i < n; ++i) {
     const sv cell = fields[kept[i]];
-    const sv alleles = cell.substr(0, cell.find(':'));
     scr.off[i] = (uint32_t)scr.vals.size();
+    {  // the overwhelmingly common cell "a|b:GQ..." with one-digit alleles and GQ second: no searching at all
+      const char* c = cell.data();
+      const size_t L = cell.size();
+      if (gq_index == 1 && L >= 5 && c[3] == ':' && (c[1] == '|' || c[1] == '/') && (unsigned)(c[0] - '0') < 10u && (unsigned)(c[2] - '0') < 10u) {
+        size_t j = 4;
+        unsigned v = 0;
+        while (j < L && (unsigned)(c[j] - '0') < 10u && v < 100000u) { v = v * 10 + (unsigned)(c[j] - '0'); ++j; }
+        if (j > 4 && v <= 65535u && (j == L || c[j] == ':' || (c[j] == '\n' && j + 1 == L))) {
+          scr.vals.push_back((uint8_t)(c[0] - '0'));
+          scr.vals.push_back((uint8_t)(c[2] - '0'));
+          scr.len[i] = 2;
+          scr.none[i] = 2;  // called, and its GQ is already judged
+          max_len = std::max<size_t>(max_len, 2);
+          if (v < min_gq) low_gq = true;
+          continue;
+        }
+      }
+    }
+    const sv alleles = cell.substr(0, cell.find(':'));
     scr.len[i] = 0;
     scr.none[i] = 1;
     if (alleles == "." || alleles == "./." || alleles == ".|.") continue;
@@ -556,6 +596,7 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
     max_len = std::max(max_len, cnt);
   }
   for (size_t i = 0; i < n; ++i) {
+    if (scr.none[i] == 2) continue;
     if (scr.none[i]) { missing = true; continue; }
     sv part;
     if (!colon_part(fields[kept[i]], gq_index, &part)) throw Error("GQ value missing in sample genotype field");
@@ -576,7 +617,11 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
   out->max_len = max_len;
   out->data.assign(n * max_ploidy, 0xFF);
   for (size_t s2 = 0; s2 < n; ++s2)
-    if (!scr.none[s2]) memcpy(&out->data[s2 * max_ploidy], &scr.vals[scr.off[s2]], std::min<size_t>(scr.len[s2], max_ploidy));
+    if (scr.none[s2] != 1) {
+      const uint8_t* src = &scr.vals[scr.off[s2]];
+      uint8_t* dst = &out->data[s2 * max_ploidy];
+      for (size_t k = 0, m = std::min<size_t>(scr.len[s2], max_ploidy); k < m; ++k) dst[k] = src[k];
+    }
   *out_flags = flags;
   return true;
 }
@@ -628,17 +673,20 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
   // (the reference runs the same stage as a reader thread + rayon consumers, process.rs:4274-4392).
   vector<std::pair<Variant, uint8_t>> items;
   const unsigned T = worker_threads();
-  string block, carry;
+  string block, carry, ahead;
   const size_t kBlock = (size_t)64 << 20;
   bool eof = false;
+  // the next block is read (and inflated) by a helper thread while this one is parsed
+  auto fetch = [&r, kBlock](string* dst) -> size_t { dst->resize(kBlock); const size_t got = r.read(&(*dst)[0], kBlock); dst->resize(got); return got; };
+  size_t ahead_got = fetch(&ahead);
   while (!eof) {
-    block = carry;
+    block = std::move(carry);
     carry.clear();
-    const size_t had = block.size();
-    block.resize(had + kBlock);
-    const size_t got = r.read(&block[had], kBlock);
-    block.resize(had + got);
-    if (got < kBlock) eof = true;
+    block += ahead;
+    if (ahead_got < kBlock) eof = true;
+    std::thread reader;
+    if (!eof) reader = std::thread([&] { ahead_got = fetch(&ahead); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) { StageTimer w("    ingest:wait_for_reader"); t.join(); } } } joiner{reader};
     size_t usable = block.size();
     if (!eof) {
       const size_t nl = block.rfind('\n');
@@ -657,6 +705,7 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
     }
     vector<vector<std::pair<Variant, uint8_t>>> parts(T);
     vector<string> complaints(T);
+    StageTimer tparse("    ingest:parse_block");
     parallel_for(T, [&](unsigned t) {
       VariantScratch scr;
       size_t b = cut[t];
@@ -679,6 +728,7 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
       for (auto& it : parts[t]) items.push_back(std::move(it));
     }
   }
+  StageTimer tsort("    ingest:sort_and_store");
   std::stable_sort(items.begin(), items.end(), [](const auto& a, const auto& b) {
     if (a.first.position != b.first.position) return a.first.position < b.first.position;
     return a.first.data < b.first.data;  // lexicographic on the flat genotype bytes (process.rs:4397-4405)
@@ -744,7 +794,7 @@ struct DevBuf {
 // reference has no dense matrix; a one-allele all-missing matrix carries the same (empty) information for
 // the sparse formulas, and `has_dense` records which arm the reference would take.
 struct RegionMatrix {
-  std::unique_ptr<DeviceMatrix> dm;
+  std::shared_ptr<DeviceMatrix> dm;
   bool has_dense = false;
   size_t ploidy = 0;
 };
@@ -1216,8 +1266,68 @@ string join(const vector<string>& v, char d, bool csv_quote = false) {
 void gz_append(const string& path, const string& text) {  // open_append_compressed: one gzip member per call
   gzFile f = gzopen(path.c_str(), "ab");
   if (!f) throw Error("cannot open " + path);
-  if (!text.empty() && gzwrite(f, text.data(), (unsigned)text.size()) <= 0) { gzclose(f); throw Error("write failed: " + path); }
+  for (size_t off = 0; off < text.size();) {
+    const size_t n = std::min<size_t>(text.size() - off, (size_t)1 << 30);
+    if (gzwrite(f, text.data() + off, (unsigned)n) <= 0) { gzclose(f); throw Error("write failed: " + path); }
+    off += n;
+  }
   gzclose(f);
+}
+
+// A complete gzip member holding `text` (what one open_append_compressed + write + finish produces).
+string gzip_member(const string& text) {
+  z_stream z;
+  memset(&z, 0, sizeof z);
+  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
+  string out;
+  out.resize(deflateBound(&z, (uLong)std::min<size_t>(text.size(), (size_t)1 << 30)) + 64);
+  size_t in_off = 0, out_off = 0;
+  for (;;) {
+    const size_t n = std::min<size_t>(text.size() - in_off, (size_t)1 << 30);
+    z.next_in = (Bytef*)text.data() + in_off;
+    z.avail_in = (uInt)n;
+    in_off += n;
+    const int flush = in_off == text.size() ? Z_FINISH : Z_NO_FLUSH;
+    int rc;
+    do {
+      if (out.size() - out_off < (size_t)1 << 16) out.resize(out.size() * 2 + ((size_t)1 << 16));
+      z.next_out = (Bytef*)&out[out_off];
+      const size_t room = std::min<size_t>(out.size() - out_off, (size_t)1 << 30);
+      z.avail_out = (uInt)room;
+      rc = deflate(&z, flush);
+      if (rc == Z_STREAM_ERROR) { deflateEnd(&z); throw Error("deflate failed"); }
+      out_off += room - z.avail_out;
+    } while (z.avail_out == 0 || (flush == Z_FINISH && rc != Z_STREAM_END));
+    if (flush == Z_FINISH) break;
+  }
+  deflateEnd(&z);
+  out.resize(out_off);
+  return out;
+}
+
+// FALSTA tracks of one region: every track is formatted and deflated on its own thread and lands in the file as
+// its own gzip member, in track order (the files are multi-member already: one member per region in the
+// reference; readers see the same decompressed text).
+typedef std::function<string()> TrackFn;
+void append_tracks(const string& path, const vector<TrackFn>& tracks) {
+  if (tracks.empty()) return;
+  vector<string> members(tracks.size());
+  std::atomic<size_t> next{0};
+  parallel_for((unsigned)std::min<size_t>(worker_threads(), tracks.size()), [&](unsigned) {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= tracks.size()) break;
+      const string text = tracks[i]();
+      if (!text.empty()) members[i] = gzip_member(text);
+    }
+  });
+  FILE* f = nullptr;
+  for (auto& m : members) {
+    if (m.empty()) continue;
+    if (!f && !(f = fopen(path.c_str(), "ab"))) throw Error("cannot open " + path);
+    if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); throw Error("write failed: " + path); }
+  }
+  if (f) fclose(f);
 }
 
 struct RegionOutput {
@@ -1231,67 +1341,90 @@ struct RegionOutput {
   vector<vector<string>> wc_rows;
 };
 
-string diversity_falsta(const RegionOutput& r) {  // append_diversity_falsta, process.rs:3740-3806
-  if (r.diversity.empty()) return "";
-  const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
-  const int64_t n = hal_len(region);
-  if (n > (int64_t)1 << 31) throw Error("region too long for a dense FALSTA track");
-  std::set<int> gids;
-  for (auto& d : r.diversity) gids.insert(std::get<3>(d));
-  string out;
-  struct Spec { bool filtered; bool is_pi; const char* prefix; };
-  const Spec specs[4] = {{false, true, "unfiltered_pi_"}, {false, false, "unfiltered_theta_"}, {true, true, "filtered_pi_"}, {true, false, "filtered_theta_"}};
-  for (int g : gids)
-    for (const Spec& sp : specs) {
-      vector<string> line((size_t)n, "0");
-      bool any = false;
-      for (auto& d : r.diversity) {
-        if (std::get<3>(d) != g || std::get<4>(d) != sp.filtered) continue;
-        const int64_t p = std::get<0>(d) - 1;
-        if (!hal_contains(region, p)) continue;
-        line[(size_t)(p - region.first)] = falsta_div_value(sp.is_pi ? std::get<1>(d) : std::get<2>(d));
-        any = true;
-      }
-      if (any) {
-        out += ">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1) + "_group_" + std::to_string(g) + "\n";
-        out += join(line, ',') + "\n";
-      }
-    }
-  return out;
+// One dense FALSTA line: `n` comma-joined tokens, `dflt` everywhere except at the positions present, where the
+// LAST record of a position wins (the reference assigns into a Vec in record order).
+template <class PosAt, class TokenAt>
+bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, PosAt pos_at, TokenAt token_at, const char* dflt,
+                 vector<int32_t>& slot) {
+  slot.assign((size_t)n, -1);
+  bool any = false;
+  for (size_t i = 0; i < count; ++i) {
+    const int64_t p = pos_at(i) - 1;
+    if (!hal_contains(region, p)) continue;
+    slot[(size_t)(p - region.first)] = (int32_t)i;
+    any = true;
+  }
+  const size_t dl = strlen(dflt);
+  out.reserve(out.size() + (size_t)n * (dl + 1) + 16);
+  for (int64_t k = 0; k < n; ++k) {
+    if (k) out.push_back(',');
+    if (slot[(size_t)k] < 0) out.append(dflt, dl);
+    else out += token_at((size_t)slot[(size_t)k]);
+  }
+  out.push_back('\n');
+  return any;
 }
 
-string fst_falsta(const RegionOutput& r) {  // append_fst_falsta, process.rs:3809-4003
-  if (r.wc_sites.empty() && r.hudson_sites.empty()) return "";
+vector<TrackFn> diversity_tracks(const RegionOutput& r) {  // append_diversity_falsta, process.rs:3740-3806
+  vector<TrackFn> tracks;
+  if (r.diversity.empty()) return tracks;
   const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
   const int64_t n = hal_len(region);
-  if (n > (int64_t)1 << 31) throw Error("region too long for a dense FALSTA track");
+  if (n > (int64_t)1 << 31 || r.diversity.size() >= (size_t)1 << 31) throw Error("region too long for a dense FALSTA track");
+  std::set<int> gids;
+  for (auto& d : r.diversity) gids.insert(std::get<3>(d));
+  struct Spec { bool filtered; bool is_pi; const char* prefix; };
+  static const Spec specs[4] = {{false, true, "unfiltered_pi_"}, {false, false, "unfiltered_theta_"}, {true, true, "filtered_pi_"}, {true, false, "filtered_theta_"}};
+  for (int g : gids)
+    for (const Spec& sp : specs)
+      tracks.push_back([&r, region, n, g, sp]() -> string {
+        vector<size_t> sel;  // records of this (group, filter) in record order
+        for (size_t i = 0; i < r.diversity.size(); ++i)
+          if (std::get<3>(r.diversity[i]) == g && std::get<4>(r.diversity[i]) == sp.filtered) sel.push_back(i);
+        string line;
+        vector<int32_t> slot;
+        const bool any = falsta_line(line, region, n, sel.size(), [&](size_t i) { return std::get<0>(r.diversity[sel[i]]); },
+                                     [&](size_t i) { const auto& d = r.diversity[sel[i]]; return falsta_div_value(sp.is_pi ? std::get<1>(d) : std::get<2>(d)); },
+                                     "0", slot);
+        if (!any) return "";
+        return ">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" +
+               std::to_string(r.region_end1) + "_group_" + std::to_string(g) + "\n" + line;
+      });
+  return tracks;
+}
+
+vector<TrackFn> fst_tracks(const RegionOutput& r) {  // append_fst_falsta, process.rs:3809-4003
+  vector<TrackFn> tracks;
+  if (r.wc_sites.empty() && r.hudson_sites.empty()) return tracks;
+  const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
+  const int64_t n = hal_len(region);
+  if (n > (int64_t)1 << 31 || r.wc_sites.size() >= (size_t)1 << 31 || r.hudson_sites.size() >= (size_t)1 << 31)
+    throw Error("region too long for a dense FALSTA track");
   const string suffix = "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1);
-  string out;
-  auto emit = [&](const string& header, auto getter, size_t count) {
-    vector<string> v((size_t)n, "NA");
-    for (size_t i = 0; i < count; ++i) {
-      std::pair<int64_t, double> pv = getter(i);
-      const int64_t p = pv.first - 1;
-      if (hal_contains(region, p)) v[(size_t)(p - region.first)] = falsta_fst_value(pv.second);
-    }
-    out += ">" + header + "_" + suffix + "\n" + join(v, ',') + "\n";
+  auto add = [&](const string& header, size_t count, std::function<std::pair<int64_t, double>(size_t)> getter) {
+    tracks.push_back([=]() -> string {
+      string out = ">" + header + "_" + suffix + "\n";
+      vector<int32_t> slot;
+      falsta_line(out, region, n, count, [&](size_t i) { return getter(i).first; }, [&](size_t i) { return falsta_fst_value(getter(i).second); }, "NA", slot);
+      return out;
+    });
   };
   if (!r.wc_sites.empty()) {
-    const auto& w = r.wc_sites;
-    emit("haplotype_overall_fst_summary", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].overall_fst); }, w.size());
-    emit("haplotype_overall_fst_numerator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].overall_num); }, w.size());
-    emit("haplotype_overall_fst_denominator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].overall_den); }, w.size());
-    emit("haplotype_0v1_pairwise_fst_summary", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].pair_fst); }, w.size());
-    emit("haplotype_0v1_pairwise_fst_numerator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].pair_num); }, w.size());
-    emit("haplotype_0v1_pairwise_fst_denominator", [&](size_t i) { return std::make_pair(w[i].pos1, w[i].pair_den); }, w.size());
+    const vector<WcSite>* w = &r.wc_sites;
+    add("haplotype_overall_fst_summary", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].overall_fst); });
+    add("haplotype_overall_fst_numerator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].overall_num); });
+    add("haplotype_overall_fst_denominator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].overall_den); });
+    add("haplotype_0v1_pairwise_fst_summary", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].pair_fst); });
+    add("haplotype_0v1_pairwise_fst_numerator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].pair_num); });
+    add("haplotype_0v1_pairwise_fst_denominator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].pair_den); });
   }
   if (!r.hudson_sites.empty()) {
-    const auto& h = r.hudson_sites;
-    emit("hudson_pairwise_fst_hap_0v1", [&](size_t i) { return std::make_pair(std::get<0>(h[i]), std::get<1>(h[i])); }, h.size());
-    emit("hudson_pairwise_fst_hap_0v1_numerator", [&](size_t i) { return std::make_pair(std::get<0>(h[i]), std::get<2>(h[i])); }, h.size());
-    emit("hudson_pairwise_fst_hap_0v1_denominator", [&](size_t i) { return std::make_pair(std::get<0>(h[i]), std::get<3>(h[i])); }, h.size());
+    const auto* h = &r.hudson_sites;
+    add("hudson_pairwise_fst_hap_0v1", h->size(), [h](size_t i) { return std::make_pair(std::get<0>((*h)[i]), std::get<1>((*h)[i])); });
+    add("hudson_pairwise_fst_hap_0v1_numerator", h->size(), [h](size_t i) { return std::make_pair(std::get<0>((*h)[i]), std::get<2>((*h)[i])); });
+    add("hudson_pairwise_fst_hap_0v1_denominator", h->size(), [h](size_t i) { return std::make_pair(std::get<0>((*h)[i]), std::get<3>((*h)[i])); });
   }
-  return out;
+  return tracks;
 }
 
 // ---- per-region driver (process.rs:2468-3653) ----------------------------------------------------------------
@@ -1301,6 +1434,7 @@ struct Args {
   unsigned min_gq = 30;
   bool enable_fst = false, enable_pca = false;
   int device = 0;
+  bool ingest_only = false;  // diagnostic: parse the inputs, report counts, compute nothing (needs no GPU)
   vector<int> devices;  // --devices: one worker thread per entry, config regions dealt out dynamically
 };
 
@@ -1323,7 +1457,8 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
   const size_t N = vcf.sample_names.size();
   std::optional<StageTimer> tm;
   tm.emplace("  region:pack_and_upload_matrices");
-  RegionMatrix m_unf = build_matrix(unf, N, args.device), m_fil = build_matrix(fil, N, args.device);
+  RegionMatrix m_unf = build_matrix(unf, N, args.device);
+  RegionMatrix m_fil = fil == unf ? m_unf : build_matrix(fil, N, args.device);  // same variants -> one matrix in HBM
   tm.emplace("  region:gpu_sweeps_and_host_statistics");
 
   WcRegion wc;
@@ -1525,6 +1660,11 @@ int run(const Args& args) {
       tm.emplace("vcf_ingest");
       try { vcf = process_vcf(vcf_path, chr, merge_intervals(hulls), args.min_gq, &final_mask, allow_regions ? &*allow_regions : nullptr, exclusion); }
       catch (const Error& e) { logmsg("ERROR", "Error processing VCF for " + chr + ": " + e.what()); continue; }
+      if (args.ingest_only) {
+        tm.reset();
+        printf("[INGEST] chr %s: %zu variants x %zu samples\n", chr.c_str(), vcf.variants.size(), vcf.sample_names.size());
+        continue;
+      }
       tm.emplace("regions_statistics_and_writers");
       // Regions are independent units: one worker per GPU pulls the next config entry; rows and
       // tracks are emitted in config order whatever the completion order, so the files match a 1-GPU run.
@@ -1539,9 +1679,8 @@ int run(const Args& args) {
           std::optional<RegionOutput>& res = done[emitted];
           if (res) {
             csv << join(res->csv_row, ',', true) << "\n";
-            const string d = diversity_falsta(*res), f = fst_falsta(*res);
-            if (!d.empty()) gz_append(div_path, d);
-            if (!f.empty()) gz_append(fst_path, f);
+            append_tracks(div_path, diversity_tracks(*res));
+            append_tracks(fst_path, fst_tracks(*res));
             for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
             for (auto& r : res->wc_rows) wc_rows.push_back(r);
             res.reset();
@@ -1624,6 +1763,7 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--pca_components" || k == "--pca_output") (void)value();
     else if (k == "--fst") a.enable_fst = true;
     else if (k == "--fst_populations") a.fst_populations = value();
+    else if (k == "--ingest_only") a.ingest_only = true;
     else if (k == "--device") a.device = atoi(value().c_str());
     else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)
       const string v2 = value();
@@ -1648,7 +1788,7 @@ int main(int argc, char** argv) {
   try {
     const Args args = parse_args(argc, argv);
     int n = 0;
-    fmh_check(fmh_device_count(&n), "GPU required (run_vcf has no CPU fallback)");
+    if (!args.ingest_only) fmh_check(fmh_device_count(&n), "GPU required (run_vcf has no CPU fallback)");
     return run(args);
   } catch (const std::exception& e) {
     fprintf(stderr, "Error: %s\n", e.what());
