@@ -543,6 +543,21 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   for (int p = 0; p < 8; ++p) a.group_size[p] = p < g->n_groups ? (uint32_t)g->sizes[p] : 0;
   a.n_groups = g->n_groups;
   a.max_allele = m->max_allele;
+  if (mode & kModeWc) {
+    // without missing data every site has n_i = group size: the allele-independent W&C terms are per launch
+    const int P = g->padded;
+    uint32_t n8[8];
+    bool use8[8];
+    for (int i = 0; i < 8; ++i) { n8[i] = i < P ? a.group_size[i] : 0; use8[i] = n8[i] != 0; }
+    a.wc_shape[0] = wc_shape<8>(n8, use8);
+    int k = 1;
+    for (int i = 0; i < P; ++i)
+      for (int j = i + 1; j < P; ++j, ++k) {
+        const uint32_t pn[2] = {n8[i], n8[j]};
+        const bool pu[2] = {true, true};
+        a.wc_shape[k] = wc_shape<2>(pn, pu);
+      }
+  }
   a.part_f64 = w->part_f64;
   a.part_u64 = w->part_u64;
   if (mode & kModeDiversity) {

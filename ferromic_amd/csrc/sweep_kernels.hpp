@@ -44,6 +44,21 @@ struct MatrixView {
   uint32_t nvec;     // 16-byte vectors per row = ceil(H/16) (<= pitch/16)
 };
 
+// The allele-independent part of calculate_variance_components (stats.rs:2034-2127) for one W&C slot
+// (overall or one pair): everything that depends only on the called counts n_i of the groups taking part.
+// Without missing data the n_i are the group sizes, so the host evaluates these once per launch with the same
+// IEEE operations and hands them over as kernel arguments (scalar operands, no registers, no divisions).
+struct WcShape {
+  double s2_den;      // (r - 1) * n_bar
+  double rm1_over_r;  // (r - 1) / r
+  double nbar_m1;     // n_bar - 1
+  double a_den;       // 1 - c_squared / (r - 1)
+  double b_fac;       // n_bar / (n_bar - 1)
+  int live;           // 0: r < 2 or n_bar - 1 < 1e-9 -> the slot contributes (0, 0)
+  int s2_ok;          // (r - 1) > 1e-9 && n_bar > 1e-9
+};
+constexpr int kMaxWcSlots = 1 + (8 * 7) / 2;
+
 struct SweepArgs {
   MatrixView mv;
   const uint8_t* masks;   // device [P][pitch] 0/1 bytes
@@ -63,6 +78,7 @@ struct SweepArgs {
   const double* harmonic;  // device table H_k, k = 0..H (stats.rs:4234-4240)
   double* wc_a; double* wc_b; uint8_t* wc_state;                                 // W&C [(1+npairs)][row_count]
   int8_t wc_slot[32];      // kernel slot k (padded-P pair order) -> caller slot, -1 = not reported
+  WcShape wc_shape[kMaxWcSlots];  // kernel slot order; valid when the matrix has no missing data
   // block partials
   double* part_f64;        // [grid][kMaxF64]
   unsigned long long* part_u64;  // [grid][kMaxU64]
@@ -177,39 +193,44 @@ __device__ __forceinline__ double clamp01(double x) {  // f64::max(0.0).min(1.0)
   return x < 1.0 ? x : 1.0;
 }
 
-// calculate_variance_components, stats.rs:2034-2127.  n[i], c[i] for the r groups with data, in
-// group order; global_p = sum c / sum n.
+// calculate_variance_components, stats.rs:2034-2127, split in two so that nothing is evaluated twice:
+// wc_shape() is the part that depends on the called counts only, wc_apply() the per-allele remainder.
+// Groups are visited in group order skipping those not taking part, which is the order the reference's
+// compacted `pop_stats` vector has, so every sum sees the same operands in the same sequence.
 template <int R>
-__device__ __forceinline__ void wc_components(const uint32_t (&n)[R], const uint32_t (&c)[R], int r_i,
-                                              double global_p, double& a, double& b) {
-  double r = (double)r_i;
-  a = 0.0; b = 0.0;
-  if (r < 2.0) return;
+__host__ __device__ __forceinline__ WcShape wc_shape(const uint32_t (&n)[R], const bool (&use)[R]) {
+  WcShape s;
+  s.s2_den = 0.0; s.rm1_over_r = 0.0; s.nbar_m1 = 0.0; s.a_den = 1.0; s.b_fac = 0.0; s.live = 0; s.s2_ok = 0;
+  int r_i = 0;
   unsigned long long total_h = 0;
 #pragma unroll
-  for (int i = 0; i < R; ++i) if (i < r_i) total_h += n[i];
+  for (int i = 0; i < R; ++i) if (use[i]) { ++r_i; total_h += n[i]; }
+  double r = (double)r_i;
+  if (r < 2.0) return s;
   double n_bar = (double)total_h / r;
-  if ((n_bar - 1.0) < 1e-9) return;
+  if ((n_bar - 1.0) < 1e-9) return s;
   double sum_sq_diff_n = 0.0;
 #pragma unroll
-  for (int i = 0; i < R; ++i) if (i < r_i) { double diff = (double)n[i] - n_bar; sum_sq_diff_n += diff * diff; }
+  for (int i = 0; i < R; ++i) if (use[i]) { double diff = (double)n[i] - n_bar; sum_sq_diff_n += diff * diff; }
   double c_squared = (r > 0.0 && n_bar > 0.0) ? sum_sq_diff_n / (r * n_bar * n_bar) : 0.0;
-  double numerator_s_squared = 0.0;
-#pragma unroll
-  for (int i = 0; i < R; ++i) if (i < r_i) {
-    double freq = (double)c[i] / (double)n[i];
-    double diff_p = freq - global_p;
-    numerator_s_squared += (double)n[i] * diff_p * diff_p;
-  }
-  double s_squared = ((r - 1.0) > 1e-9 && n_bar > 1e-9) ? numerator_s_squared / ((r - 1.0) * n_bar) : 0.0;
-  double x_wc = global_p * (1.0 - global_p) - ((r - 1.0) / r) * s_squared;
-  double a_numerator_term = s_squared - (x_wc / (n_bar - 1.0));
-  double a_denominator_factor = 1.0 - (c_squared / (r - 1.0));
-  a = a_numerator_term / a_denominator_factor;
-  b = (n_bar / (n_bar - 1.0)) * x_wc;
+  s.s2_ok = ((r - 1.0) > 1e-9 && n_bar > 1e-9) ? 1 : 0;
+  s.s2_den = (r - 1.0) * n_bar;
+  s.rm1_over_r = (r - 1.0) / r;
+  s.nbar_m1 = n_bar - 1.0;
+  s.a_den = 1.0 - (c_squared / (r - 1.0));
+  s.b_fac = n_bar / (n_bar - 1.0);
+  s.live = 1;
+  return s;
 }
 
-// fst_estimate_from_components, stats.rs:1781-1812 -> state code
+// numerator_s_squared = sum n_i (p_i - p)^2 is accumulated by the caller; this finishes a and b.
+__device__ __forceinline__ void wc_apply(const WcShape& s, double numerator_s_squared, double global_p, double& a, double& b) {
+  double s_squared = s.s2_ok ? numerator_s_squared / s.s2_den : 0.0;
+  double x_wc = global_p * (1.0 - global_p) - s.rm1_over_r * s_squared;
+  double a_numerator_term = s_squared - (x_wc / s.nbar_m1);
+  a = a_numerator_term / s.a_den;
+  b = s.b_fac * x_wc;
+}
 __device__ __forceinline__ uint8_t wc_classify(double a, double b) {
   double denominator = a + b;
   if (denominator > kFstEps) return 0;   // Calculable
@@ -240,45 +261,73 @@ struct WcSite {
   double b[1 + (P * (P - 1)) / 2];
 };
 
-template <int P>
-__device__ __forceinline__ void wc_add_allele(const uint32_t (&n)[P], const uint32_t (&c)[P], WcSite<P>& w) {
-  // groups with data, in group order (stats.rs:1907-1922)
-  uint32_t vn[P], vc[P];
+// calculate_fst_wc_at_site_with_membership, stats.rs:1893-1985, for NA alleles of one site at once.
+// c[al][i] = calls of allele `al` in group i, n[i] = called haplotypes of group i.  Slot-major: the shape of a
+// slot is obtained once (kernel argument when PRE, else computed here) and applied to every allele; each
+// accumulator still receives its per-allele terms in allele order.
+template <int P, int NA, bool PRE>
+__device__ __forceinline__ void wc_add_alleles(const SweepArgs& A, const uint32_t (&n)[P], const uint32_t (&c)[NA][P], WcSite<P>& w) {
+  bool use[P];
+  double nd[P], freq[NA][P];
   int valid = 0;
-  unsigned long long total_called = 0, total_target = 0;
+  unsigned long long total_called = 0;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
-    if (n[i] != 0) {
-      // compacting insert without dynamic register indexing
+    use[i] = n[i] != 0;
+    nd[i] = (double)n[i];
+    if (use[i]) { ++valid; total_called += n[i]; }
 #pragma unroll
-      for (int j = 0; j < P; ++j) if (j == valid) { vn[j] = n[i]; vc[j] = c[i]; }
-      ++valid;
-      total_called += n[i];
-      total_target += c[i];
+    for (int al = 0; al < NA; ++al) freq[al][i] = use[i] ? (double)c[al][i] / nd[i] : 0.0;
+  }
+  if (valid < 2) return;  // stats.rs:1925-1930
+  {
+    WcShape sh;
+    if constexpr (PRE) sh = A.wc_shape[0]; else sh = wc_shape<P>(n, use);
+    if (sh.live) {
+#pragma unroll
+      for (int al = 0; al < NA; ++al) {
+        unsigned long long total_target = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) if (use[i]) total_target += c[al][i];
+        double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
+        double num = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) if (use[i]) { double diff_p = freq[al][i] - global_freq; num += nd[i] * diff_p * diff_p; }
+        double ca, cb;
+        wc_apply(sh, num, global_freq, ca, cb);
+        w.a[0] += ca;
+        w.b[0] += cb;
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < P; ++j) if (j >= valid) { vn[j] = 1; vc[j] = 0; }
-  if (valid < 2) return;  // stats.rs:1925-1930
-  double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
-  double ca, cb;
-  wc_components<P>(vn, vc, valid, global_freq, ca, cb);
-  w.a[0] += ca;
-  w.b[0] += cb;
   int k = 1;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
 #pragma unroll
     for (int j = i + 1; j < P; ++j) {
-      if (n[i] != 0 && n[j] != 0) {  // stats.rs:1950-1952
-        uint32_t pn[2] = {n[i], n[j]};
-        uint32_t pc[2] = {c[i], c[j]};
-        unsigned long long pair_total = (unsigned long long)n[i] + n[j];
-        double pair_global = pair_total > 0 ? (double)((unsigned long long)c[i] + c[j]) / (double)pair_total : 0.0;
-        double pa, pb;
-        wc_components<2>(pn, pc, 2, pair_global, pa, pb);
-        w.a[k] += pa;
-        w.b[k] += pb;
+      if (use[i] && use[j]) {  // stats.rs:1950-1952
+        WcShape sh;
+        if constexpr (PRE) {
+          sh = A.wc_shape[k];
+        } else {
+          const uint32_t pn[2] = {n[i], n[j]};
+          const bool pu[2] = {true, true};
+          sh = wc_shape<2>(pn, pu);
+        }
+        if (sh.live) {
+          unsigned long long pair_total = (unsigned long long)n[i] + n[j];
+#pragma unroll
+          for (int al = 0; al < NA; ++al) {
+            double pair_global = pair_total > 0 ? (double)((unsigned long long)c[al][i] + c[al][j]) / (double)pair_total : 0.0;
+            double num = 0.0;
+            { double diff_p = freq[al][i] - pair_global; num += nd[i] * diff_p * diff_p; }
+            { double diff_p = freq[al][j] - pair_global; num += nd[j] * diff_p * diff_p; }
+            double pa, pb;
+            wc_apply(sh, num, pair_global, pa, pb);
+            w.a[k] += pa;
+            w.b[k] += pb;
+          }
+        }
       }
       ++k;
     }
@@ -793,7 +842,10 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
           if constexpr ((MODE & kModeWc) != 0) {
             // the reference iterates only alleles present among all samples; an absent allele
             // contributes exact zeros, so iterating it is harmless
-            wc_add_allele<P>(n, c, wc);
+            uint32_t cc[1][P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) cc[0][p] = c[p];
+            wc_add_alleles<P, 1, !MISSING>(A, n, cc, wc);
           }
         };
         if (bound <= 3) {
@@ -837,8 +889,10 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         }
       }
       if constexpr ((MODE & kModeWc) != 0) {
-        wc_add_allele<P>(mine.n, c0, wc);
-        wc_add_allele<P>(mine.n, c1, wc);
+        uint32_t cc[2][P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) { cc[0][p] = c0[p]; cc[1][p] = c1[p]; }
+        wc_add_alleles<P, 2, !MISSING>(A, mine.n, cc, wc);
       }
     }
 

@@ -60,6 +60,8 @@ def main():
         elif kind == "wc":
             nw = 1 + P * (P - 1) // 2
             pa, pb, ps, pn = buf(8 * nw * S), buf(8 * nw * S), buf(nw * S), buf(4 * P * S)
+            if os.environ.get("MEASURE_NO_SITE_OUTPUTS") == "1":  # totals only: how much of the time is the stores
+                pa = pb = ps = pn = None
             tot = _abi.WcTotals()
             w_out = nw * 17 + 4 * P  # a, b f64 + state u8 per slot, called u32 per group
 
