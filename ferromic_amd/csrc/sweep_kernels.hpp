@@ -594,6 +594,15 @@ constexpr int kOffWcInf = 24;    // u64
 // ------------------------------------------------------------------------------------------------
 // epilogue: statistics of one site from its tallies (lane-parallel, one site per lane)
 // ------------------------------------------------------------------------------------------------
+// Per-site tracks are written once and never read back by the sweep: streaming (non-temporal) stores.
+template <class T, class V>
+__device__ __forceinline__ void site_store(T* p, V v) {
+#ifdef FMH_PLAIN_STORES
+  *p = (T)v;
+#else
+  __builtin_nontemporal_store((T)v, p);
+#endif
+}
 template <int P, int MODE, bool MISSING, bool GENERAL>
 __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx, bool row_ok,
                                               const SiteTally<P>& t, double hud_dot, const WcSite<P>& wc,
@@ -622,8 +631,8 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
       if (pi_ok[p]) T.pop_pi[p] += v; else T.pop_unc[p] += 1;
       if (t.distinct[p] >= 2) T.pop_seg[p] += 1;
       if (p < A.n_groups) {
-        if (A.alt) A.alt[(size_t)p * A.row_count + out_idx] = t.alt[p];
-        if (A.called) A.called[(size_t)p * A.row_count + out_idx] = n;
+        if (A.alt) site_store(A.alt + ((size_t)p * A.row_count + out_idx), t.alt[p]);
+        if (A.called) site_store(A.called + ((size_t)p * A.row_count + out_idx), n);
       }
     }
   }
@@ -639,9 +648,9 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
       pv = pi_sparse(n, (double)t.ssq[0]);
     }
     if (row_ok) {
-      if (A.site_pi) A.site_pi[out_idx] = pv;
-      if (A.site_theta) A.site_theta[out_idx] = tv;
-      if (A.site_distinct) A.site_distinct[out_idx] = t.distinct[0];
+      if (A.site_pi) site_store(A.site_pi + (out_idx), pv);
+      if (A.site_theta) site_store(A.site_theta + (out_idx), tv);
+      if (A.site_distinct) site_store(A.site_distinct + (out_idx), t.distinct[0]);
     }
   }
 
@@ -666,12 +675,12 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
       }
     }
     if (row_ok) {
-      if (A.fst) A.fst[out_idx] = fst;
-      if (A.dxy) A.dxy[out_idx] = dxy_ok ? dxy : f64_nan();
-      if (A.pi1) A.pi1[out_idx] = pi_ok[0] ? pi[0] : f64_nan();
-      if (A.pi2) A.pi2[out_idx] = pi_ok[1] ? pi[1] : f64_nan();
-      if (A.num) A.num[out_idx] = numc;
-      if (A.den) A.den[out_idx] = denc;
+      if (A.fst) site_store(A.fst + (out_idx), fst);
+      if (A.dxy) site_store(A.dxy + (out_idx), dxy_ok ? dxy : f64_nan());
+      if (A.pi1) site_store(A.pi1 + (out_idx), pi_ok[0] ? pi[0] : f64_nan());
+      if (A.pi2) site_store(A.pi2 + (out_idx), pi_ok[1] ? pi[1] : f64_nan());
+      if (A.num) site_store(A.num + (out_idx), numc);
+      if (A.den) site_store(A.den + (out_idx), denc);
       if (comp_ok) { T.hud[5] += numc; T.hud[6] += denc; T.hud_u[1] += 1; }  // hudson_component_sums 1625-1635
       // calculate_dxy_dense 2546-2596 / sparse fold 2476-2496 always use the frequency-dot form
       if (dxy_ok) T.hud[7] += clamp01(1.0 - hud_dot); else T.hud_u[2] += 1;
@@ -730,9 +739,9 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
       for (int k = 0; k < NW; ++k) {
         const int slot = A.wc_slot[k];
         if (slot >= 0) {
-          if (A.wc_a) A.wc_a[(size_t)slot * A.row_count + out_idx] = oa[k];
-          if (A.wc_b) A.wc_b[(size_t)slot * A.row_count + out_idx] = ob[k];
-          if (A.wc_state) A.wc_state[(size_t)slot * A.row_count + out_idx] = st[k];
+          if (A.wc_a) site_store(A.wc_a + ((size_t)slot * A.row_count + out_idx), oa[k]);
+          if (A.wc_b) site_store(A.wc_b + ((size_t)slot * A.row_count + out_idx), ob[k]);
+          if (A.wc_state) site_store(A.wc_state + ((size_t)slot * A.row_count + out_idx), st[k]);
         }
         if (st[k] != 3) { T.wc_a[k] += oa[k]; T.wc_b[k] += ob[k]; T.wc_inf[k] += 1; }  // 2172-2203
       }

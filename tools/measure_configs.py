@@ -54,14 +54,33 @@ def main():
             sites = _abi.HudsonSites(None, buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S))
             tot = _abi.HudsonTotals()
             w_out = 56
+            mode = os.environ.get("MEASURE_NO_SITE_OUTPUTS")
+            if mode == "1":
+                sites = _abi.HudsonSites()
+            elif mode == "f64only":
+                sites.d_alt = None
+                sites.d_called = None
+            elif mode == "u32only":
+                sites = _abi.HudsonSites(None, None, None, None, None, None, sites.d_alt, sites.d_called)
+            elif mode == "one":
+                sites = _abi.HudsonSites(None, sites.d_dxy, None, None, None, None, None, None)
 
             def step():
                 _abi.check(lib.fmh_hudson_sweep(dm._h, g._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(tot), None))
         elif kind == "wc":
             nw = 1 + P * (P - 1) // 2
             pa, pb, ps, pn = buf(8 * nw * S), buf(8 * nw * S), buf(nw * S), buf(4 * P * S)
-            if os.environ.get("MEASURE_NO_SITE_OUTPUTS") == "1":  # totals only: how much of the time is the stores
+            mode = os.environ.get("MEASURE_NO_SITE_OUTPUTS")
+            if mode == "1":  # totals only: how much of the time is the stores
                 pa = pb = ps = pn = None
+            elif mode == "nostate":
+                ps = None
+            elif mode == "stateonly":
+                pa = pb = pn = None
+            elif mode == "abonly":
+                ps = pn = None
+            elif mode == "aonly":
+                pb = ps = pn = None
             tot = _abi.WcTotals()
             w_out = nw * 17 + 4 * P  # a, b f64 + state u8 per slot, called u32 per group
 
