@@ -104,6 +104,7 @@ SYMBOLS = {
     "fmh_device_info": (_i, [_i, C.c_char_p, _sz, _P(_i), _P(_u64)]),
     "fmh_device_alloc": (_i, [_i, _sz, _P(_vp)]),
     "fmh_device_free": (_i, [_i, _vp]),
+    "fmh_device_release_scratch": (_i, [_i]),
     "fmh_copy_to_host": (_i, [_i, _vp, _vp, _sz, _vp]),
     "fmh_copy_to_device": (_i, [_i, _vp, _vp, _sz, _vp]),
     "fmh_stream_synchronize": (_i, [_i, _vp]),

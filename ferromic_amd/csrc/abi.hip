@@ -418,6 +418,8 @@ struct Workspace {
   double* harmonic = nullptr;
   size_t harmonic_len = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint8_t* pd_planes = nullptr;  // pairwise-differences planes, kept between calls (fmh_device_release_scratch frees them)
+  size_t pd_planes_bytes = 0;
   std::mutex in_use;  // one sweep at a time per device: concurrent callers share the partials and the pinned staging
 };
 static Workspace g_ws[64];
@@ -744,35 +746,88 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   if (!m || !d_diff || !d_both) return fail(FMH_ERR_INVALID, "NULL argument");
   if (n_samples > m->samples) return fail(FMH_ERR_INVALID, "n_samples %zu exceeds the matrix's %zu samples", n_samples, m->samples);
   if (m->max_allele > 15) return fail(FMH_ERR_UNSUPPORTED, "pairwise differences support max_allele <= 15 (got %u)", m->max_allele);
+  if (m->ploidy > 127) return fail(FMH_ERR_UNSUPPORTED, "pairwise differences support ploidy <= 127 (int8 operands), got %zu", m->ploidy);
   FMH_TRY(use_device(m->device));
   if (n_samples < 2 || m->variants == 0) return FMH_OK;
   hipStream_t st = (hipStream_t)stream;
   const int n_alleles = (int)m->max_allele + 1;
-  const int n_planes = n_alleles + 2;
-  const size_t n_pad = round_up(n_samples, kPdTile), s_pad = round_up(m->variants, kPdTile);
-  uint8_t* planes = nullptr;
-  const size_t bytes = (size_t)n_planes * n_pad * s_pad;
-  HIP_TRY(hipMalloc((void**)&planes, bytes));
-  hipError_t e = hipMemsetAsync(planes, 0, bytes, st);
-  if (e == hipSuccess) {
-    MatrixView mv{m->data, m->bits, m->pitch, m->bits_pitch, m->columns, m->nvec};
-    hipLaunchKernelGGL(pd_planes_kernel, dim3((unsigned)(s_pad / kPdTile), (unsigned)(n_pad / kPdTile)), dim3(256), 0, st, mv,
-                       m->variants, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, planes, n_pad, s_pad);
-    e = hipGetLastError();
+  const bool missing = m->bits != nullptr;
+  const int n_planes = missing ? n_alleles + 2 : n_alleles;  // + genotype length, + valid flag only when calls can be missing
+  const size_t n_pad = round_up(n_samples, kPdBlock);
+  // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
+  static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
+  size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK);
+  slab = std::min(round_up(m->variants, kPdStageK), slab / kPdStageK * kPdStageK);
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(m->device, &w));
+  std::lock_guard<std::mutex> busy(w->in_use);
+  const size_t planes_bytes = (size_t)n_planes * n_pad * slab;
+  if (w->pd_planes_bytes < planes_bytes) {
+    if (w->pd_planes) (void)hipFree(w->pd_planes);
+    w->pd_planes = nullptr;
+    w->pd_planes_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&w->pd_planes, planes_bytes));
+    w->pd_planes_bytes = planes_bytes;
   }
-  if (e == hipSuccess) {
-    const size_t nt = n_pad / kPdTile, tiles = nt * (nt + 1) / 2;
-    // split K so that an i32 partial cannot overflow (<= 81 per site at ploidy 9) and the grid fills the chip
-    size_t k_chunk = round_up(std::min<size_t>(s_pad, (size_t)1 << 20), kPdTile);
-    while (tiles * ((s_pad + k_chunk - 1) / k_chunk) < 2048 && k_chunk > 4096) k_chunk = round_up(k_chunk / 2, kPdTile);
-    const size_t ksplit = (s_pad + k_chunk - 1) / k_chunk;
-    hipLaunchKernelGGL(pd_gram_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), 0, st, planes, n_pad, s_pad, n_alleles,
-                       k_chunk, (uint32_t)n_samples, d_diff, d_both);
+  uint8_t* planes = w->pd_planes;
+  hipError_t e = hipSuccess;
+  const size_t nt = n_pad / kPdBlock, tiles = nt * (nt + 1) / 2;
+  static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
+  for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
+    const size_t rows = std::min(slab, m->variants - row0);
+    const size_t s_pad = round_up(rows, kPdStageK);
+    MatrixView mv{m->data + row0 * m->pitch, m->bits ? m->bits + row0 * m->bits_pitch : nullptr, m->pitch, m->bits_pitch, m->columns, m->nvec};
+    // samples per planes workgroup: the tile's raw bytes (128 sites x sb x ploidy) stay within 64 KiB of LDS
+    uint32_t sb = kPdBlock;
+    while ((size_t)sb * m->ploidy > 512 && sb > 4) sb /= 2;
+    const size_t planes_smem = (size_t)kPdStageK * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
+    if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute((const void*)pd_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
+    hipLaunchKernelGGL(pd_planes_kernel, dim3((unsigned)(s_pad / kPdStageK), (unsigned)(n_pad / sb)), dim3(256), planes_smem, st, mv,
+                       rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, n_planes, sb, planes, n_pad, s_pad);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    // persistent grid: 3 workgroups per CU, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
+    // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
+    static const int cus = [&] { hipDeviceProp_t prop; return hipGetDeviceProperties(&prop, m->device) == hipSuccess ? prop.multiProcessorCount : 256; }();
+    const unsigned grid = (unsigned)std::max(8, cus * 3 / 8 * 8);
+    const size_t slots = grid / 8;
+    size_t j = env_chunk ? std::max<size_t>(1, (s_pad + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
+    const size_t k_cap = (((size_t)1 << 31) - 1) / (m->ploidy * m->ploidy) / kPdStageK * kPdStageK;
+    size_t k_chunk = round_up((s_pad + 8 * j - 1) / (8 * j), kPdStageK);
+    const size_t k_floor = std::min<size_t>(s_pad, 4096);  // at least 32 stages per item unless the slab is shorter
+    if (k_chunk < k_floor) k_chunk = k_floor;
+    if (k_chunk > k_cap) k_chunk = k_cap;
+    j = ((s_pad + k_chunk - 1) / k_chunk + 7) / 8;
+    auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst) {
+      hipLaunchKernelGGL(pd_gram_mfma_kernel, dim3(grid), dim3(256), 0, st, planes, n_pad, s_pad, plane_begin, plane_count, k_chunk,
+                         (uint32_t)j, (uint32_t)n_samples, negate, dst);
+      return hipGetLastError();
+    };
+    // diff = sum len_i len_j - sum_a cnt_i(a) cnt_j(a)
+    if ((e = gram(0, n_alleles, 1, d_diff)) != hipSuccess) break;
+    if (missing) {
+      if ((e = gram(n_alleles, 1, 0, d_diff)) != hipSuccess) break;
+      if ((e = gram(n_alleles + 1, 1, 0, d_both)) != hipSuccess) break;
+    }
+  }
+  if (e == hipSuccess && !missing) {
+    const size_t total = n_samples * n_samples;
+    hipLaunchKernelGGL(pd_constant_terms_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_diff, d_both, (uint32_t)n_samples,
+                       (unsigned long long)m->variants * m->ploidy * m->ploidy, (unsigned long long)m->variants);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(planes);
   if (e != hipSuccess) return fail(FMH_ERR_HIP, "pairwise differences failed: %s", hipGetErrorString(e));
+  return FMH_OK;
+}
+
+extern "C" int fmh_device_release_scratch(int device) {
+  FMH_TRY(use_device(device));
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(device, &w));
+  std::lock_guard<std::mutex> busy(w->in_use);
+  if (w->pd_planes) (void)hipFree(w->pd_planes);
+  w->pd_planes = nullptr;
+  w->pd_planes_bytes = 0;
   return FMH_OK;
 }
 

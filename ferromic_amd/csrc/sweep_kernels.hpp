@@ -1080,122 +1080,236 @@ __global__ void max_allele_kernel(const uint8_t* __restrict__ data, size_t pitch
 //   diff(i, j) = sum over sites where both genotypes are Some of  len_i*len_j - sum_a cnt_i(a)*cnt_j(a)
 //   both(i, j) = number of sites where both genotypes are Some
 // Step 1 turns the site-major matrix into sample-major int8 planes (K = sites contiguous); step 2 is a
-// tiled Gram product on v_dot4_u32_u8 with split-K and exact integer atomics.
+// tiled Gram product on the int8 matrix cores (v_mfma_i32_32x32x32_i8) with split-K and exact integer atomics.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPdTile = 64;
+constexpr int kPdBlock = 128;   // samples per Gram workgroup tile edge
+constexpr int kPdStageK = 128;  // K bytes (sites) per Gram stage
 
-// planes[p][sample][s_pad]: p = 0..A allele counts, A+1 = genotype length, A+2 = valid (length > 0)
+// planes[p][site / 128][sample][site % 128]: p = 0..A-1 allele counts, then (only when calls can be missing)
+// p = A genotype length and p = A+1 valid (length > 0).  K-blocked so that one Gram stage (128 samples x 128 K
+// bytes) is one contiguous 16 KiB run.
+// Workgroup = one K block (128 sites) x SB samples: the raw genotype bytes (and called bits) of the tile are staged
+// in LDS with coalesced row reads, then every thread turns (sample, 16 consecutive sites) into one 16-byte store
+// per plane; a sample's 128 bytes and the SB samples of the tile are contiguous in the output.
 __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, size_t row_count, uint32_t samples,
-                                                        uint32_t ploidy, int n_alleles, uint8_t* __restrict__ planes,
-                                                        size_t n_pad, size_t s_pad) {
-  __shared__ uint8_t tile[kPdTile][kPdTile + 4];  // [sample][site]
-  const size_t site0 = (size_t)blockIdx.x * kPdTile;
-  const uint32_t samp0 = blockIdx.y * kPdTile;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-  const int n_planes = n_alleles + 2;
-  for (int p = 0; p < n_planes; ++p) {
-    for (int r = ty; r < kPdTile; r += 4) {  // r = site in tile, tx = sample in tile (coalesced along samples)
-      const size_t site = site0 + r;
-      const uint32_t smp = samp0 + tx;
-      uint8_t v = 0;
-      if (site < row_count && smp < samples) {
-        const uint8_t* row = mv.data + site * mv.pitch;
-        uint32_t len = 0;
-        uint32_t cnt = 0;
-        bool open = true;
-        for (uint32_t k = 0; k < ploidy; ++k) {
-          const uint32_t h = smp * ploidy + k;
-          bool called = true;
-          if (mv.bits) called = ((mv.bits[site * mv.bits_pitch + (h >> 3)] >> (h & 7)) & 1u) != 0;
-          open = open && called;  // CompressedGenotypes::get stops at the first missing allele
-          if (open) { ++len; if (p < n_alleles && row[h] == (uint8_t)p) ++cnt; }
-        }
-        v = p < n_alleles ? (uint8_t)cnt : (p == n_alleles ? (uint8_t)len : (uint8_t)(len > 0));
+                                                        uint32_t ploidy, int n_alleles, int n_planes, uint32_t sb,
+                                                        uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
+  extern __shared__ __align__(16) unsigned char pd_smem[];
+  const uint32_t rowb = sb * ploidy;           // genotype bytes per site in the tile (multiple of 4)
+  const uint32_t bitb = (rowb + 7) / 8 + 1;    // called-bit bytes per site in the tile (+1: unaligned start)
+  uint8_t* raw = pd_smem;                      // [128][rowb]
+  uint8_t* cbits = pd_smem + (size_t)kPdStageK * rowb;  // [128][bitb]
+  const size_t kb = blockIdx.x, site0 = kb * kPdStageK;
+  const uint32_t samp0 = blockIdx.y * sb;
+  const size_t col0 = (size_t)samp0 * ploidy;  // first column of the tile (multiple of 4)
+  if ((rowb & 15) == 0 && (col0 & 15) == 0) {
+    // 16-byte row pieces, eight loads in flight per thread before the first LDS store
+    const uint32_t vecs = rowb / 16, total = (uint32_t)kPdStageK * vecs;
+    for (uint32_t base = 0; base < total; base += 256 * 8) {
+      uint4 tmp[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t w = base + q * 256 + threadIdx.x;
+        const uint32_t r = w / vecs, c = (w - r * vecs) * 16;
+        tmp[q] = make_uint4(0, 0, 0, 0);
+        if (w < total && site0 + r < row_count && col0 + c + 16 <= mv.pitch) tmp[q] = load_vec(mv.data + (site0 + r) * mv.pitch + col0 + c);
       }
-      tile[tx][r] = v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t w = base + q * 256 + threadIdx.x;
+        const uint32_t r = w / vecs, c = (w - r * vecs) * 16;
+        if (w < total) *reinterpret_cast<uint4*>(raw + (size_t)r * rowb + c) = tmp[q];
+      }
     }
-    __syncthreads();
-    for (int r = ty; r < kPdTile; r += 4) {  // r = sample in tile, tx = site in tile (coalesced along sites)
-      planes[((size_t)p * n_pad + samp0 + r) * s_pad + site0 + tx] = tile[r][tx];
+  } else {
+    const uint32_t words = rowb / 4;
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * words; w += 256) {
+      const uint32_t r = w / words, c = (w - r * words) * 4;
+      uint32_t v = 0;
+      if (site0 + r < row_count && col0 + c + 4 <= mv.pitch) v = *reinterpret_cast<const uint32_t*>(mv.data + (site0 + r) * mv.pitch + col0 + c);
+      *reinterpret_cast<uint32_t*>(raw + (size_t)r * rowb + c) = v;
     }
-    __syncthreads();
+  }
+  const uint32_t bit0 = (uint32_t)(col0 & 7);
+  if (mv.bits) {
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * bitb; w += 256) {
+      const uint32_t r = w / bitb, c = w - r * bitb;
+      uint8_t v = 0;
+      if (site0 + r < row_count && (col0 >> 3) + c < mv.bits_pitch) v = mv.bits[(site0 + r) * mv.bits_pitch + (col0 >> 3) + c];
+      cbits[(size_t)r * bitb + c] = v;
+    }
+  }
+  __syncthreads();
+  const size_t k_blocks = s_pad / kPdStageK;
+  const bool diploid_complete = ploidy == 2 && !mv.bits;  // the common case: one 16-bit LDS read per genotype, no loops
+  for (int p = 0; p < n_planes; ++p) {
+    for (uint32_t v = threadIdx.x; v < sb * 8; v += 256) {
+      const uint32_t s = v % sb, chunk = v / sb;
+      const uint32_t smp = samp0 + s;
+      uint32_t out[4] = {0, 0, 0, 0};
+      if (diploid_complete) {
+        if (smp < samples) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t r = chunk * 16 + i;
+            const uint32_t g = *reinterpret_cast<const uint16_t*>(raw + (size_t)r * rowb + s * 2);
+            uint32_t val = ((g & 0xFFu) == (uint32_t)p ? 1u : 0u) + ((g >> 8) == (uint32_t)p ? 1u : 0u);
+            if (site0 + r >= row_count) val = 0;
+            out[i >> 2] |= val << (8 * (i & 3));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t r = chunk * 16 + i;
+          // genotype length: CompressedGenotypes::get stops at the first missing allele (process.rs:479-496)
+          uint32_t len = 0;
+          if (smp < samples && site0 + r < row_count) {
+            if (mv.bits) {
+              for (uint32_t k = 0; k < ploidy; ++k) {
+                const uint32_t h = bit0 + s * ploidy + k;
+                if (((cbits[(size_t)r * bitb + (h >> 3)] >> (h & 7)) & 1u) == 0) break;
+                ++len;
+              }
+            } else {
+              len = ploidy;
+            }
+          }
+          uint32_t val;
+          if (p < n_alleles) {
+            val = 0;
+            const uint8_t* g = raw + (size_t)r * rowb + s * ploidy;
+            for (uint32_t k = 0; k < len; ++k) val += g[k] == (uint8_t)p ? 1u : 0u;
+          } else {
+            val = p == n_alleles ? len : (len > 0 ? 1u : 0u);
+          }
+          out[i >> 2] |= val << (8 * (i & 3));
+        }
+      }
+      // 16-byte chunk positions are XOR-swizzled by (sample >> 1) & 7 for the Gram kernel's unpadded LDS image
+      *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void pd_gram_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad,
-                                                      int n_alleles, size_t k_chunk, uint32_t n_samples,
-                                                      unsigned long long* __restrict__ diff,
-                                                      unsigned long long* __restrict__ both) {
-  // upper-triangular tile index -> (bi, bj), bi <= bj
-  const uint32_t nt = (uint32_t)(n_pad / kPdTile);
-  uint32_t t = blockIdx.x, bi = 0;
-  while (t >= nt - bi) { t -= nt - bi; ++bi; }
+// Gram product of sample-major int8 planes on the matrix cores:
+//   out(i, j) += sign * sum_{p in [plane_begin, plane_begin + plane_count)} sum_{k in chunk} planes[p][i][k] * planes[p][j][k]
+// v_mfma_i32_32x32x32_i8: each lane feeds 16 consecutive K bytes of one row of A and of one row of B.  A and B
+// fragments are cut from LDS images with the SAME (row, k) -> lane rule, so whatever order the instruction walks
+// K inside a step, both operands agree and the sum over K is the plain dot product.  C/D: column = lane & 31
+// (B row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (A row).
+// Workgroup = 4 waves = 128 x 128 samples (2 x 2 waves of 64 x 64, each 2 x 2 MFMA tiles); K advances 128 bytes per
+// stage; the next stage's global loads are issued before the current stage's MFMAs (register prefetch).
+typedef int pd_v4i __attribute__((ext_vector_type(4)));
+typedef int pd_v16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void pd_gram_mfma_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad,
+                                                           int plane_begin, int plane_count, size_t k_chunk,
+                                                           uint32_t slices_per_xcd, uint32_t n_samples, int negate,
+                                                           unsigned long long* __restrict__ out) {
+  // Persistent and XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so the group blockIdx.x & 7 shares one L2.
+  // Each XCD owns `slices_per_xcd` K slices; its workgroups take (slice, tile pair) items tile-fastest, so at any moment
+  // they are walking the same K range over different tile pairs and every stage tile fetched from HBM by one of them
+  // is an L2 hit for the ~2 * n_tiles others that need it.
+  const uint32_t nt = (uint32_t)(n_pad / kPdBlock);
+  const uint32_t tiles = nt * (nt + 1) / 2;
+  const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  // LDS images are byte-for-byte copies of the 16 KiB stage tiles (global_load_lds writes wave-linear), whose 16-byte
+  // chunks the planes kernel stored XOR-swizzled by (row >> 1) & 7: 16 consecutive rows of one K chunk then sit in 16
+  // different 16-byte slots of the 256-byte bank row, so the fragment reads are conflict-free without padding.
+  __shared__ __align__(16) uint8_t sa[kPdBlock * kPdStageK];
+  __shared__ __align__(16) uint8_t sb[kPdBlock * kPdStageK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
+  uint32_t t = item % tiles, bi = 0;
+  while (t >= nt - bi) { t -= nt - bi; ++bi; }  // upper-triangular tile index -> (bi, bj), bi <= bj
   const uint32_t bj = bi + t;
-  __shared__ __align__(16) uint8_t sa[kPdTile][kPdTile + 16];
-  __shared__ __align__(16) uint8_t sb[kPdTile][kPdTile + 16];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
-  int32_t acc_d[4][4], acc_v[4][4];
+  const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
+  if (k0 >= s_pad) continue;  // uniform for the workgroup
+  pd_v16i acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { acc_d[a][b] = 0; acc_v[a][b] = 0; }
-  const size_t k0 = (size_t)blockIdx.y * k_chunk;
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
   const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
-  const int n_planes = n_alleles + 2;
-  for (size_t k = k0; k < k1; k += kPdTile) {
-    for (int p = 0; p < n_planes; ++p) {
-      // stage 64 rows x 64 bytes of both operands (one uint4 per thread per operand)
-      {
-        const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) * 16;
-        *reinterpret_cast<uint4*>(&sa[r][c]) = *reinterpret_cast<const uint4*>(planes + ((size_t)p * n_pad + (size_t)bi * kPdTile + r) * s_pad + k + c);
-        *reinterpret_cast<uint4*>(&sb[r][c]) = *reinterpret_cast<const uint4*>(planes + ((size_t)p * n_pad + (size_t)bj * kPdTile + r) * s_pad + k + c);
-      }
-      __syncthreads();
-      uint32_t part[4][4];
+  const size_t stages_per_plane = (k1 - k0) / kPdStageK;  // k_chunk and s_pad are multiples of kPdStageK
+  const size_t n_stages = stages_per_plane * (size_t)plane_count;
+  const size_t k_blocks = s_pad / kPdStageK;
+  const size_t kb0 = k0 / kPdStageK;
+  const size_t tile_stride = n_pad * kPdStageK;  // bytes between consecutive K blocks of one plane
+  const uint8_t* pa = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bi * kPdBlock) * kPdStageK + (size_t)threadIdx.x * 16;
+  const uint8_t* pb = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bj * kPdBlock) * kPdStageK + (size_t)threadIdx.x * 16;
+  const size_t plane_skip = (k_blocks - stages_per_plane) * tile_stride;  // from the end of one plane's slice to the next plane's
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // wave-uniform LDS bases of this wave's four 1 KiB pieces per operand (piece q covers chunks q*256 + wave*64 ..)
+  uint8_t* la = sa + (size_t)wave * 1024;
+  uint8_t* lb = sb + (size_t)wave * 1024;
+  // fragment addresses: row r, logical K chunk 2*ks + (lane >> 5), physical chunk = logical ^ ((r >> 1) & 7)
+  uint32_t offa[2], offb[2], swza[2], swzb[2];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+  for (int m = 0; m < 2; ++m) { const uint32_t r = wr * 64 + m * 32 + (lane & 31); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) part[a][b] = 0;
+  for (int n = 0; n < 2; ++n) { const uint32_t r = wc * 64 + n * 32 + (lane & 31); offb[n] = r * kPdStageK; swzb[n] = (r >> 1) & 7; }
+  size_t in_plane = 0;
+  for (size_t stage = 0; stage < n_stages; ++stage) {
+    if (in_plane == stages_per_plane) { pa += plane_skip; pb += plane_skip; in_plane = 0; }
+    ++in_plane;
+    __builtin_amdgcn_global_load_lds((gptr_t)(pa), (lptr_t)(la), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pa + 4096), (lptr_t)(la + 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pa + 8192), (lptr_t)(la + 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pa + 12288), (lptr_t)(la + 12288), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pb), (lptr_t)(lb), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pb + 4096), (lptr_t)(lb + 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pb + 8192), (lptr_t)(lb + 8192), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(pb + 12288), (lptr_t)(lb + 12288), 16, 0, 0);
+    pa += tile_stride;
+    pb += tile_stride;
+    __syncthreads();  // waits for this wave's loads (vmcnt(0)) and for everybody else's
 #pragma unroll
-      for (int c = 0; c < kPdTile; c += 16) {
-        uint4 va[4], vb[4];
+    for (int ks = 0; ks < kPdStageK / 32; ++ks) {
+      const uint32_t cl = (uint32_t)(ks * 2 + (lane >> 5));
+      pd_v4i fa[2], fb[2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) va[a] = *reinterpret_cast<const uint4*>(&sa[ty * 4 + a][c]);
+      for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&sa[offa[m] + ((cl ^ swza[m]) << 4)]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) vb[b] = *reinterpret_cast<const uint4*>(&sb[tx * 4 + b][c]);
+      for (int n = 0; n < 2; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&sb[offb[n] + ((cl ^ swzb[n]) << 4)]);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            uint32_t x = part[a][b];
-            x = dot4(va[a].x, vb[b].x, x); x = dot4(va[a].y, vb[b].y, x);
-            x = dot4(va[a].z, vb[b].z, x); x = dot4(va[a].w, vb[b].w, x);
-            part[a][b] = x;
-          }
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (p < n_alleles) acc_d[a][b] -= (int32_t)part[a][b];
-          else if (p == n_alleles) acc_d[a][b] += (int32_t)part[a][b];
-          else acc_v[a][b] += (int32_t)part[a][b];
-        }
-      __syncthreads();
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
     }
+    __syncthreads();
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const uint32_t i = bi * kPdTile + ty * 4 + a, j = bj * kPdTile + tx * 4 + b;
-      if (i < j && j < n_samples) {
-        // within one K chunk the per-site contributions sum to a non-negative value only over the whole
-        // range, so add as two's-complement 64-bit (exact, order-independent)
-        atomicAdd(&diff[(size_t)i * n_samples + j], (unsigned long long)(long long)acc_d[a][b]);
-        atomicAdd(&both[(size_t)i * n_samples + j], (unsigned long long)acc_v[a][b]);
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t i = bi * kPdBlock + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const uint32_t j = bj * kPdBlock + wc * 64 + n * 32 + (lane & 31);
+        if (i < j && j < n_samples) {
+          const long long v = acc[m][n][r];
+          if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));  // exact, order-independent
+        }
       }
-    }
+  }  // items
+}
+
+// Without missing data every genotype has `ploidy` alleles: sum over sites of len_i * len_j = rows * ploidy^2 and every
+// site counts for every pair, so those two Gram products collapse into constants.
+__global__ void pd_constant_terms_kernel(unsigned long long* __restrict__ diff, unsigned long long* __restrict__ both,
+                                         uint32_t n_samples, unsigned long long add_diff, unsigned long long add_both) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_samples * n_samples;
+  if (idx >= total) return;
+  const uint32_t i = (uint32_t)(idx / n_samples), j = (uint32_t)(idx % n_samples);
+  if (i < j) { diff[idx] += add_diff; both[idx] += add_both; }
 }
 
 }  // namespace fmh

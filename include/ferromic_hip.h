@@ -71,6 +71,9 @@ int fmh_device_free(int device, void* d_ptr);
 int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
 int fmh_copy_to_device(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
 int fmh_stream_synchronize(int device, void* stream);
+/* Frees the scratch the library keeps between calls on `device` (the sample-major planes of
+ * fmh_pairwise_differences, up to 8 GiB); it is re-created on demand. */
+int fmh_device_release_scratch(int device);
 
 /* ---- genotype matrix (replaces DenseGenotypeMatrix::new, stats.rs:261-296) ------------------- */
 /*

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Development measurement: pairwise-differences Gram throughput (fmh_pairwise_differences) on random biallelic data."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ferromic_amd import device  # noqa: E402
+
+
+def main():
+    cases = [(int(a), int(b)) for a, b in (x.split("x") for x in sys.argv[1:])] or [(200_000, 500), (1_000_000, 2500)]
+    rng = np.random.default_rng(5)
+    for S, N in cases:
+        data = rng.integers(0, 2, size=(S, 2 * N), dtype=np.uint8)
+        dm = device.DeviceMatrix.from_host(data, None, S, N, 2, 1)
+        device.pairwise_differences(dm, N)
+        t0 = time.perf_counter()
+        device.pairwise_differences(dm, N)
+        dt = time.perf_counter() - t0
+        n_pad = -(-N // 128) * 128
+        tiles = (n_pad // 128) * (n_pad // 128 + 1) // 2
+        macs = tiles * 128 * 128 * S * 2  # two allele-count planes; length/valid terms are constants without missing data
+        print(json.dumps({"case": f"pairwise {S}x{N}", "seconds": dt, "sample_pair_sites_per_s": N * (N - 1) / 2 * S / dt,
+                          "mfma_TMAC_per_s": macs / dt / 1e12}), flush=True)
+        dm.close()
+
+
+if __name__ == "__main__":
+    main()
