@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): the measurements and rocprofv3 passes whose summaries are kept under profiles/.
+# Usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>/)
+set -eo pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-r01}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd /tmp
+export TMPDIR=/tmp
+echo "[1/8] bench.py (C4)"; python3 $R/bench.py --steps 20 --warmup 3 > $O/c4_bench.json
+echo "[2/8] kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -o c4 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/c4_bench_under_rocprof.json 2> $O/c4_trace.log
+python3 $R/tools/summarize_rocprof.py trace $O/c4_trace $O/c4_kernel_stats.csv
+echo "[3/8] pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_fetch.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch $O/c4_pmc_fetch_summary.csv
+echo "[4/8] pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_write $O/c4_pmc_write_summary.csv
+echo "[5/8] other configs"; python3 $R/tools/measure_configs.py C2 C3 C4m C5 C3h 2>/dev/null | grep '^{' > $O/other_configs.jsonl
+echo "[6/8] multi-allelic path"; python3 $R/tools/measure_general.py 2>/dev/null | grep '^{' | grep hudson > $O/general_path.jsonl
+echo "[7/8] pairwise"; python3 $R/tools/measure_pairwise.py 1000000x2500 200000x500 2>/dev/null | grep '^{' > $O/pairwise.jsonl
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pd_trace -o pd -- python3 $R/tools/measure_pairwise.py 1000000x2500 > /dev/null 2> $O/pd_trace.log
+python3 $R/tools/summarize_rocprof.py trace $O/pd_trace $O/pairwise_kernel_stats.csv
+echo "[8/8] run_vcf at reduced C4 scale"; python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 2>/dev/null | tail -1 > $O/run_vcf_scale_200k_x_2500.json
+rm -rf $O/c4_trace $O/c4_pmc_fetch $O/c4_pmc_write $O/pd_trace
+ls -la $O
