@@ -24,6 +24,7 @@ FORMULA_DENSE = 1
 FORMULA_SUMMARY = 2
 
 MAX_GROUPS = 8
+MAX_GROUPS_MANY = 256
 MAX_PAIRS = 28
 HUDSON_PACK_F64 = 10
 HUDSON_PACK_U64 = 10
@@ -124,6 +125,7 @@ SYMBOLS = {
     "fmh_hudson_sweep": (_i, [_vp, _vp, _sz, _sz, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_diversity_sites": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(PopTotals), _vp]),
     "fmh_wc_sweep": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(WcTotals), _vp]),
+    "fmh_wc_sweep_many": (_i, [_vp, _vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fmh_pairwise_differences": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "fmh_hudson_totals_pack": (_i, [_P(HudsonTotals), _P(_d), _P(_u64)]),
     "fmh_hudson_totals_unpack": (_i, [_P(HudsonTotals), _P(_d), _P(_u64)]),

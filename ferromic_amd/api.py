@@ -1152,8 +1152,6 @@ def wc_fst(variants, sample_names, sample_to_group, region) -> WcFstResult:
         return WcFstResult(_insufficient(0), {}, {}, [], "haplotype_groups")  # stats.rs:2152-2159
     sub = store.subset(rows)
     _, N, P = sub.shape
-    if G > dev._abi.MAX_GROUPS:
-        raise ValueError(f"wc_fst supports at most {dev._abi.MAX_GROUPS} haplotype groups on the device")
     masks = np.zeros((max(G, 1), N * P), dtype=np.uint8)
     label_idx = {lab: i for i, lab in enumerate(labels)}
     for (sample_idx, side), lab in hap_to_group.items():
@@ -1178,7 +1176,8 @@ def wc_fst(variants, sample_names, sample_to_group, region) -> WcFstResult:
         n_inf = sum(1 for s in site_objs if s.overall_fst.state != "insufficient_data_for_estimation")
         overall = _insufficient(len(site_objs)) if n_inf == 0 else _classify(0.0, 0.0, n_inf)
         return WcFstResult(overall, {}, {}, site_objs, "haplotype_groups")
-    w = dev.wc_sweep(dm, dev.Groups(dm, masks))
+    # up to 8 groups: the fused sweep; more: counting sweeps in batches of 8 + the counts kernel (same per-site bits)
+    w = dev.wc_sweep(dm, dev.Groups(dm, masks)) if G <= dev._abi.MAX_GROUPS else dev.wc_sweep_many(dm, masks)
     states = dev.WC_STATES
     site_objs = []
     for i in range(sub.count):

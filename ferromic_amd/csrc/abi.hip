@@ -741,6 +741,95 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   return FMH_OK;
 }
 
+// RAII for the scratch of one call
+struct DeviceScratch {
+  std::vector<void*> ptrs;
+  ~DeviceScratch() { for (void* p : ptrs) (void)hipFree(p); }
+  template <class T> int get(T** out, size_t count) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    ptrs.push_back(p);
+    *out = (T*)p;
+    return FMH_OK;
+  }
+};
+
+extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_mask, int n_groups, size_t row_begin,
+                                 size_t row_count, double* d_a, double* d_b, uint8_t* d_state, uint32_t* d_group_called,
+                                 double* h_sum_a, double* h_sum_b, uint64_t* h_informative_sites, void* stream) {
+  if (!m || !h_column_mask) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n_groups < 2 || n_groups > FMH_MAX_GROUPS_MANY) return fail(FMH_ERR_INVALID, "n_groups %d out of range 2..%d", n_groups, FMH_MAX_GROUPS_MANY);
+  if (row_begin > m->variants || row_count > m->variants - row_begin)
+    return fail(FMH_ERR_INVALID, "row range [%zu, +%zu) exceeds %zu variants", row_begin, row_count, m->variants);
+  FMH_TRY(use_device(m->device));
+  const size_t G = (size_t)n_groups, nslots = 1 + G * (G - 1) / 2;
+  if (h_sum_a) for (size_t k = 0; k < nslots; ++k) h_sum_a[k] = 0.0;
+  if (h_sum_b) for (size_t k = 0; k < nslots; ++k) h_sum_b[k] = 0.0;
+  if (h_informative_sites) for (size_t k = 0; k < nslots; ++k) h_informative_sites[k] = 0;
+  if (row_count == 0) return FMH_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool general = m->max_allele > 1;
+  const int n_alleles = (int)m->max_allele + 1;
+  DeviceScratch scratch;
+  uint32_t *called = d_group_called, *alt = nullptr, *acounts = nullptr, *n_all = nullptr, *all_alt = nullptr;
+  if (!called) FMH_TRY(scratch.get(&called, G * row_count));
+  FMH_TRY(scratch.get(&n_all, row_count));
+  if (general) {
+    FMH_TRY(scratch.get(&acounts, (size_t)n_alleles * G * row_count));
+    HIP_TRY(hipMemsetAsync(acounts, 0, (size_t)n_alleles * G * row_count * sizeof(uint32_t), st));
+  } else {
+    FMH_TRY(scratch.get(&alt, G * row_count));
+  }
+  if (!d_a) FMH_TRY(scratch.get(&d_a, nslots * row_count));
+  if (!d_b) FMH_TRY(scratch.get(&d_b, nslots * row_count));
+  if (!d_state) FMH_TRY(scratch.get(&d_state, nslots * row_count));
+  // (1) called entries over ALL columns: pop_sizes_populated (stats.rs:1987)
+  {
+    std::vector<uint8_t> ones(m->columns, 1);
+    fmh_groups* g = nullptr;
+    FMH_TRY(fmh_groups_create(m, ones.data(), 1, &g));
+    SweepArgs a{};
+    a.row_begin = row_begin; a.row_count = row_count; a.formula = FMH_FORMULA_SPARSE; a.called = n_all;
+    SweepResult r;
+    const int rc = run_sweep(m, g, kModeSummary, a, stream, &r);
+    fmh_groups_destroy(g);
+    FMH_TRY(rc);
+  }
+  (void)all_alt;
+  // (2) counts of every group, eight groups per sweep
+  for (size_t g0 = 0; g0 < G; g0 += FMH_MAX_GROUPS) {
+    const int cnt = (int)std::min<size_t>(FMH_MAX_GROUPS, G - g0);
+    fmh_groups* g = nullptr;
+    FMH_TRY(fmh_groups_create(m, h_column_mask + g0 * m->columns, cnt, &g));
+    SweepArgs a{};
+    a.row_begin = row_begin; a.row_count = row_count; a.formula = FMH_FORMULA_SPARSE;
+    a.called = called + g0 * row_count;
+    if (alt) a.alt = alt + g0 * row_count;
+    a.acounts = acounts; a.acounts_groups = (uint32_t)G; a.acounts_group0 = (uint32_t)g0;
+    SweepResult r;
+    const int rc = run_sweep(m, g, kModeSummary, a, stream, &r);
+    fmh_groups_destroy(g);
+    FMH_TRY(rc);
+  }
+  // (3) per-site components from the count tables, (4) regional sums per slot
+  hipLaunchKernelGGL(wc_from_counts_kernel, dim3((unsigned)((row_count + 255) / 256)), dim3(256), 0, st, n_groups, n_alleles, row_count,
+                     (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, d_a, d_b, d_state);
+  HIP_TRY(hipGetLastError());
+  double *sa = nullptr, *sb = nullptr;
+  unsigned long long* si = nullptr;
+  FMH_TRY(scratch.get(&sa, nslots));
+  FMH_TRY(scratch.get(&sb, nslots));
+  FMH_TRY(scratch.get(&si, nslots));
+  hipLaunchKernelGGL(wc_slot_reduce_kernel, dim3((unsigned)nslots), dim3(256), 0, st, row_count, (const double*)d_a, (const double*)d_b,
+                     (const uint8_t*)d_state, sa, sb, si);
+  HIP_TRY(hipGetLastError());
+  if (h_sum_a) HIP_TRY(hipMemcpyAsync(h_sum_a, sa, nslots * 8, hipMemcpyDeviceToHost, st));
+  if (h_sum_b) HIP_TRY(hipMemcpyAsync(h_sum_b, sb, nslots * 8, hipMemcpyDeviceToHost, st));
+  if (h_informative_sites) HIP_TRY(hipMemcpyAsync(h_informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return FMH_OK;
+}
+
 extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
                                         unsigned long long* d_both, void* stream) {
   if (!m || !d_diff || !d_both) return fail(FMH_ERR_INVALID, "NULL argument");

@@ -1148,7 +1148,7 @@ vector<vector<string>> wc_csv_population_rows(const vector<const Variant*>& vs, 
   if (vs.empty()) { rows.push_back(row("overall", "ALL", "ALL", insufficient)); return rows; }  // sites_attempted 0, no pair keys
   const DeviceMatrix& dm = *rm.dm;
   const size_t S = dm.variants, P = dm.ploidy;
-  if (G > FMH_MAX_GROUPS) throw Error("--fst_populations: more than 8 populations present in the VCF are not supported on the device yet");
+  if (G > FMH_MAX_GROUPS_MANY) throw Error("--fst_populations: more than 256 populations");
   if (G < 2) {
     Groups all(dm, {vector<uint8_t>(N * P, 1)});
     DevBuf dcalled(device, 4 * S);
@@ -1166,9 +1166,22 @@ vector<vector<string>> wc_csv_population_rows(const vector<const Variant*>& vs, 
     const size_t gi = std::find(labels.begin(), labels.end(), kv.second) - labels.begin();
     for (size_t k = 0; k < std::min<size_t>(P, 2); ++k) if (kv.first < N) masks[gi][kv.first * P + k] = 1;
   }
-  Groups grp(dm, masks);
-  fmh_wc_totals tot;
-  fmh_check(fmh_wc_sweep(dm.h, grp.h, 0, S, nullptr, nullptr, nullptr, nullptr, &tot, nullptr), "wc sweep");
+  // totals per slot (0 = overall, then pairs in label order): the fused sweep up to 8 populations, beyond that the
+  // counting sweeps in batches of 8 + the counts kernel (fmh_wc_sweep_many)
+  struct { vector<double> sum_a, sum_b; vector<uint64_t> informative_sites; } tot;
+  const size_t nslots = 1 + G * (G - 1) / 2;
+  tot.sum_a.assign(nslots, 0.0); tot.sum_b.assign(nslots, 0.0); tot.informative_sites.assign(nslots, 0);
+  if (G <= FMH_MAX_GROUPS) {
+    Groups grp(dm, masks);
+    fmh_wc_totals t8;
+    fmh_check(fmh_wc_sweep(dm.h, grp.h, 0, S, nullptr, nullptr, nullptr, nullptr, &t8, nullptr), "wc sweep");
+    for (size_t k2 = 0; k2 < nslots; ++k2) { tot.sum_a[k2] = t8.sum_a[k2]; tot.sum_b[k2] = t8.sum_b[k2]; tot.informative_sites[k2] = t8.informative_sites[k2]; }
+  } else {
+    vector<uint8_t> flat;
+    for (auto& m2 : masks) flat.insert(flat.end(), m2.begin(), m2.end());
+    fmh_check(fmh_wc_sweep_many(dm.h, flat.data(), (int)G, 0, S, nullptr, nullptr, nullptr, nullptr, tot.sum_a.data(), tot.sum_b.data(),
+                                tot.informative_sites.data(), nullptr), "wc sweep (many groups)");
+  }
   WcEstimate overall;
   if (tot.informative_sites[0] == 0) overall.sites = S; else overall = wc_estimate(tot.sum_a[0], tot.sum_b[0], (size_t)tot.informative_sites[0]);
   rows.push_back(row("overall", "ALL", "ALL", overall));

@@ -283,6 +283,25 @@ def wc_sweep(m: DeviceMatrix, g: Groups, row_begin: int = 0, row_count: Optional
                     d_n.to_numpy(np.uint32, P * rows).reshape(P, rows))
 
 
+def wc_sweep_many(m: DeviceMatrix, masks: np.ndarray, row_begin: int = 0, row_count: Optional[int] = None) -> WcResult:
+    """fmh_wc_sweep_many: W&C for any number of groups (counting in batches of 8, arithmetic from count tables)."""
+    rows = m.variants - row_begin if row_count is None else row_count
+    masks = np.ascontiguousarray(masks, dtype=np.uint8)
+    G = int(masks.shape[0])
+    nw = 1 + G * (G - 1) // 2
+    d_a, d_b = DeviceBuffer(m.device, 8 * nw * rows), DeviceBuffer(m.device, 8 * nw * rows)
+    d_s, d_n = DeviceBuffer(m.device, nw * rows), DeviceBuffer(m.device, 4 * G * rows)
+    sum_a, sum_b = np.zeros(nw, dtype=np.float64), np.zeros(nw, dtype=np.float64)
+    inf = np.zeros(nw, dtype=np.uint64)
+    _abi.check(_abi.load().fmh_wc_sweep_many(m._h, _ptr(masks), G, row_begin, rows, d_a.ptr, d_b.ptr, d_s.ptr, d_n.ptr,
+                                             _ptr(sum_a), _ptr(sum_b), _ptr(inf), None))
+    return WcResult(sum_a, sum_b, inf, int(rows),
+                    d_a.to_numpy(np.float64, nw * rows).reshape(nw, rows),
+                    d_b.to_numpy(np.float64, nw * rows).reshape(nw, rows),
+                    d_s.to_numpy(np.uint8, nw * rows).reshape(nw, rows),
+                    d_n.to_numpy(np.uint32, G * rows).reshape(G, rows))
+
+
 def pairwise_differences(m: DeviceMatrix, n_samples: int):
     """fmh_pairwise_differences -> (diff, both) as [n, n] uint64 arrays (upper triangle filled)."""
     n = int(n_samples)

@@ -223,6 +223,19 @@ int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, siz
                  double* d_a, double* d_b, uint8_t* d_state, uint32_t* d_group_called,
                  fmh_wc_totals* h_totals, void* stream);
 
+/*
+ * The same statistics for ANY number of groups (2 <= n_groups <= FMH_MAX_GROUPS_MANY; labels are u8 in the
+ * reference, so 256 covers every input).  h_column_mask is a HOST array [n_groups][columns] of 0/1 bytes in
+ * sorted-label order.  Counting runs as summary sweeps over batches of 8 groups, the per-site W&C arithmetic
+ * in a counts kernel with the same operand order as fmh_wc_sweep (bit-identical per-site a, b).  Device outputs
+ * are [(1 + n_groups(n_groups-1)/2)][row_count] (a, b, state; any may be NULL) and [n_groups][row_count]
+ * (d_group_called, may be NULL); host outputs h_sum_a / h_sum_b / h_informative_sites have 1 + npairs entries.
+ */
+#define FMH_MAX_GROUPS_MANY 256
+int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_mask, int n_groups, size_t row_begin,
+                      size_t row_count, double* d_a, double* d_b, uint8_t* d_state, uint32_t* d_group_called,
+                      double* h_sum_a, double* h_sum_b, uint64_t* h_informative_sites, void* stream);
+
 /* ---- pairwise differences ------------------------------------------------------------------------- */
 /*
  * Replaces the nested sample-pair loops of calculate_pairwise_differences (stats.rs:4158-4221) for the first

@@ -278,7 +278,8 @@ def _est_equal(got, exp):
     assert H.rel_close(got.sum_a, exp.sum_a) and H.rel_close(got.sum_b, exp.sum_b)
 
 
-@pytest.mark.parametrize("G,max_allele,p_missing", [(2, 1, 0.0), (2, 1, 0.2), (4, 1, 0.05), (3, 3, 0.1), (1, 1, 0.1)])
+@pytest.mark.parametrize("G,max_allele,p_missing", [(2, 1, 0.0), (2, 1, 0.2), (4, 1, 0.05), (3, 3, 0.1), (1, 1, 0.1),
+                                                  (9, 1, 0.0), (11, 1, 0.05), (13, 3, 0.1)])  # > 8 groups: counts path
 def test_wc_fst_api(G, max_allele, p_missing):
     rng = random.Random(G * 100 + max_allele)
     S, N = 90, 24

@@ -271,6 +271,20 @@ def test_csv_defined_populations(tmp_path):
     assert "NamedPopulation\tAFR\tNamedPopulation\tEAS" in hud and "HaplotypeGroup\t0\tHaplotypeGroup\t1" in hud
 
 
+def test_many_csv_populations(tmp_path):
+    """More CSV populations than the fused sweep holds in registers (8): fmh_wc_sweep_many (counting sweeps in
+    batches of 8 + counts kernel) and one Hudson sweep per population pair."""
+    kw, names = make_cohort(tmp_path, seed=41, n_samples=33)
+    pops = {f"P{k:02d}": names[k::11] for k in range(11)}
+    (tmp_path / "pops.csv").write_text("".join(f"{k}," + ",".join(v) + "\n" for k, v in pops.items()))
+    kw.update(enable_fst=True, fst_populations=str(tmp_path / "pops.csv"))
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), **kw)
+    compare(got, exp)
+    wc = got["wc_fst_results.tsv.gz"].splitlines()
+    assert sum(1 for r in wc if "\tpairwise\t" in r) == 55 * 5 and sum(1 for r in wc if "\toverall\tALL\tALL\t" in r) == 5
+
+
 def test_region_workers_match_single_worker(tmp_path):
     """--devices: config regions dealt out to one worker thread per GPU ("whole config regions").
     A one-GPU box can only alias device 0, which still exercises the dynamic work queue, the ordered emit
