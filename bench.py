@@ -37,11 +37,20 @@ def synthetic_thresholds(sites: int, first_site: int, total_sites: int, seed: in
     (src/pybenches/test_population_statistics_benchmarks.py:113-158): base ~ Beta(0.8, 0.8),
     divergence ~ N(0, sigma), clip [0.001, 0.999]; rows 0 and 1 of the cohort forced informative.
     Returned as 24-bit integer thresholds [2][sites] for the counter-based generator."""
-    rng = np.random.default_rng(seed + first_site)
-    base = rng.beta(0.8, 0.8, size=sites)
-    div = rng.normal(0.0, sigma, size=sites)
-    f1 = np.clip(base + div, 0.001, 0.999)
-    f2 = np.clip(base - div, 0.001, 0.999)
+    # a pure function of the GLOBAL site index (blocks of 2^20 sites, one stream per block), so any sharding of the
+    # cohort sees the same frequencies as one GPU holding all of it
+    block = 1 << 20
+    f1 = np.empty(sites, dtype=np.float64)
+    f2 = np.empty(sites, dtype=np.float64)
+    b = first_site // block
+    while b * block < first_site + sites:
+        rng = np.random.default_rng([seed, b])
+        base = rng.beta(0.8, 0.8, size=block)
+        div = rng.normal(0.0, sigma, size=block)
+        lo, hi = max(first_site, b * block), min(first_site + sites, (b + 1) * block)
+        f1[lo - first_site:hi - first_site] = np.clip(base + div, 0.001, 0.999)[lo - b * block:hi - b * block]
+        f2[lo - first_site:hi - first_site] = np.clip(base - div, 0.001, 0.999)[lo - b * block:hi - b * block]
+        b += 1
     thr = np.stack([f1, f2]) * float(1 << 24)
     thr = thr.astype(np.uint32)
     if first_site == 0 and sites > 0:
@@ -89,11 +98,16 @@ def main() -> int:
     ap.add_argument("--haplotypes", type=int, default=5000)
     ap.add_argument("--cpu-sample-sites", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--rehearse-on-one-device", action="store_true",
+                    help="all ranks share cuda:0 (with --backend gloo): exercises the sharded code path on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rehearse_on_one_device:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}",
@@ -112,7 +126,10 @@ def main() -> int:
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from ferromic_amd import _abi, device
 
@@ -208,7 +225,7 @@ def main() -> int:
             "sites_per_gpu": S,
             "haplotypes": H,
             "populations": 2,
-            "parallelism": f"region-sharded x{world} (one slab per GPU, one RCCL all-reduce of 20 accumulators per step)",
+            "parallelism": f"region-sharded x{world} (one slab per GPU, one {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of 20 accumulators per step)",
             "seed": seed,
             "generate_s": gen_s,
         },

@@ -1,0 +1,38 @@
+"""bench.py's N > 1 path rehearsed on one GPU: two ranks (gloo, both on cuda:0) each own a slab of the cohort,
+sweep it and all-reduce the 20 accumulators; the combined totals must equal one rank sweeping both slabs."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_equal_one_rank():
+    S = 300_000
+    common = ["--steps", "2", "--warmup", "1", "--haplotypes", "1000", "--no-cpu-baseline"]
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", "bench.py", "--gpus", "2", "--sites", str(S), "--backend", "gloo", "--rehearse-on-one-device"] + common)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 2
+    assert two["value"] == pytest.approx(2 * S * 2 / (two["ms_per_step"] * 2 / 1e3), rel=1e-6)  # whole-job sites / max-over-ranks time
+    # the same 2 x S sites generated and swept by one rank (same seed recipe: seed = total sites + samples)
+    one = run([sys.executable, "bench.py", "--sites", str(2 * S)] + common)
+    assert one["config"]["seed"] == two["config"]["seed"]
+    assert one["results"]["segregating_sites"] == two["results"]["segregating_sites"]
+    for a, b in zip(one["results"]["pi_sum"], two["results"]["pi_sum"]):
+        assert a == pytest.approx(b, rel=1e-9)
+    assert one["results"]["hudson_fst"] == pytest.approx(two["results"]["hudson_fst"], rel=1e-9)
