@@ -42,8 +42,32 @@ def _extract_u8(obj) -> int:
     return v
 
 
-def _parse_genotypes(genotypes_obj) -> List[Optional[List[int]]]:
-    """parse_genotypes, lib.rs:1301-1332: None | int (haploid) | iterable of ints per sample."""
+def _regular_genotypes(genotypes_obj) -> Optional[np.ndarray]:
+    """Fast path of parse_genotypes for the common shape - every sample a same-length sequence of in-range ints,
+    no None: one numpy conversion instead of a Python loop per allele.  Anything else returns None and takes the
+    literal path (which also raises the literal errors)."""
+    if isinstance(genotypes_obj, np.ndarray):
+        arr = genotypes_obj
+    elif isinstance(genotypes_obj, (list, tuple)) and genotypes_obj and isinstance(genotypes_obj[0], (list, tuple, np.ndarray)):
+        try:
+            arr = np.array(genotypes_obj)
+        except ValueError:  # ragged
+            return None
+    else:
+        return None
+    if arr.ndim != 2 or arr.dtype.kind not in "iu" or arr.shape[1] == 0:
+        return None
+    if arr.size and (int(arr.min()) < 0 or int(arr.max()) > 255):
+        return None
+    return arr.astype(np.uint8, copy=False)
+
+
+def _parse_genotypes(genotypes_obj):
+    """parse_genotypes, lib.rs:1301-1332: None | int (haploid) | iterable of ints per sample.
+    Returns a list of Optional[List[int]], or a uint8 array [samples][ploidy] when every sample is regular."""
+    fast = _regular_genotypes(genotypes_obj)
+    if fast is not None:
+        return fast
     out: List[Optional[List[int]]] = []
     for entry in genotypes_obj:
         if entry is None:
@@ -179,6 +203,9 @@ class _Store:
         self.shape = tuple(data.shape) if data is not None else shape
         self.num_samples = num_samples        # int64 [S]: genotypes.len() of every variant
         self._device: Dict[int, dev.DeviceMatrix] = {}
+        self.twin: Optional["_Dense"] = None  # dense matrix whose device image equals this store's (from_numpy, nothing missing)
+        self._root: Optional["_Store"] = None  # contiguous row view of another store: its rows live in the root's device matrix
+        self._row0 = 0
 
     def _materialise(self):
         if self._data is None:
@@ -210,12 +237,24 @@ class _Store:
         N = max((len(g) for _, g in parsed), default=0)
         P = 1
         for _, g in parsed:
+            if isinstance(g, np.ndarray):
+                P = max(P, g.shape[1])
+                continue
             for gt in g:
                 if gt is not None:
                     P = max(P, len(gt))
         data = np.zeros((S, max(N, 1), P), dtype=np.uint8)
         called = np.zeros((S, max(N, 1), P), dtype=bool)
         for s, (_, g) in enumerate(parsed):
+            if isinstance(g, np.ndarray):  # regular block: every sample has g.shape[1] alleles
+                n, k = g.shape
+                ok = g != 0xFF
+                if not ok.all():  # 0xFF is the missing sentinel: leading -> None, later -> truncation
+                    ok = np.logical_and.accumulate(ok, axis=1)
+                    g = np.where(ok, g, 0)
+                data[s, :n, :k] = g
+                called[s, :n, :k] = ok
+                continue
             for i, gt in enumerate(g):
                 if gt is None:
                     continue
@@ -251,9 +290,27 @@ class _Store:
         return cls(np.asarray(positions, dtype=np.int64), None, None, np.full(S, N, dtype=np.int64), shape=shape, lazy=build)
 
     def subset(self, idx: np.ndarray) -> "_Store":
+        """Rows `idx` (ascending, as np.nonzero gives them).  A contiguous run - every region query over sorted
+        positions - becomes a VIEW: no host copy, and its sweeps run over a row range of the root's resident
+        device matrix instead of uploading the rows again."""
+        if idx.size and int(idx[-1]) - int(idx[0]) + 1 == idx.size:
+            a, b = int(idx[0]), int(idx[-1]) + 1
+            view = _Store(self.positions[a:b], None, None, self.num_samples[a:b], shape=(b - a,) + tuple(self.shape[1:]),
+                          lazy=lambda: (self.data[a:b], self.called[a:b]))
+            view._root = self._root if self._root is not None else self
+            view._row0 = self._row0 + a
+            return view
         return _Store(self.positions[idx], self.data[idx], self.called[idx], self.num_samples[idx])
 
+    def device_rows(self, device: int = 0) -> Tuple[dev.DeviceMatrix, int, int]:
+        """(device matrix, first row, row count) holding this store's variants."""
+        if self._root is not None:
+            return self._root.device_matrix(device), self._row0, self.count
+        return self.device_matrix(device), 0, self.count
+
     def device_matrix(self, device: int = 0) -> dev.DeviceMatrix:
+        if self.twin is not None:
+            return self.twin.device_matrix(device)  # same bytes, same (absent) missing mask: one copy in HBM
         if device not in self._device:
             S, N, P = self.data.shape
             flat_called = self.called.reshape(-1)
@@ -338,6 +395,8 @@ def _convert_numeric_array(genotypes, positions) -> Tuple[_Store, Optional[_Dens
     g = np.ascontiguousarray(g)
     store = _Store.from_numpy(g, neg, pos)
     dense = _Dense(g, neg) if genotypes.shape[2] == 2 else None
+    if dense is not None and neg is None and dense.max_allele != 0xFF and genotypes.shape[1] > 0:
+        store.twin = dense  # sparse semantics == dense semantics: no None sample, no 0xFF sentinel
     return store, dense
 
 
@@ -384,23 +443,26 @@ def _rust_debug_opt(v) -> str:
     return f"Some({v})"
 
 
+_set = object.__setattr__  # result objects are immutable for callers (PyO3 `#[pyo3(get)]`); constructors write through this
+
+
 class _ReadOnly:
     __slots__ = ()
 
     def __setattr__(self, key, value):
-        if hasattr(self, "_frozen") and self._frozen:
-            raise AttributeError(f"attribute '{key}' of '{type(self).__name__}' objects is not writable")
-        object.__setattr__(self, key, value)
+        raise AttributeError(f"attribute '{key}' of '{type(self).__name__}' objects is not writable")
+
+    def __delattr__(self, key):
+        raise AttributeError(f"attribute '{key}' of '{type(self).__name__}' objects is not writable")
 
 
 class FstEstimate(_ReadOnly):
     """ferromic.FstEstimate, lib.rs:76-165."""
 
-    __slots__ = ("state", "value", "sum_a", "sum_b", "sites", "_frozen")
+    __slots__ = ("state", "value", "sum_a", "sum_b", "sites")
 
     def __init__(self, state, value, sum_a, sum_b, sites):
-        self.state, self.value, self.sum_a, self.sum_b, self.sites = state, value, sum_a, sum_b, sites
-        self._frozen = True
+        _set(self, "state", state); _set(self, "value", value); _set(self, "sum_a", sum_a); _set(self, "sum_b", sum_b); _set(self, "sites", sites)
 
     def components(self):
         return (self.value, self.sum_a, self.sum_b, self.sites)
@@ -414,11 +476,11 @@ class FstEstimate(_ReadOnly):
 
 
 class PairwiseDifference(_ReadOnly):
-    __slots__ = ("sample_i", "sample_j", "differences", "comparable_sites", "_frozen")
+    __slots__ = ("sample_i", "sample_j", "differences", "comparable_sites")
 
     def __init__(self, sample_i, sample_j, differences, comparable_sites):
-        self.sample_i, self.sample_j, self.differences, self.comparable_sites = sample_i, sample_j, differences, comparable_sites
-        self._frozen = True
+        _set(self, "sample_i", sample_i); _set(self, "sample_j", sample_j); _set(self, "differences", differences)
+        _set(self, "comparable_sites", comparable_sites)
 
     def __repr__(self):
         return (f"PairwiseDifference(sample_i={self.sample_i}, sample_j={self.sample_j}, differences={self.differences}, "
@@ -431,22 +493,20 @@ class ChromosomePcaResult:  # lib.rs:195-257 — PCA is outside the hot path
 
 
 class DiversitySite(_ReadOnly):
-    __slots__ = ("position", "pi", "watterson_theta", "_frozen")
+    __slots__ = ("position", "pi", "watterson_theta")
 
     def __init__(self, position, pi, watterson_theta):
-        self.position, self.pi, self.watterson_theta = position, pi, watterson_theta
-        self._frozen = True
+        _set(self, "position", position); _set(self, "pi", pi); _set(self, "watterson_theta", watterson_theta)
 
     def __repr__(self):
         return f"DiversitySite(position={self.position}, pi={self.pi:.6f}, watterson_theta={self.watterson_theta:.6f})"
 
 
 class HudsonDxyResult(_ReadOnly):
-    __slots__ = ("d_xy", "_frozen")
+    __slots__ = ("d_xy")
 
     def __init__(self, d_xy):
-        self.d_xy = d_xy
-        self._frozen = True
+        _set(self, "d_xy", d_xy)
 
     def __repr__(self):
         return "HudsonDxyResult(d_xy=None)" if self.d_xy is None else f"HudsonDxyResult(d_xy={self.d_xy:.6f})"
@@ -454,12 +514,12 @@ class HudsonDxyResult(_ReadOnly):
 
 class HudsonFstSite(_ReadOnly):
     __slots__ = ("position", "fst", "d_xy", "pi_pop1", "pi_pop2", "n1_called", "n2_called", "numerator_component",
-                 "denominator_component", "_frozen")
+                 "denominator_component")
 
     def __init__(self, position, fst, d_xy, pi_pop1, pi_pop2, n1_called, n2_called, num, den):
-        self.position, self.fst, self.d_xy, self.pi_pop1, self.pi_pop2 = position, fst, d_xy, pi_pop1, pi_pop2
-        self.n1_called, self.n2_called, self.numerator_component, self.denominator_component = n1_called, n2_called, num, den
-        self._frozen = True
+        _set(self, "position", position); _set(self, "fst", fst); _set(self, "d_xy", d_xy); _set(self, "pi_pop1", pi_pop1)
+        _set(self, "pi_pop2", pi_pop2); _set(self, "n1_called", n1_called); _set(self, "n2_called", n2_called)
+        _set(self, "numerator_component", num); _set(self, "denominator_component", den)
 
     def __repr__(self):
         return (f"HudsonFstSite(position={self.position}, fst={_optional_float_display(self.fst)}, "
@@ -469,13 +529,15 @@ class HudsonFstSite(_ReadOnly):
 
 class HudsonFstResult(_ReadOnly):
     __slots__ = ("fst", "d_xy", "pi_pop1", "pi_pop2", "pi_xy_avg", "population1_label", "population1_haplotype_group",
-                 "population2_label", "population2_haplotype_group", "_frozen")
+                 "population2_label", "population2_haplotype_group")
 
     def __init__(self, fst, d_xy, pi_pop1, pi_pop2, pi_xy_avg, id1, id2):
-        self.fst, self.d_xy, self.pi_pop1, self.pi_pop2, self.pi_xy_avg = fst, d_xy, pi_pop1, pi_pop2, pi_xy_avg
-        self.population1_label, self.population1_haplotype_group = _population_label(id1)
-        self.population2_label, self.population2_haplotype_group = _population_label(id2)
-        self._frozen = True
+        _set(self, "fst", fst); _set(self, "d_xy", d_xy); _set(self, "pi_pop1", pi_pop1); _set(self, "pi_pop2", pi_pop2)
+        _set(self, "pi_xy_avg", pi_xy_avg)
+        l1, g1 = _population_label(id1)
+        l2, g2 = _population_label(id2)
+        _set(self, "population1_label", l1); _set(self, "population1_haplotype_group", g1)
+        _set(self, "population2_label", l2); _set(self, "population2_haplotype_group", g2)
 
     def __repr__(self):
         return (f"HudsonFstResult(fst={_optional_float_display(self.fst)}, d_xy={_optional_float_display(self.d_xy)}, "
@@ -486,13 +548,12 @@ class HudsonFstResult(_ReadOnly):
 
 class WcFstSite(_ReadOnly):
     __slots__ = ("position", "overall_fst", "pairwise_fst", "variance_components_a", "variance_components_b",
-                 "population_sizes", "pairwise_variance_components", "_frozen")
+                 "population_sizes", "pairwise_variance_components")
 
     def __init__(self, position, overall_fst, pairwise_fst, a, b, population_sizes, pairwise_variance_components):
-        self.position, self.overall_fst, self.pairwise_fst = position, overall_fst, pairwise_fst
-        self.variance_components_a, self.variance_components_b = a, b
-        self.population_sizes, self.pairwise_variance_components = population_sizes, pairwise_variance_components
-        self._frozen = True
+        _set(self, "position", position); _set(self, "overall_fst", overall_fst); _set(self, "pairwise_fst", pairwise_fst)
+        _set(self, "variance_components_a", a); _set(self, "variance_components_b", b)
+        _set(self, "population_sizes", population_sizes); _set(self, "pairwise_variance_components", pairwise_variance_components)
 
     def variance_components(self):
         return (self.variance_components_a, self.variance_components_b)
@@ -502,12 +563,12 @@ class WcFstSite(_ReadOnly):
 
 
 class WcFstResult(_ReadOnly):
-    __slots__ = ("overall_fst", "pairwise_fst", "pairwise_variance_components", "site_fst", "fst_type", "_frozen")
+    __slots__ = ("overall_fst", "pairwise_fst", "pairwise_variance_components", "site_fst", "fst_type")
 
     def __init__(self, overall_fst, pairwise_fst, pairwise_variance_components, site_fst, fst_type):
-        self.overall_fst, self.pairwise_fst = overall_fst, pairwise_fst
-        self.pairwise_variance_components, self.site_fst, self.fst_type = pairwise_variance_components, site_fst, fst_type
-        self._frozen = True
+        _set(self, "overall_fst", overall_fst); _set(self, "pairwise_fst", pairwise_fst)
+        _set(self, "pairwise_variance_components", pairwise_variance_components); _set(self, "site_fst", site_fst)
+        _set(self, "fst_type", fst_type)
 
     def __repr__(self):
         return f"WcFstResult(overall_fst={self.overall_fst!r})"
@@ -678,9 +739,9 @@ def _sparse_pop_sweep(store: _Store, masks: np.ndarray, rows: Optional[np.ndarra
         store = store.subset(rows)
     if store.count == 0:
         return [dict(haplotype_capacity=int(m.sum()), segregating_sites=0, uncallable_sites=0, pi_sum=0.0) for m in masks]
-    dm = store.device_matrix()
+    dm, r0, rc = store.device_rows()
     g = dev.Groups(dm, masks)
-    return dev.population_summaries(dm, g, dev.FORMULA_SPARSE, want_sites=False).totals
+    return dev.population_summaries(dm, g, dev.FORMULA_SPARSE, r0, rc, want_sites=False).totals
 
 
 def _count_segregating_sites_for_population(pop: Population) -> int:
@@ -789,20 +850,27 @@ def _hudson_sites_sparse(p1: Population, p2: Population, rows: Optional[np.ndarr
     store, masks = _joint_sparse_matrix(p1, p2, rows)
     if store.count == 0:
         return store, None
-    dm = store.device_matrix()
-    return store, dev.hudson_sweep(dm, dev.Groups(dm, masks), dev.FORMULA_SPARSE)
+    dm, r0, rc = store.device_rows()
+    return store, dev.hudson_sweep(dm, dev.Groups(dm, masks), dev.FORMULA_SPARSE, r0, rc)
+
+
+def _opt_list(a: np.ndarray) -> list:
+    """f64 track -> Python floats with NaN -> None (Option<f64>)."""
+    out = a.tolist()
+    nan = np.flatnonzero(a != a)
+    for i in nan.tolist():
+        out[i] = None
+    return out
 
 
 def _sites_to_py(store: _Store, res) -> List[HudsonFstSite]:
     if res is None:
         return []
     s = res.sites
-    out = []
-    for i in range(store.count):
-        out.append(HudsonFstSite(int(store.positions[i]) + 1, _nan_to_none(s["fst"][i]), _nan_to_none(s["dxy"][i]),
-                                 _nan_to_none(s["pi1"][i]), _nan_to_none(s["pi2"][i]), int(s["called"][0][i]),
-                                 int(s["called"][1][i]), _nan_to_none(s["num"][i]), _nan_to_none(s["den"][i])))
-    return out
+    n = store.count
+    return list(map(HudsonFstSite, (store.positions[:n] + 1).tolist(), _opt_list(s["fst"][:n]), _opt_list(s["dxy"][:n]),
+                    _opt_list(s["pi1"][:n]), _opt_list(s["pi2"][:n]), s["called"][0][:n].tolist(), s["called"][1][:n].tolist(),
+                    _opt_list(s["num"][:n]), _opt_list(s["den"][:n])))
 
 
 def _calculate_d_xy_hudson(p1: Population, p2: Population) -> Optional[float]:
@@ -1039,9 +1107,9 @@ def per_site_diversity(variants, haplotypes, region=None) -> List[DiversitySite]
         return []
     mask = store.mask_for(haps, store.first_sample_count)  # membership built from the FIRST variant's sample count
     sub = store.subset(rows)
-    dm = sub.device_matrix()
-    res = dev.diversity_sites(dm, dev.Groups(dm, mask[None, :]))
-    return [DiversitySite(int(sub.positions[i]) + 1, float(res.pi[i]), float(res.theta[i])) for i in range(sub.count)]
+    dm, r0, rc = sub.device_rows()
+    res = dev.diversity_sites(dm, dev.Groups(dm, mask[None, :]), r0, rc)
+    return list(map(DiversitySite, (sub.positions + 1).tolist(), res.pi.tolist(), res.theta.tolist()))
 
 
 def hudson_dxy(population1, population2) -> HudsonDxyResult:
@@ -1158,14 +1226,14 @@ def wc_fst(variants, sample_names, sample_to_group, region) -> WcFstResult:
         if sample_idx >= len(sample_names) or sample_idx >= N or side >= P:
             continue
         masks[label_idx[lab], sample_idx * P + side] = 1
-    dm = sub.device_matrix()
+    dm, r0, rc = sub.device_rows()
     if G < 2:
         # fewer than two groups: every site with any called allele is NoInterPopulationVariance (0, 0),
         # sites without any call are InsufficientData (stats.rs:1925-1930, 1987-2003).  One summary
         # sweep over all columns supplies "any call"; the single group's sizes come with it.
         allm = np.ones((1, N * P), dtype=np.uint8)
         gm = np.concatenate([allm, masks[:1]]) if G == 1 else allm
-        res = dev.population_summaries(dm, dev.Groups(dm, gm), dev.FORMULA_SPARSE)
+        res = dev.population_summaries(dm, dev.Groups(dm, gm), dev.FORMULA_SPARSE, r0, rc)
         site_objs = []
         for i in range(sub.count):
             if res.called[0][i] == 0:
@@ -1177,7 +1245,7 @@ def wc_fst(variants, sample_names, sample_to_group, region) -> WcFstResult:
         overall = _insufficient(len(site_objs)) if n_inf == 0 else _classify(0.0, 0.0, n_inf)
         return WcFstResult(overall, {}, {}, site_objs, "haplotype_groups")
     # up to 8 groups: the fused sweep; more: counting sweeps in batches of 8 + the counts kernel (same per-site bits)
-    w = dev.wc_sweep(dm, dev.Groups(dm, masks)) if G <= dev._abi.MAX_GROUPS else dev.wc_sweep_many(dm, masks)
+    w = dev.wc_sweep(dm, dev.Groups(dm, masks), r0, rc) if G <= dev._abi.MAX_GROUPS else dev.wc_sweep_many(dm, masks, r0, rc)
     states = dev.WC_STATES
     site_objs = []
     for i in range(sub.count):
