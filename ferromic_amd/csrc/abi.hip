@@ -127,6 +127,8 @@ struct fmh_matrix {
   bool owns = true;
 };
 
+static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 struct fmh_groups {
   int device = 0;
   int n_groups = 0;   // caller's P
@@ -135,9 +137,12 @@ struct fmh_groups {
   size_t pitch = 0;
   uint32_t columns = 0;
   uint64_t sizes[FMH_MAX_GROUPS] = {0};
+  std::vector<uint8_t> host_mask;  // [n_groups][columns] as handed in (the wide-matrix W&C route re-batches the groups)
 };
 
-static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// LDS the sweep needs for P (padded) groups of an `nvec`-vector row; the kernels take at most 150 KiB
+static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 16; }
+static const size_t kSweepLdsLimit = 150 * 1024;
 
 static int check_dims(size_t variants, size_t samples, size_t ploidy) {
   if (ploidy == 0 || samples == 0) return fail(FMH_ERR_INVALID, "samples and ploidy must be positive");
@@ -366,6 +371,7 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
   g->padded = padded_groups(n_groups);
   g->pitch = m->pitch;
   g->columns = m->columns;
+  g->host_mask.assign(h_mask, h_mask + (size_t)n_groups * m->columns);
   std::vector<uint8_t> staged((size_t)g->padded * g->pitch, 0);
   for (int p = 0; p < n_groups; ++p) {
     uint64_t cnt = 0;
@@ -575,7 +581,9 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   a.unroll = env_unroll == 8 ? 8 : 4;
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
   const size_t smem = (size_t)P * a.nvec_pad * 16;
-  if (smem > 150 * 1024) return fail(FMH_ERR_UNSUPPORTED, "P=%d masks of %u columns need %zu B of LDS (> 150 KiB)", P, m->columns, smem);
+  if (smem > kSweepLdsLimit)
+    return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns need %zu B of LDS (> 150 KiB): sweep fewer groups at a time (at most %u columns per group)",
+                P, m->columns, smem, (unsigned)(kSweepLdsLimit / 16 * 16));
   int grid = 0;
   int rc = FMH_ERR_UNSUPPORTED;
 #define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
@@ -635,6 +643,21 @@ extern "C" int fmh_population_summaries(const fmh_matrix* m, const fmh_groups* g
   a.formula = formula;
   a.alt = d_alt;
   a.called = d_called;
+  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit && g->n_groups > 1) {
+    // rows too wide for all masks at once: the populations are independent, sweep them in smaller batches
+    int batch = g->n_groups;
+    while (batch > 1 && sweep_lds_bytes(padded_groups(batch), m->nvec) > kSweepLdsLimit) batch = (batch + 1) / 2;
+    for (int p0 = 0; p0 < g->n_groups; p0 += batch) {
+      const int cnt = std::min(batch, g->n_groups - p0);
+      fmh_groups* sub = nullptr;
+      FMH_TRY(fmh_groups_create(m, g->host_mask.data() + (size_t)p0 * m->columns, cnt, &sub));
+      const int rc = fmh_population_summaries(m, sub, row_begin, row_count, formula, d_alt ? d_alt + (size_t)p0 * row_count : nullptr,
+                                              d_called ? d_called + (size_t)p0 * row_count : nullptr, h_totals ? h_totals + p0 : nullptr, stream);
+      fmh_groups_destroy(sub);
+      FMH_TRY(rc);
+    }
+    return FMH_OK;
+  }
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeSummary, a, stream, &r));
   if (h_totals) for (int p = 0; p < g->n_groups; ++p) fill_pop_totals(g, r, p, &h_totals[p]);
@@ -724,6 +747,20 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
         }
       }
   }
+  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit) {
+    // rows too wide for all groups' masks to sit in LDS at once: count in smaller batches, components from the count tables
+    const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
+    std::vector<double> sa(nslots), sb(nslots);
+    std::vector<uint64_t> si(nslots);
+    FMH_TRY(fmh_wc_sweep_many(m, g->host_mask.data(), g->n_groups, row_begin, row_count, d_a, d_b, d_state, d_group_called, sa.data(),
+                              sb.data(), si.data(), stream));
+    if (h_totals) {
+      memset(h_totals, 0, sizeof *h_totals);
+      h_totals->sites_attempted = row_count;
+      for (size_t k = 0; k < nslots; ++k) { h_totals->sum_a[k] = sa[k]; h_totals->sum_b[k] = sb[k]; h_totals->informative_sites[k] = si[k]; }
+    }
+    return FMH_OK;
+  }
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeWc, a, stream, &r));
   if (h_totals) {
@@ -797,8 +834,10 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   }
   (void)all_alt;
   // (2) counts of every group, eight groups per sweep
-  for (size_t g0 = 0; g0 < G; g0 += FMH_MAX_GROUPS) {
-    const int cnt = (int)std::min<size_t>(FMH_MAX_GROUPS, G - g0);
+  size_t batch = FMH_MAX_GROUPS;  // as many groups per sweep as the LDS holds masks for
+  while (batch > 1 && sweep_lds_bytes((int)batch, m->nvec) > kSweepLdsLimit) batch /= 2;
+  for (size_t g0 = 0; g0 < G; g0 += batch) {
+    const int cnt = (int)std::min<size_t>(batch, G - g0);
     fmh_groups* g = nullptr;
     FMH_TRY(fmh_groups_create(m, h_column_mask + g0 * m->columns, cnt, &g));
     SweepArgs a{};

@@ -279,3 +279,43 @@ def test_generator_matches_host_hash(dev):
             got_miss = (int(words[idx >> 6]) >> (idx & 63)) & 1
             assert got_miss == int(miss)
             assert data[s, h] == (0 if miss else bit)
+
+
+def test_rows_wider_than_lds_for_all_masks(dev):
+    """24 000 haplotypes x 8 groups: the eight byte masks (8 x 24 000 B) do not fit the 150 KiB of LDS the fused sweep
+    may use, so W&C re-batches the groups (counts path) and the summaries sweep the populations in batches - same
+    numbers as the oracle / as the fused kernel on a subset that fits."""
+    rng = np.random.default_rng(99)
+    S, N, G = 24, 12_000, 8
+    m = H.random_dense_matrix(rng, S, N, 2, 1, 0.01)
+    dm = upload(dev, m)
+    pop_of_sample = rng.integers(0, G, size=N)
+    lists = [H.haps_for_samples(np.nonzero(pop_of_sample == g)[0].tolist()) for g in range(G)]
+    masks = np.stack([dev.Groups.mask_from_haplotypes(dm, hl) for hl in lists])
+    groups = dev.Groups(dm, masks)
+    got = dev.population_summaries(dm, groups, dev.FORMULA_SUMMARY)
+    for g in range(G):
+        exp = R.build_dense_population_summary(m, lists[g])
+        assert got.totals[g]["segregating_sites"] == exp.segregating_sites
+        assert np.array_equal(got.alt[g], np.array(exp.alt_counts, dtype=np.uint32))
+        assert np.array_equal(got.called[g], np.array(exp.called_counts, dtype=np.uint32))
+        assert H.rel_close(got.totals[g]["pi_sum"], exp.pi_sum)
+    w = dev.wc_sweep(dm, groups)          # too wide for the fused kernel -> counts path inside the library
+    w8 = dev.wc_sweep_many(dm, masks)
+    assert np.array_equal(w.a, w8.a) and np.array_equal(w.b, w8.b) and np.array_equal(w.state, w8.state)
+    assert np.array_equal(w.group_called, got.called)
+    # four of the groups fit the fused kernel: the shared pair slots must agree bit for bit
+    keep = [0, 3, 5, 6]
+    w4 = dev.wc_sweep(dm, dev.Groups(dm, masks[keep]))
+    slot8 = {}
+    k = 1
+    for i in range(G):
+        for j in range(i + 1, G):
+            slot8[(i, j)] = k
+            k += 1
+    k4 = 1
+    for x in range(4):
+        for y in range(x + 1, 4):
+            k8 = slot8[(keep[x], keep[y])]
+            assert np.array_equal(w4.a[k4], w.a[k8]) and np.array_equal(w4.b[k4], w.b[k8])
+            k4 += 1
