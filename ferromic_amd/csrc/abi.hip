@@ -873,7 +873,6 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
                                         unsigned long long* d_both, void* stream) {
   if (!m || !d_diff || !d_both) return fail(FMH_ERR_INVALID, "NULL argument");
   if (n_samples > m->samples) return fail(FMH_ERR_INVALID, "n_samples %zu exceeds the matrix's %zu samples", n_samples, m->samples);
-  if (m->max_allele > 15) return fail(FMH_ERR_UNSUPPORTED, "pairwise differences support max_allele <= 15 (got %u)", m->max_allele);
   if (m->ploidy > 127) return fail(FMH_ERR_UNSUPPORTED, "pairwise differences support ploidy <= 127 (int8 operands), got %zu", m->ploidy);
   FMH_TRY(use_device(m->device));
   if (n_samples < 2 || m->variants == 0) return FMH_OK;

@@ -331,7 +331,7 @@ def test_wc_analytic_through_api(kats):
 
 
 @pytest.mark.parametrize("N,S,max_allele,p_missing,p_haploid", [(3, 3, 1, 0.0, 0.0), (9, 150, 1, 0.1, 0.1), (70, 300, 3, 0.05, 0.05),
-                                                                 (130, 64, 2, 0.0, 0.0), (150, 200, 2, 0.03, 0.02)])
+                                                                 (130, 64, 2, 0.0, 0.0), (150, 200, 2, 0.03, 0.02), (20, 60, 40, 0.05, 0.0)])
 def test_pairwise_differences(N, S, max_allele, p_missing, p_haploid):
     rng = random.Random(N * 31 + S)
     variants = H.random_sparse_variants(rng, S, N, max_allele, p_missing, p_haploid, 1 if p_missing else 0)
