@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -430,7 +431,7 @@ struct Workspace {
 };
 static Workspace g_ws[64];
 static std::mutex g_ws_mutex;
-static bool g_timing = false;
+static std::atomic<bool> g_timing{false};
 static double g_timing_ms = 0.0;
 static uint64_t g_timing_launches = 0;
 
@@ -477,8 +478,14 @@ static int ensure_harmonic(Workspace* w, size_t max_k, hipStream_t st) {
 }
 
 extern "C" int fmh_timing_enable(int on) { g_timing = on != 0; return FMH_OK; }
-extern "C" int fmh_timing_reset(void) { g_timing_ms = 0.0; g_timing_launches = 0; return FMH_OK; }
+extern "C" int fmh_timing_reset(void) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  g_timing_ms = 0.0;
+  g_timing_launches = 0;
+  return FMH_OK;
+}
 extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
   if (ms) *ms = g_timing_ms;
   if (launches) *launches = g_timing_launches;
   return FMH_OK;
@@ -914,8 +921,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     if ((e = hipGetLastError()) != hipSuccess) break;
     // persistent grid: 3 workgroups per CU, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
     // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
-    static const int cus = [&] { hipDeviceProp_t prop; return hipGetDeviceProperties(&prop, m->device) == hipSuccess ? prop.multiProcessorCount : 256; }();
-    const unsigned grid = (unsigned)std::max(8, cus * 3 / 8 * 8);
+    const unsigned grid = (unsigned)std::max(8, w->cus * 3 / 8 * 8);  // w = this device's workspace
     const size_t slots = grid / 8;
     size_t j = env_chunk ? std::max<size_t>(1, (s_pad + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
     const size_t k_cap = (((size_t)1 << 31) - 1) / (m->ploidy * m->ploidy) / kPdStageK * kPdStageK;
