@@ -24,6 +24,9 @@ def test_module_surface_matches_reference():
         assert callable(getattr(fm, name)), name
     for attr in ("__version__", "__rust_profile__", "__rust_opt_level__", "__debug_build__"):
         assert hasattr(fm, attr)
+    # the host side is the compiled extension (C++/pybind11 over the C-ABI), not a Python re-implementation
+    import ferromic._core as core
+    assert core.__file__.endswith(".so") and fm.Population is core.Population and fm.hudson_fst is core.hudson_fst
     with pytest.raises(NotImplementedError):
         fm.global_pca({}, [], "out")
     with pytest.raises(ValueError, match="sequence_length"):

@@ -1,4 +1,4 @@
-"""Drop-in API parity: the `ferromic` module (ferromic_amd.api -> C-ABI -> HIP) exercised the way the
+"""Drop-in API parity: the `ferromic` module (ferromic._core, C++ -> C-ABI -> HIP) exercised the way the
 reference's own Python tests do (src/pytests/test_ferromic.py, test_hudson_fst_integration.py,
 test_diversity_integration.py, src/pybenches/test_population_statistics_benchmarks.py), with the
 CPU oracle standing in for scikit-allel (absent here)."""
