@@ -134,8 +134,9 @@ struct fmh_groups {
   int device = 0;
   int n_groups = 0;   // caller's P
   int padded = 0;     // kernel P (1, 2, 4 or 8)
-  uint8_t* masks = nullptr;  // [padded][pitch]
+  uint8_t* masks = nullptr;  // [padded][mask_pitch], zero beyond the row
   size_t pitch = 0;
+  size_t mask_pitch = 0;     // pitch rounded up to 2048: covers the kernels' zero-padded mask stride
   uint32_t columns = 0;
   uint64_t sizes[FMH_MAX_GROUPS] = {0};
   std::vector<uint8_t> host_mask;  // [n_groups][columns] as handed in (the wide-matrix W&C route re-batches the groups)
@@ -371,14 +372,15 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
   g->n_groups = n_groups;
   g->padded = padded_groups(n_groups);
   g->pitch = m->pitch;
+  g->mask_pitch = round_up(m->pitch, 2048);
   g->columns = m->columns;
   g->host_mask.assign(h_mask, h_mask + (size_t)n_groups * m->columns);
-  std::vector<uint8_t> staged((size_t)g->padded * g->pitch, 0);
+  std::vector<uint8_t> staged((size_t)g->padded * g->mask_pitch, 0);
   for (int p = 0; p < n_groups; ++p) {
     uint64_t cnt = 0;
     for (uint32_t h = 0; h < m->columns; ++h) {
       const uint8_t v = h_mask[(size_t)p * m->columns + h] ? 1 : 0;
-      staged[(size_t)p * g->pitch + h] = v;
+      staged[(size_t)p * g->mask_pitch + h] = v;
       cnt += v;
     }
     g->sizes[p] = cnt;
@@ -494,9 +496,9 @@ extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int P, int MODE, bool MISSING, bool GENERAL>
+template <int P, int MODE, bool MISSING, bool GENERAL, bool MASKG = false>
 static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStream_t st, int* grid_out) {
-  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL>;
+  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL, MASKG>;
   static thread_local int cached_occ[64];
   static thread_local size_t cached_smem[64];
   int dev = 0;
@@ -526,10 +528,10 @@ static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStrea
   return FMH_OK;
 }
 
-template <int P, int MODE>
+template <int P, int MODE, bool MASKG = false>
 static int launch_pm(Workspace* w, const SweepArgs& a, size_t smem, hipStream_t st, bool missing, bool general, int* grid) {
-  if (missing) return general ? launch_one<P, MODE, true, true>(w, a, smem, st, grid) : launch_one<P, MODE, true, false>(w, a, smem, st, grid);
-  return general ? launch_one<P, MODE, false, true>(w, a, smem, st, grid) : launch_one<P, MODE, false, false>(w, a, smem, st, grid);
+  if (missing) return general ? launch_one<P, MODE, true, true, MASKG>(w, a, smem, st, grid) : launch_one<P, MODE, true, false, MASKG>(w, a, smem, st, grid);
+  return general ? launch_one<P, MODE, false, true, MASKG>(w, a, smem, st, grid) : launch_one<P, MODE, false, false, MASKG>(w, a, smem, st, grid);
 }
 
 struct SweepResult {
@@ -555,6 +557,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   a.mv.columns = m->columns;
   a.mv.nvec = m->nvec;
   a.masks = g->masks;
+  a.mask_pitch = g->mask_pitch;
   for (int p = 0; p < 8; ++p) a.group_size[p] = p < g->n_groups ? (uint32_t)g->sizes[p] : 0;
   a.n_groups = g->n_groups;
   a.max_allele = m->max_allele;
@@ -587,14 +590,21 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   static const int env_unroll = getenv("FMH_UNROLL") ? atoi(getenv("FMH_UNROLL")) : 0;
   a.unroll = env_unroll == 8 ? 8 : 4;
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
-  const size_t smem = (size_t)P * a.nvec_pad * 16;
-  if (smem > kSweepLdsLimit)
-    return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns need %zu B of LDS (> 150 KiB): sweep fewer groups at a time (at most %u columns per group)",
-                P, m->columns, smem, (unsigned)(kSweepLdsLimit / 16 * 16));
+  size_t smem = (size_t)P * a.nvec_pad * 16;
+  const bool wide = smem > kSweepLdsLimit;  // the masks do not fit LDS: read them from global memory (L2) instead
+  if (wide) smem = 0;
   int grid = 0;
   int rc = FMH_ERR_UNSUPPORTED;
 #define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
-  if (mode == kModeSummary) {
+#define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, true>(w, a, smem, st, missing, general, &grid)
+  if (wide) {
+    // one or two groups per sweep on this route (summaries and W&C re-batch their groups accordingly)
+    if (mode == kModeSummary && P == 1) WIDE(1, kModeSummary);
+    else if (mode == kModeSummary && P == 2) WIDE(2, kModeSummary);
+    else if (mode == (kModeSummary | kModeHudson) && P == 2) WIDE(2, kModeSummary | kModeHudson);
+    else if (mode == (kModeSummary | kModeDiversity) && P == 1) WIDE(1, kModeSummary | kModeDiversity);
+    else return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
+  } else if (mode == kModeSummary) {
     if (P == 1) CASE(1, kModeSummary); else if (P == 2) CASE(2, kModeSummary); else if (P == 4) CASE(4, kModeSummary); else CASE(8, kModeSummary);
   } else if (mode == (kModeSummary | kModeHudson)) {
     if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
@@ -608,6 +618,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   } else {
     return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
   }
+#undef WIDE
 #undef CASE
   FMH_TRY(rc);
   hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, w->part_f64, w->part_u64, grid, w->out_f64, w->out_u64);
@@ -650,10 +661,10 @@ extern "C" int fmh_population_summaries(const fmh_matrix* m, const fmh_groups* g
   a.formula = formula;
   a.alt = d_alt;
   a.called = d_called;
-  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit && g->n_groups > 1) {
+  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit && g->n_groups > 2) {
     // rows too wide for all masks at once: the populations are independent, sweep them in smaller batches
     int batch = g->n_groups;
-    while (batch > 1 && sweep_lds_bytes(padded_groups(batch), m->nvec) > kSweepLdsLimit) batch = (batch + 1) / 2;
+    while (batch > 2 && sweep_lds_bytes(padded_groups(batch), m->nvec) > kSweepLdsLimit) batch = (batch + 1) / 2;
     for (int p0 = 0; p0 < g->n_groups; p0 += batch) {
       const int cnt = std::min(batch, g->n_groups - p0);
       fmh_groups* sub = nullptr;
@@ -842,7 +853,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   (void)all_alt;
   // (2) counts of every group, eight groups per sweep
   size_t batch = FMH_MAX_GROUPS;  // as many groups per sweep as the LDS holds masks for
-  while (batch > 1 && sweep_lds_bytes((int)batch, m->nvec) > kSweepLdsLimit) batch /= 2;
+  while (batch > 2 && sweep_lds_bytes((int)batch, m->nvec) > kSweepLdsLimit) batch /= 2;  // two groups fit any width (global-mask route)
   for (size_t g0 = 0; g0 < G; g0 += batch) {
     const int cnt = (int)std::min<size_t>(batch, G - g0);
     fmh_groups* g = nullptr;

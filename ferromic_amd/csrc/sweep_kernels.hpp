@@ -61,7 +61,8 @@ constexpr int kMaxWcSlots = 1 + (8 * 7) / 2;
 
 struct SweepArgs {
   MatrixView mv;
-  const uint8_t* masks;   // device [P][pitch] 0/1 bytes
+  const uint8_t* masks;   // device [P][mask_pitch] 0/1 bytes, zero beyond the row
+  size_t mask_pitch;      // bytes per mask: pitch rounded up to 2048 (>= nvec_pad * 16)
   uint32_t group_size[8]; // mask popcounts
   uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
   int unroll;             // vectors per lane issued back to back (4 or 8)
@@ -757,20 +758,28 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
 // ------------------------------------------------------------------------------------------------
 // the sweep kernel
 // ------------------------------------------------------------------------------------------------
-template <int P, int MODE, bool MISSING, bool GENERAL>
+// MASKG = the membership masks are read from global memory (L2-resident) instead of LDS: the route for rows so wide
+// that P masks exceed the LDS budget (more than 153 600 haplotypes for one group, 76 800 for a Hudson pair).
+template <int P, int MODE, bool MISSING, bool GENERAL, bool MASKG = false>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint4* lds_mask = reinterpret_cast<uint4*>(smem);
   const MatrixView mv = A.mv;
   const uint32_t nvec = mv.nvec;
-
-  // stage the P membership masks into LDS (16 B per thread per step), zero-padded to nvec_pad
-  const uint32_t nvec_pad = A.nvec_pad;
-  for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec_pad; i += kBlock) {
-    const uint32_t p = i / nvec_pad, v = i - p * nvec_pad;
-    lds_mask[i] = v < nvec ? load_vec(A.masks + (size_t)p * mv.pitch + (size_t)v * 16) : make_uint4(0, 0, 0, 0);
+  uint32_t nvec_pad = A.nvec_pad;
+  const uint4* lds_mask;
+  if constexpr (MASKG) {
+    lds_mask = reinterpret_cast<const uint4*>(A.masks);
+    nvec_pad = (uint32_t)(A.mask_pitch / 16);  // the stride between the masks of two groups, in vectors
+  } else {
+    // stage the P membership masks into LDS (16 B per thread per step), zero-padded to nvec_pad
+    uint4* staged = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec_pad; i += kBlock) {
+      const uint32_t p = i / nvec_pad, v = i - p * nvec_pad;
+      staged[i] = v < nvec ? load_vec(A.masks + (size_t)p * A.mask_pitch + (size_t)v * 16) : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    lds_mask = staged;
   }
-  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;

@@ -36,6 +36,8 @@ SHAPES = [
     (130, 45, 3, 0.0),     # multi-allelic
     (130, 45, 5, 0.1),     # multi-allelic with missing
     (70, 2500, 1, 0.0),    # C4-like width (H = 5000)
+    (6, 100_000, 1, 0.0),  # H = 200 000: the masks exceed the LDS budget -> global-mask route of the same kernels
+    (5, 90_001, 2, 0.02),  # the same, multi-allelic with missing calls, ragged width
 ]
 
 
@@ -114,6 +116,7 @@ SPARSE_CASES = [
     (150, 21, 1, 0.15, 0.05, 2),
     (90, 33, 3, 0.1, 0.1, 1),
     (40, 300, 2, 0.02, 0.0, 0),
+    (5, 90_000, 1, 0.02, 0.0, 0),  # 180 000 columns: wide route for the Hudson pair and the one-group diversity sweep
 ]
 
 
@@ -176,6 +179,7 @@ WC_CASES = [
     (100, 40, 4, 1, 0.05, 0.0, 1, 4),
     (80, 30, 3, 3, 0.1, 0.05, 1, 2),
     (60, 50, 5, 2, 0.05, 0.0, 0, 5),
+    (4, 60_000, 3, 1, 0.02, 0.0, 0, 7),  # 120 000 columns: W&C re-batches to two groups per (wide) counting sweep
 ]
 
 
