@@ -271,6 +271,31 @@ def test_csv_defined_populations(tmp_path):
     assert "NamedPopulation\tAFR\tNamedPopulation\tEAS" in hud and "HaplotypeGroup\t0\tHaplotypeGroup\t1" in hud
 
 
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_random_flag_combinations(tmp_path, seed):
+    """Seeded random cohorts x random CLI flags (mask / allow / exclude / min_gq / --fst / population CSV / gz input / workers)."""
+    rng = random.Random(seed)
+    n = rng.randint(6, 22)
+    kw, names = make_cohort(tmp_path, seed=seed, n_samples=n, gz=rng.random() < 0.3)
+    if rng.random() < 0.7:
+        kw["enable_fst"] = True
+    if rng.random() < 0.5:
+        kw["mask_file"] = str(tmp_path / "mask.bed")
+    if rng.random() < 0.5:
+        kw["allow_file"] = str(tmp_path / "allow.tsv")
+    if rng.random() < 0.4:
+        kw["exclude"] = rng.sample(names, rng.randint(1, 2))
+    if rng.random() < 0.5:
+        kw["min_gq"] = rng.choice([0, 20, 31, 46, 70])
+    if kw.get("enable_fst") and rng.random() < 0.5:
+        k = rng.randint(2, 4)
+        (tmp_path / "pops.csv").write_text("".join(f"G{g}," + ",".join(names[g::k]) + "\n" for g in range(k)))
+        kw["fst_populations"] = str(tmp_path / "pops.csv")
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), devices="0,0" if rng.random() < 0.3 else None, **kw)
+    compare(got, exp)
+
+
 def test_many_csv_populations(tmp_path):
     """More CSV populations than the fused sweep holds in registers (8): fmh_wc_sweep_many (counting sweeps in
     batches of 8 + counts kernel) and one Hudson sweep per population pair."""
