@@ -898,7 +898,8 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   const int n_alleles = (int)m->max_allele + 1;
   const bool missing = m->bits != nullptr;
   const int n_planes = missing ? n_alleles + 2 : n_alleles;  // + genotype length, + valid flag only when calls can be missing
-  const size_t n_pad = round_up(n_samples, kPdBlock);
+  const size_t tile_edge = kPdBig;
+  const size_t n_pad = round_up(n_samples, kPdBig);
   // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
   static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
   size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK);
@@ -916,7 +917,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   }
   uint8_t* planes = w->pd_planes;
   hipError_t e = hipSuccess;
-  const size_t nt = n_pad / kPdBlock, tiles = nt * (nt + 1) / 2;
+  const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
   static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
   for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
     const size_t rows = std::min(slab, m->variants - row0);
@@ -930,9 +931,19 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     hipLaunchKernelGGL(pd_planes_kernel, dim3((unsigned)(s_pad / kPdStageK), (unsigned)(n_pad / sb)), dim3(256), planes_smem, st, mv,
                        rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, n_planes, sb, planes, n_pad, s_pad);
     if ((e = hipGetLastError()) != hipSuccess) break;
-    // persistent grid: 3 workgroups per CU, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
+    // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
     // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
-    const unsigned grid = (unsigned)std::max(8, w->cus * 3 / 8 * 8);  // w = this device's workspace
+    static thread_local int gram_occ[64];
+    if (gram_occ[m->device] == 0) {
+      int occ = 0;
+      hipError_t oe = hipFuncSetAttribute((const void*)pd_gram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPdBigStageBytes);
+      if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel, 1024, 2 * kPdBigStageBytes);
+      if (oe != hipSuccess || occ < 1) occ = 1;
+      static const int env_occ = getenv("FMH_PD_OCC") ? atoi(getenv("FMH_PD_OCC")) : 0;
+      if (env_occ > 0 && occ > env_occ) occ = env_occ;
+      gram_occ[m->device] = occ;
+    }
+    const unsigned grid = (unsigned)std::max(8, w->cus * gram_occ[m->device] / 8 * 8);  // persistent: every workgroup resident
     const size_t slots = grid / 8;
     size_t j = env_chunk ? std::max<size_t>(1, (s_pad + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
     const size_t k_cap = (((size_t)1 << 31) - 1) / (m->ploidy * m->ploidy) / kPdStageK * kPdStageK;
@@ -942,8 +953,8 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     if (k_chunk > k_cap) k_chunk = k_cap;
     j = ((s_pad + k_chunk - 1) / k_chunk + 7) / 8;
     auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst) {
-      hipLaunchKernelGGL(pd_gram_mfma_kernel, dim3(grid), dim3(256), 0, st, planes, n_pad, s_pad, plane_begin, plane_count, k_chunk,
-                         (uint32_t)j, (uint32_t)n_samples, negate, dst);
+      hipLaunchKernelGGL(pd_gram256_kernel, dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
+                         k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst);
       return hipGetLastError();
     };
     // diff = sum len_i len_j - sum_a cnt_i(a) cnt_j(a)

@@ -1102,7 +1102,7 @@ __global__ void max_allele_kernel(const uint8_t* __restrict__ data, size_t pitch
 // tiled Gram product on the int8 matrix cores (v_mfma_i32_32x32x32_i8) with split-K and exact integer atomics.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPdTile = 64;
-constexpr int kPdBlock = 128;   // samples per Gram workgroup tile edge
+constexpr int kPdBlock = 128;   // samples per planes-kernel workgroup
 constexpr int kPdStageK = 128;  // K bytes (sites) per Gram stage
 
 // planes[p][site / 128][sample][site % 128]: p = 0..A-1 allele counts, then (only when calls can be missing)
@@ -1218,106 +1218,114 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
 // fragments are cut from LDS images with the SAME (row, k) -> lane rule, so whatever order the instruction walks
 // K inside a step, both operands agree and the sum over K is the plain dot product.  C/D: column = lane & 31
 // (B row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (A row).
-// Workgroup = 4 waves = 128 x 128 samples (2 x 2 waves of 64 x 64, each 2 x 2 MFMA tiles); K advances 128 bytes per
-// stage; the next stage's global loads are issued before the current stage's MFMAs (register prefetch).
+// LDS images are byte-for-byte copies of the stage tiles (global_load_lds writes wave-linear), whose 16-byte chunks
+// the planes kernel stored XOR-swizzled by (row >> 1) & 7: 16 consecutive rows of one K chunk then sit in 16
+// different 16-byte slots of the 256-byte bank row, so the fragment reads are conflict-free without padding.
+// Persistent and XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so the group blockIdx.x & 7 shares one L2.
+// Each XCD owns `slices_per_xcd` K slices; its workgroups take (slice, tile pair) items tile-fastest, so at any moment
+// they are walking the same K range over different tile pairs and every stage tile fetched from HBM by one of them
+// is an L2 hit for the others that need it.
 typedef int pd_v4i __attribute__((ext_vector_type(4)));
 typedef int pd_v16i __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void pd_gram_mfma_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad,
-                                                           int plane_begin, int plane_count, size_t k_chunk,
-                                                           uint32_t slices_per_xcd, uint32_t n_samples, int negate,
-                                                           unsigned long long* __restrict__ out) {
-  // Persistent and XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so the group blockIdx.x & 7 shares one L2.
-  // Each XCD owns `slices_per_xcd` K slices; its workgroups take (slice, tile pair) items tile-fastest, so at any moment
-  // they are walking the same K range over different tile pairs and every stage tile fetched from HBM by one of them
-  // is an L2 hit for the ~2 * n_tiles others that need it.
-  const uint32_t nt = (uint32_t)(n_pad / kPdBlock);
+// Workgroup tile 256 x 256 samples: half the operand bytes per MAC of a 128 x 128 tile, whose L2 -> LDS traffic per CU
+// (not MFMA issue) bounded the first version of this kernel at 26 % of peak.  16 waves (4 x 4 of 64 x 64), one workgroup per CU;
+// the two 64 KiB stage buffers alternate: the global_load_lds of stage s+1 are in flight while stage s feeds the MFMAs,
+// one raw s_barrier per stage (a __syncthreads() would drain the loads before the MFMAs start).
+constexpr int kPdBig = 256;
+constexpr int kPdBigStageBytes = 2 * kPdBig * kPdStageK;  // A image + B image of one stage
+
+__global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
+                                                          int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
+                                                          int negate, unsigned long long* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char pd_lds[];  // [2 buffers][A 32 KiB | B 32 KiB]
+  const uint32_t nt = (uint32_t)(n_pad / kPdBig);
   const uint32_t tiles = nt * (nt + 1) / 2;
   const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  // LDS images are byte-for-byte copies of the 16 KiB stage tiles (global_load_lds writes wave-linear), whose 16-byte
-  // chunks the planes kernel stored XOR-swizzled by (row >> 1) & 7: 16 consecutive rows of one K chunk then sit in 16
-  // different 16-byte slots of the 256-byte bank row, so the fragment reads are conflict-free without padding.
-  __shared__ __align__(16) uint8_t sa[kPdBlock * kPdStageK];
-  __shared__ __align__(16) uint8_t sb[kPdBlock * kPdStageK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
-  uint32_t t = item % tiles, bi = 0;
-  while (t >= nt - bi) { t -= nt - bi; ++bi; }  // upper-triangular tile index -> (bi, bj), bi <= bj
-  const uint32_t bj = bi + t;
-  const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
-  if (k0 >= s_pad) continue;  // uniform for the workgroup
-  pd_v16i acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
-  const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
-  const size_t stages_per_plane = (k1 - k0) / kPdStageK;  // k_chunk and s_pad are multiples of kPdStageK
-  const size_t n_stages = stages_per_plane * (size_t)plane_count;
-  const size_t k_blocks = s_pad / kPdStageK;
-  const size_t kb0 = k0 / kPdStageK;
-  const size_t tile_stride = n_pad * kPdStageK;  // bytes between consecutive K blocks of one plane
-  const uint8_t* pa = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bi * kPdBlock) * kPdStageK + (size_t)threadIdx.x * 16;
-  const uint8_t* pb = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bj * kPdBlock) * kPdStageK + (size_t)threadIdx.x * 16;
-  const size_t plane_skip = (k_blocks - stages_per_plane) * tile_stride;  // from the end of one plane's slice to the next plane's
+  const int wr = wave >> 2, wc = wave & 3;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // wave-uniform LDS bases of this wave's four 1 KiB pieces per operand (piece q covers chunks q*256 + wave*64 ..)
-  uint8_t* la = sa + (size_t)wave * 1024;
-  uint8_t* lb = sb + (size_t)wave * 1024;
-  // fragment addresses: row r, logical K chunk 2*ks + (lane >> 5), physical chunk = logical ^ ((r >> 1) & 7)
   uint32_t offa[2], offb[2], swza[2], swzb[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) { const uint32_t r = wr * 64 + m * 32 + (lane & 31); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
 #pragma unroll
-  for (int n = 0; n < 2; ++n) { const uint32_t r = wc * 64 + n * 32 + (lane & 31); offb[n] = r * kPdStageK; swzb[n] = (r >> 1) & 7; }
-  size_t in_plane = 0;
-  for (size_t stage = 0; stage < n_stages; ++stage) {
-    if (in_plane == stages_per_plane) { pa += plane_skip; pb += plane_skip; in_plane = 0; }
-    ++in_plane;
-    __builtin_amdgcn_global_load_lds((gptr_t)(pa), (lptr_t)(la), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pa + 4096), (lptr_t)(la + 4096), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pa + 8192), (lptr_t)(la + 8192), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pa + 12288), (lptr_t)(la + 12288), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pb), (lptr_t)(lb), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pb + 4096), (lptr_t)(lb + 4096), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pb + 8192), (lptr_t)(lb + 8192), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(pb + 12288), (lptr_t)(lb + 12288), 16, 0, 0);
-    pa += tile_stride;
-    pb += tile_stride;
-    __syncthreads();  // waits for this wave's loads (vmcnt(0)) and for everybody else's
+  for (int n = 0; n < 2; ++n) { const uint32_t r = wc * 64 + n * 32 + (lane & 31); offb[n] = kPdBig * kPdStageK + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
+  for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
+    uint32_t t = item % tiles, bi = 0;
+    while (t >= nt - bi) { t -= nt - bi; ++bi; }
+    const uint32_t bj = bi + t;
+    const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
+    if (k0 >= s_pad) continue;  // uniform for the workgroup
+    pd_v16i acc[2][2];
 #pragma unroll
-    for (int ks = 0; ks < kPdStageK / 32; ++ks) {
-      const uint32_t cl = (uint32_t)(ks * 2 + (lane >> 5));
-      pd_v4i fa[2], fb[2];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&sa[offa[m] + ((cl ^ swza[m]) << 4)]);
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&sb[offb[n] + ((cl ^ swzb[n]) << 4)]);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
+    const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
+    const size_t stages_per_plane = (k1 - k0) / kPdStageK;
+    const size_t n_stages = stages_per_plane * (size_t)plane_count;
+    const size_t k_blocks = s_pad / kPdStageK;
+    const size_t kb0 = k0 / kPdStageK;
+    const size_t tile_stride = n_pad * kPdStageK;
+    const uint8_t* pa = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bi * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
+    const uint8_t* pb = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bj * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
+    const size_t plane_skip = (k_blocks - stages_per_plane) * tile_stride;
+    size_t in_plane = 0;
+    // 1024 threads x 16 B = 16 KiB per instruction: two per operand image; wave-uniform LDS bases
+    auto issue = [&](int buf) {
+      if (in_plane == stages_per_plane) { pa += plane_skip; pb += plane_skip; in_plane = 0; }
+      ++in_plane;
+      unsigned char* la = pd_lds + (size_t)buf * kPdBigStageBytes + (size_t)wave * 1024;
+      unsigned char* lb = la + kPdBig * kPdStageK;
+      __builtin_amdgcn_global_load_lds((gptr_t)(pa), (lptr_t)(la), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pa + 16384), (lptr_t)(la + 16384), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb), (lptr_t)(lb), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb + 16384), (lptr_t)(lb + 16384), 16, 0, 0);
+      pa += tile_stride;
+      pb += tile_stride;
+    };
+    if (n_stages) {
+      issue(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    __syncthreads();
-  }
+    for (size_t stage = 0; stage < n_stages; ++stage) {
+      if (stage + 1 < n_stages) issue((int)((stage + 1) & 1));
+      const unsigned char* img = pd_lds + (stage & 1) * (size_t)kPdBigStageBytes;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+      for (int ks = 0; ks < kPdStageK / 32; ++ks) {
+        const uint32_t cl = (uint32_t)(ks * 2 + (lane >> 5));
+        pd_v4i fa[2], fb[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t i = bi * kPdBlock + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const uint32_t j = bj * kPdBlock + wc * 64 + n * 32 + (lane & 31);
-        if (i < j && j < n_samples) {
-          const long long v = acc[m][n][r];
-          if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));  // exact, order-independent
-        }
+        for (int n = 0; n < 2; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
       }
-  }  // items
+      // every wave: my loads of the next stage have landed; everybody: done reading this stage's image
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t i = bi * kPdBig + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const uint32_t j = bj * kPdBig + wc * 64 + n * 32 + (lane & 31);
+          if (i < j && j < n_samples) {
+            const long long v = acc[m][n][r];
+            if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));
+          }
+        }
+  }
 }
 
 // Without missing data every genotype has `ploidy` alleles: sum over sites of len_i * len_j = rows * ploidy^2 and every

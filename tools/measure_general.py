@@ -54,9 +54,9 @@ def main():
         t0 = time.perf_counter()
         device.pairwise_differences(dm, N2)
         dt = time.perf_counter() - t0
-        n_pad = -(-N2 // 128) * 128
-        tiles = (n_pad // 128) * (n_pad // 128 + 1) // 2
-        macs = tiles * 128 * 128 * S2 * 2  # two allele-count planes (no missing data: length/valid terms are constants)
+        n_pad = -(-N2 // 256) * 256
+        tiles = (n_pad // 256) * (n_pad // 256 + 1) // 2
+        macs = tiles * 256 * 256 * S2 * 2  # two allele-count planes (no missing data: length/valid terms are constants)
         print(json.dumps({"case": f"pairwise {S2}x{N2}", "seconds": dt, "sample_pair_sites_per_s": N2 * (N2 - 1) / 2 * S2 / dt,
                           "mfma_TMAC_per_s": macs / dt / 1e12}), flush=True)
         dm.close()

@@ -22,9 +22,9 @@ def main():
         t0 = time.perf_counter()
         device.pairwise_differences(dm, N)
         dt = time.perf_counter() - t0
-        n_pad = -(-N // 128) * 128
-        tiles = (n_pad // 128) * (n_pad // 128 + 1) // 2
-        macs = tiles * 128 * 128 * S * 2  # two allele-count planes; length/valid terms are constants without missing data
+        n_pad = -(-N // 256) * 256
+        tiles = (n_pad // 256) * (n_pad // 256 + 1) // 2
+        macs = tiles * 256 * 256 * S * 2  # two allele-count planes; length/valid terms are constants without missing data
         print(json.dumps({"case": f"pairwise {S}x{N}", "seconds": dt, "sample_pair_sites_per_s": N * (N - 1) / 2 * S / dt,
                           "mfma_TMAC_per_s": macs / dt / 1e12}), flush=True)
         dm.close()
