@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <cstring>
 #include <atomic>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -75,6 +77,89 @@ static int use_device(int device) {
   return FMH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// device memory pool.  A region of run_vcf or one call of the Python module allocates a dozen small device
+// buffers (masks, per-site tracks, temporaries); hipMalloc/hipFree cost tens to hundreds of microseconds each
+// and hipFree synchronises the device.  Blocks up to 64 MiB are recycled through size-class free lists (at most
+// 2 GiB cached per device; fmh_device_release_scratch empties them).  Every entry point of this library
+// synchronises before it returns, so a block handed back by the caller is idle.
+// ------------------------------------------------------------------------------------------------
+struct DevicePool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;           // pooled blocks in use -> class size
+  std::map<size_t, std::vector<void*>> free_lists;  // class size -> idle blocks
+  size_t cached_bytes = 0;
+};
+static DevicePool g_pool[64];
+static const size_t kPoolMaxBlock = (size_t)64 << 20, kPoolMaxCached = (size_t)2 << 30;
+
+static size_t pool_class(size_t bytes) {  // powers of two in quarter steps, >= 256 B
+  if (bytes <= 256) return 256;
+  size_t p2 = 256;
+  while (p2 < bytes) p2 <<= 1;
+  const size_t q = p2 / 8;  // p2/2 + k*q, k = 1..4
+  for (size_t c = p2 / 2 + q; c <= p2; c += q) if (c >= bytes) return c;
+  return p2;
+}
+
+static hipError_t pool_malloc(int device, void** out, size_t bytes) {
+  *out = nullptr;
+  if (device < 0 || device >= 64 || bytes > kPoolMaxBlock) return hipMalloc(out, bytes ? bytes : 16);
+  DevicePool& pool = g_pool[device];
+  const size_t c = pool_class(bytes);
+  {
+    std::lock_guard<std::mutex> lock(pool.mu);
+    auto it = pool.free_lists.find(c);
+    if (it != pool.free_lists.end() && !it->second.empty()) {
+      *out = it->second.back();
+      it->second.pop_back();
+      pool.cached_bytes -= c;
+      pool.live[*out] = c;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, c);
+  if (e != hipSuccess) {  // out of memory: give the cache back and retry once
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> lock(pool.mu);
+      for (auto& kv : pool.free_lists) { drop.insert(drop.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+      pool.cached_bytes = 0;
+    }
+    for (void* p : drop) (void)hipFree(p);
+    (void)hipGetLastError();
+    e = hipMalloc(out, c);
+  }
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lock(pool.mu); pool.live[*out] = c; }
+  return e;
+}
+
+static void pool_free(int device, void* p) {
+  if (!p) return;
+  if (device >= 0 && device < 64) {
+    DevicePool& pool = g_pool[device];
+    std::lock_guard<std::mutex> lock(pool.mu);
+    auto it = pool.live.find(p);
+    if (it != pool.live.end()) {
+      const size_t c = it->second;
+      pool.live.erase(it);
+      if (pool.cached_bytes + c <= kPoolMaxCached) { pool.free_lists[c].push_back(p); pool.cached_bytes += c; return; }
+    }
+  }
+  (void)hipFree(p);
+}
+
+static void pool_trim(int device) {
+  if (device < 0 || device >= 64) return;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lock(g_pool[device].mu);
+    for (auto& kv : g_pool[device].free_lists) { drop.insert(drop.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+    g_pool[device].cached_bytes = 0;
+  }
+  for (void* p : drop) (void)hipFree(p);
+}
+
 extern "C" int fmh_device_info(int device, char* h_name, size_t name_cap, int* h_cus, uint64_t* h_mem) {
   FMH_TRY(use_device(device));
   hipDeviceProp_t prop;
@@ -88,12 +173,12 @@ extern "C" int fmh_device_info(int device, char* h_name, size_t name_cap, int* h
 extern "C" int fmh_device_alloc(int device, size_t bytes, void** d_out) {
   if (!d_out) return fail(FMH_ERR_INVALID, "d_out is NULL");
   FMH_TRY(use_device(device));
-  HIP_TRY(hipMalloc(d_out, bytes ? bytes : 16));
+  HIP_TRY(pool_malloc(device, d_out, bytes));
   return FMH_OK;
 }
 extern "C" int fmh_device_free(int device, void* d_ptr) {
   FMH_TRY(use_device(device));
-  HIP_TRY(hipFree(d_ptr));
+  pool_free(device, d_ptr);
   return FMH_OK;
 }
 extern "C" int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream) {
@@ -172,13 +257,13 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
   m->bits_pitch = with_missing ? round_up(m->pitch / 8, 4) : 0;
   m->max_allele = max_allele;
   const size_t bytes = variants * m->pitch;
-  hipError_t e = hipMalloc((void**)&m->data, bytes ? bytes : 16);
+  hipError_t e = pool_malloc(device, (void**)&m->data, bytes);
   if (e == hipSuccess && with_missing) {
     const size_t bb = variants * m->bits_pitch;
-    e = hipMalloc((void**)&m->bits, bb ? bb : 16);
+    e = pool_malloc(device, (void**)&m->bits, bb);
   }
   if (e != hipSuccess) {
-    if (m->data) (void)hipFree(m->data);
+    pool_free(device, m->data);
     delete m;
     return fail(FMH_ERR_HIP, "hipMalloc of %zu-byte matrix failed: %s", bytes, hipGetErrorString(e));
   }
@@ -202,7 +287,7 @@ extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missin
   if (h_missing) {
     const size_t words = (variants * (size_t)m->columns + 63) / 64;
     unsigned long long* d_words = nullptr;
-    e = hipMalloc((void**)&d_words, words * 8);
+    e = pool_malloc(device, (void**)&d_words, words * 8);
     if (e == hipSuccess) e = hipMemcpy(d_words, h_missing, words * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
       const size_t total = variants * m->bits_pitch;
@@ -212,7 +297,7 @@ extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missin
       e = hipGetLastError();
       if (e == hipSuccess) e = hipDeviceSynchronize();
     }
-    if (d_words) (void)hipFree(d_words);
+    pool_free(device, d_words);
     if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "missing-mask upload failed: %s", hipGetErrorString(e)));
   }
   return FMH_OK;
@@ -251,8 +336,8 @@ extern "C" int fmh_matrix_destroy(fmh_matrix* m) {
   if (!m) return FMH_OK;
   if (m->owns) {
     (void)hipSetDevice(m->device);
-    if (m->data) (void)hipFree(m->data);
-    if (m->bits) (void)hipFree(m->bits);
+    pool_free(m->device, m->data);
+    pool_free(m->device, m->bits);
   }
   delete m;
   return FMH_OK;
@@ -385,10 +470,10 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
     }
     g->sizes[p] = cnt;
   }
-  hipError_t e = hipMalloc((void**)&g->masks, staged.size());
+  hipError_t e = pool_malloc(g->device, (void**)&g->masks, staged.size());
   if (e == hipSuccess) e = hipMemcpy(g->masks, staged.data(), staged.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
-    if (g->masks) (void)hipFree(g->masks);
+    pool_free(g->device, g->masks);
     delete g;
     return fail(FMH_ERR_HIP, "group mask upload failed: %s", hipGetErrorString(e));
   }
@@ -399,7 +484,7 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
 extern "C" int fmh_groups_destroy(fmh_groups* g) {
   if (!g) return FMH_OK;
   (void)hipSetDevice(g->device);
-  if (g->masks) (void)hipFree(g->masks);
+  pool_free(g->device, g->masks);
   delete g;
   return FMH_OK;
 }
@@ -798,11 +883,12 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
 
 // RAII for the scratch of one call
 struct DeviceScratch {
+  int device = 0;
   std::vector<void*> ptrs;
-  ~DeviceScratch() { for (void* p : ptrs) (void)hipFree(p); }
+  ~DeviceScratch() { for (void* p : ptrs) pool_free(device, p); }
   template <class T> int get(T** out, size_t count) {
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(pool_malloc(device, &p, std::max<size_t>(count, 1) * sizeof(T)));
     ptrs.push_back(p);
     *out = (T*)p;
     return FMH_OK;
@@ -826,6 +912,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   const bool general = m->max_allele > 1;
   const int n_alleles = (int)m->max_allele + 1;
   DeviceScratch scratch;
+  scratch.device = m->device;
   uint32_t *called = d_group_called, *alt = nullptr, *acounts = nullptr, *n_all = nullptr, *all_alt = nullptr;
   if (!called) FMH_TRY(scratch.get(&called, G * row_count));
   FMH_TRY(scratch.get(&n_all, row_count));
@@ -983,6 +1070,7 @@ extern "C" int fmh_device_release_scratch(int device) {
   if (w->pd_planes) (void)hipFree(w->pd_planes);
   w->pd_planes = nullptr;
   w->pd_planes_bytes = 0;
+  pool_trim(device);
   return FMH_OK;
 }
 

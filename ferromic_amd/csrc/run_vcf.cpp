@@ -14,7 +14,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <dirent.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -74,17 +76,61 @@ unsigned worker_threads() {
   }();
   return n;
 }
+// Persistent workers: parallel stages are entered once per block of VCF text, per matrix and per region's tracks, so
+// thread start-up per stage would dominate configs with many small regions.  Callers are the main thread or the
+// per-GPU region workers; pool workers never enter parallel_for themselves.
+class ThreadPool {
+ public:
+  explicit ThreadPool(unsigned n) {
+    for (unsigned i = 0; i < n; ++i)
+      workers_.emplace_back([this] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lock(m_);
+            cv_.wait(lock, [this] { return stop_ || !jobs_.empty(); });
+            if (stop_ && jobs_.empty()) return;
+            job = std::move(jobs_.front());
+            jobs_.pop_front();
+          }
+          job();
+        }
+      });
+  }
+  ~ThreadPool() {
+    { std::lock_guard<std::mutex> lock(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  void submit(std::function<void()> job) {
+    { std::lock_guard<std::mutex> lock(m_); jobs_.push_back(std::move(job)); }
+    cv_.notify_one();
+  }
+ private:
+  vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> jobs_;
+  bool stop_ = false;
+};
+ThreadPool& thread_pool() {
+  static ThreadPool pool(worker_threads());
+  return pool;
+}
 template <class F> void parallel_for(unsigned tasks, F&& fn) {
   if (tasks <= 1) { if (tasks) fn(0u); return; }
-  vector<std::thread> pool;
-  std::exception_ptr failure;
-  std::mutex m;
-  for (unsigned t = 0; t < tasks; ++t)
-    pool.emplace_back([&, t] {
-      try { fn(t); } catch (...) { std::lock_guard<std::mutex> lock(m); if (!failure) failure = std::current_exception(); }
-    });
-  for (auto& th : pool) th.join();
-  if (failure) std::rethrow_exception(failure);
+  struct Sync { std::mutex m; std::condition_variable cv; unsigned left; std::exception_ptr failure; } sync;
+  sync.left = tasks;
+  auto run = [&](unsigned t) {
+    try { fn(t); } catch (...) { std::lock_guard<std::mutex> lock(sync.m); if (!sync.failure) sync.failure = std::current_exception(); }
+    std::lock_guard<std::mutex> lock(sync.m);
+    if (--sync.left == 0) sync.cv.notify_all();
+  };
+  for (unsigned t = 1; t < tasks; ++t) thread_pool().submit([&run, t] { run(t); });
+  run(0u);  // the caller takes a share
+  std::unique_lock<std::mutex> lock(sync.m);
+  sync.cv.wait(lock, [&] { return sync.left == 0; });
+  if (sync.failure) std::rethrow_exception(sync.failure);
 }
 
 // ---- small string helpers ------------------------------------------------------------------------
@@ -812,7 +858,8 @@ RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, in
   vector<uint64_t> missing((total + 63) / 64, 0);
   // rows are dealt out in runs of 64 so that no two threads share a 64-bit word of the missing mask
   const size_t runs = (vs.size() + 63) / 64;
-  const unsigned T = (unsigned)std::min<size_t>(worker_threads(), runs);
+  // threads only when there is enough to pack: a config of many small regions must not pay thread start-up per region
+  const unsigned T = total < ((size_t)4 << 20) ? 1u : (unsigned)std::min<size_t>(worker_threads(), runs);
   vector<uint8_t> t_max(T, 0), t_missing(T, 0);
   parallel_for(T, [&](unsigned t) {
     const size_t r0 = runs * t / T * 64, r1 = std::min(vs.size(), runs * (t + 1) / T * 64);
@@ -1291,7 +1338,10 @@ void gz_append(const string& path, const string& text) {  // open_append_compres
 string gzip_member(const string& text) {
   z_stream z;
   memset(&z, 0, sizeof z);
-  if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
+  // Level 1: the tracks are long runs of "0," / "NA," around sparse values; the default level spends ~1 ms per 40 kB of such
+  // text searching for longer matches and gains a few hundred bytes.  Readers see the same text either way.
+  static const int level = getenv("FERROMIC_GZIP_LEVEL") ? atoi(getenv("FERROMIC_GZIP_LEVEL")) : 1;
+  if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
   string out;
   out.resize(deflateBound(&z, (uLong)std::min<size_t>(text.size(), (size_t)1 << 30)) + 64);
   size_t in_off = 0, out_off = 0;
@@ -1322,25 +1372,32 @@ string gzip_member(const string& text) {
 // its own gzip member, in track order (the files are multi-member already: one member per region in the
 // reference; readers see the same decompressed text).
 typedef std::function<string()> TrackFn;
-void append_tracks(const string& path, const vector<TrackFn>& tracks) {
-  if (tracks.empty()) return;
-  vector<string> members(tracks.size());
+// `files` = (path, tracks) pairs; all tracks of all files form one parallel batch
+void append_tracks(const vector<std::pair<string, vector<TrackFn>>>& files) {
+  vector<std::pair<size_t, size_t>> jobs;  // (file, track)
+  for (size_t f = 0; f < files.size(); ++f) for (size_t t = 0; t < files[f].second.size(); ++t) jobs.push_back({f, t});
+  if (jobs.empty()) return;
+  vector<string> members(jobs.size());
   std::atomic<size_t> next{0};
-  parallel_for((unsigned)std::min<size_t>(worker_threads(), tracks.size()), [&](unsigned) {
+  parallel_for((unsigned)std::min<size_t>(worker_threads(), jobs.size()), [&](unsigned) {
     for (;;) {
       const size_t i = next.fetch_add(1);
-      if (i >= tracks.size()) break;
-      const string text = tracks[i]();
+      if (i >= jobs.size()) break;
+      const string text = files[jobs[i].first].second[jobs[i].second]();
       if (!text.empty()) members[i] = gzip_member(text);
     }
   });
-  FILE* f = nullptr;
-  for (auto& m : members) {
-    if (m.empty()) continue;
-    if (!f && !(f = fopen(path.c_str(), "ab"))) throw Error("cannot open " + path);
-    if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); throw Error("write failed: " + path); }
+  size_t i = 0;
+  for (size_t fi = 0; fi < files.size(); ++fi) {
+    FILE* f = nullptr;
+    for (size_t t = 0; t < files[fi].second.size(); ++t, ++i) {
+      const string& m = members[i];
+      if (m.empty()) continue;
+      if (!f && !(f = fopen(files[fi].first.c_str(), "ab"))) throw Error("cannot open " + files[fi].first);
+      if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); throw Error("write failed: " + files[fi].first); }
+    }
+    if (f) fclose(f);
   }
-  if (f) fclose(f);
 }
 
 struct RegionOutput {
@@ -1447,6 +1504,7 @@ struct Args {
   unsigned min_gq = 30;
   bool enable_fst = false, enable_pca = false;
   int device = 0;
+  int workers_per_device = 4;  // region workers per GPU: host-side packing, downloads and writers of one region overlap the sweeps of another
   bool ingest_only = false;  // diagnostic: parse the inputs, report counts, compute nothing (needs no GPU)
   vector<int> devices;  // --devices: one worker thread per entry, config regions dealt out dynamically
 };
@@ -1692,8 +1750,7 @@ int run(const Args& args) {
           std::optional<RegionOutput>& res = done[emitted];
           if (res) {
             csv << join(res->csv_row, ',', true) << "\n";
-            append_tracks(div_path, diversity_tracks(*res));
-            append_tracks(fst_path, fst_tracks(*res));
+            append_tracks({{div_path, diversity_tracks(*res)}, {fst_path, fst_tracks(*res)}});
             for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
             for (auto& r : res->wc_rows) wc_rows.push_back(r);
             res.reset();
@@ -1717,11 +1774,15 @@ int run(const Args& args) {
           emit_ready();
         }
       };
-      if (args.devices.size() <= 1) {
-        worker(args.devices.empty() ? args.device : args.devices[0]);
+      vector<int> worker_devices;
+      for (int d : args.devices.empty() ? vector<int>{args.device} : args.devices)
+        for (int k = 0; k < std::max(1, args.workers_per_device); ++k) worker_devices.push_back(d);
+      if (worker_devices.size() > todo.size()) worker_devices.resize(std::max<size_t>(todo.size(), 1));
+      if (worker_devices.size() <= 1) {
+        worker(worker_devices.empty() ? args.device : worker_devices[0]);
       } else {
         vector<std::thread> pool;
-        for (int d : args.devices) pool.emplace_back(worker, d);
+        for (int d : worker_devices) pool.emplace_back(worker, d);
         for (auto& t : pool) t.join();
       }
     } catch (const Error& e) {
@@ -1777,16 +1838,18 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--fst") a.enable_fst = true;
     else if (k == "--fst_populations") a.fst_populations = value();
     else if (k == "--ingest_only") a.ingest_only = true;
+    else if (k == "--workers_per_device") a.workers_per_device = std::max(1, atoi(value().c_str()));
     else if (k == "--device") a.device = atoi(value().c_str());
     else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)
       const string v2 = value();
       if (v2.find(',') == string::npos) { for (int d = 0; d < atoi(v2.c_str()); ++d) a.devices.push_back(d); }
       else for (auto& t : split(v2, ',')) if (!t.empty()) a.devices.push_back(atoi(t.c_str()));
       if (a.devices.empty()) throw Error("invalid --devices");
+      if (v2.find(',') == string::npos && atoi(v2.c_str()) < 1) throw Error("invalid --devices");
     }
     else if (k == "--help" || k == "-h") {
       printf("run_vcf --vcf_folder DIR --reference FA --gtf GTF [--config_file TSV | --chr C [--region S-E]] [--output_file CSV]\n"
-             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--fst_populations CSV] [--device N | --devices N|a,b,c]\n");
+             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--fst_populations CSV] [--device N | --devices N|a,b,c] [--workers_per_device 4]\n");
       exit(0);
     } else throw Error("unexpected argument '" + k + "'");
   }
