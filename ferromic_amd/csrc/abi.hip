@@ -819,6 +819,40 @@ extern "C" int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, siz
   return FMH_OK;
 }
 
+// RAII for the scratch of one call
+struct DeviceScratch {
+  int device = 0;
+  std::vector<void*> ptrs;
+  ~DeviceScratch() { for (void* p : ptrs) pool_free(device, p); }
+  template <class T> int get(T** out, size_t count) {
+    void* p = nullptr;
+    HIP_TRY(pool_malloc(device, &p, std::max<size_t>(count, 1) * sizeof(T)));
+    ptrs.push_back(p);
+    *out = (T*)p;
+    return FMH_OK;
+  }
+};
+
+// regional W&C sums per slot from the per-site tracks (two small launches, deterministic)
+static int wc_slot_sums(DeviceScratch& scratch, hipStream_t st, size_t nslots, size_t rows, const double* d_a, const double* d_b,
+                        const uint8_t* d_state, double** sa, double** sb, unsigned long long** si) {
+  const size_t chunks = std::max<size_t>(1, std::min<size_t>(64, (rows + 32767) / 32768));
+  double *pa = nullptr, *pb = nullptr;
+  unsigned long long* pi = nullptr;
+  FMH_TRY(scratch.get(&pa, nslots * chunks));
+  FMH_TRY(scratch.get(&pb, nslots * chunks));
+  FMH_TRY(scratch.get(&pi, nslots * chunks));
+  FMH_TRY(scratch.get(sa, nslots));
+  FMH_TRY(scratch.get(sb, nslots));
+  FMH_TRY(scratch.get(si, nslots));
+  hipLaunchKernelGGL(wc_slot_reduce_kernel, dim3((unsigned)nslots, (unsigned)chunks), dim3(256), 0, st, rows, d_a, d_b, d_state, pa, pb, pi);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(wc_slot_finalize_kernel, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, st, nslots, chunks, (const double*)pa,
+                     (const double*)pb, (const unsigned long long*)pi, *sa, *sb, *si);
+  HIP_TRY(hipGetLastError());
+  return FMH_OK;
+}
+
 extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a,
                             double* d_b, uint8_t* d_state, uint32_t* d_group_called, fmh_wc_totals* h_totals,
                             void* stream) {
@@ -864,6 +898,31 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
     }
     return FMH_OK;
   }
+  if (g && g->padded == 8 && m && row_count > 0) {
+    // 5..8 groups: the kernel keeps no per-lane regional accumulators (29 slots would be 174 registers); the regional
+    // sums come from the per-site tracks, which therefore must exist
+    DeviceScratch scratch;
+    scratch.device = m->device;
+    const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
+    if (!a.wc_a) FMH_TRY(scratch.get(&a.wc_a, nslots * row_count));
+    if (!a.wc_b) FMH_TRY(scratch.get(&a.wc_b, nslots * row_count));
+    if (!a.wc_state) FMH_TRY(scratch.get(&a.wc_state, nslots * row_count));
+    SweepResult r8;
+    FMH_TRY(run_sweep(m, g, kModeWc, a, stream, &r8));
+    double *sa = nullptr, *sb = nullptr;
+    unsigned long long* si = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    FMH_TRY(wc_slot_sums(scratch, st, nslots, row_count, a.wc_a, a.wc_b, a.wc_state, &sa, &sb, &si));
+    if (h_totals) {
+      memset(h_totals, 0, sizeof *h_totals);
+      h_totals->sites_attempted = row_count;
+      HIP_TRY(hipMemcpyAsync(h_totals->sum_a, sa, nslots * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_totals->sum_b, sb, nslots * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_totals->informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return FMH_OK;
+  }
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeWc, a, stream, &r));
   if (h_totals) {
@@ -880,20 +939,6 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   }
   return FMH_OK;
 }
-
-// RAII for the scratch of one call
-struct DeviceScratch {
-  int device = 0;
-  std::vector<void*> ptrs;
-  ~DeviceScratch() { for (void* p : ptrs) pool_free(device, p); }
-  template <class T> int get(T** out, size_t count) {
-    void* p = nullptr;
-    HIP_TRY(pool_malloc(device, &p, std::max<size_t>(count, 1) * sizeof(T)));
-    ptrs.push_back(p);
-    *out = (T*)p;
-    return FMH_OK;
-  }
-};
 
 extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_mask, int n_groups, size_t row_begin,
                                  size_t row_count, double* d_a, double* d_b, uint8_t* d_state, uint32_t* d_group_called,
@@ -961,12 +1006,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   HIP_TRY(hipGetLastError());
   double *sa = nullptr, *sb = nullptr;
   unsigned long long* si = nullptr;
-  FMH_TRY(scratch.get(&sa, nslots));
-  FMH_TRY(scratch.get(&sb, nslots));
-  FMH_TRY(scratch.get(&si, nslots));
-  hipLaunchKernelGGL(wc_slot_reduce_kernel, dim3((unsigned)nslots), dim3(256), 0, st, row_count, (const double*)d_a, (const double*)d_b,
-                     (const uint8_t*)d_state, sa, sb, si);
-  HIP_TRY(hipGetLastError());
+  FMH_TRY(wc_slot_sums(scratch, st, nslots, row_count, d_a, d_b, d_state, &sa, &sb, &si));
   if (h_sum_a) HIP_TRY(hipMemcpyAsync(h_sum_a, sa, nslots * 8, hipMemcpyDeviceToHost, st));
   if (h_sum_b) HIP_TRY(hipMemcpyAsync(h_sum_b, sb, nslots * 8, hipMemcpyDeviceToHost, st));
   if (h_informative_sites) HIP_TRY(hipMemcpyAsync(h_informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));

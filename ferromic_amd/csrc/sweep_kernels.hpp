@@ -269,10 +269,11 @@ struct WcSite {
 
 // calculate_fst_wc_at_site_with_membership, stats.rs:1893-1985, for NA alleles of one site at once.
 // c[al][i] = calls of allele `al` in group i, n[i] = called haplotypes of group i.  Slot-major: the shape of a
-// slot is obtained once (kernel argument when PRE, else computed here) and applied to every allele; each
-// accumulator still receives its per-allele terms in allele order.
-template <int P, int NA, bool PRE>
-__device__ __forceinline__ void wc_add_alleles(const SweepArgs& A, const uint32_t (&n)[P], const uint32_t (&c)[NA][P], WcSite<P>& w) {
+// slot is obtained once (kernel argument when PRE, else computed here) and applied to every allele; the slot's a and b
+// are the sums of the per-allele terms in allele order.  emit(k, a, b, has_data) is called for EVERY slot: k = 0 overall
+// (has_data always; (0, 0) when fewer than two groups have data), k >= 1 pairs (has_data = both groups have data).
+template <int P, int NA, bool PRE, class Emit>
+__device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint32_t (&n)[P], const uint32_t (&c)[NA][P], Emit&& emit) {
   bool use[P];
   double nd[P], freq[NA][P];
   int valid = 0;
@@ -285,33 +286,38 @@ __device__ __forceinline__ void wc_add_alleles(const SweepArgs& A, const uint32_
 #pragma unroll
     for (int al = 0; al < NA; ++al) freq[al][i] = use[i] ? (double)c[al][i] / nd[i] : 0.0;
   }
-  if (valid < 2) return;  // stats.rs:1925-1930
   {
-    WcShape sh;
-    if constexpr (PRE) sh = A.wc_shape[0]; else sh = wc_shape<P>(n, use);
-    if (sh.live) {
+    double wa = 0.0, wb = 0.0;
+    if (valid >= 2) {  // stats.rs:1925-1930
+      WcShape sh;
+      if constexpr (PRE) sh = A.wc_shape[0]; else sh = wc_shape<P>(n, use);
+      if (sh.live) {
 #pragma unroll
-      for (int al = 0; al < NA; ++al) {
-        unsigned long long total_target = 0;
+        for (int al = 0; al < NA; ++al) {
+          unsigned long long total_target = 0;
 #pragma unroll
-        for (int i = 0; i < P; ++i) if (use[i]) total_target += c[al][i];
-        double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
-        double num = 0.0;
+          for (int i = 0; i < P; ++i) if (use[i]) total_target += c[al][i];
+          double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
+          double num = 0.0;
 #pragma unroll
-        for (int i = 0; i < P; ++i) if (use[i]) { double diff_p = freq[al][i] - global_freq; num += nd[i] * diff_p * diff_p; }
-        double ca, cb;
-        wc_apply(sh, num, global_freq, ca, cb);
-        w.a[0] += ca;
-        w.b[0] += cb;
+          for (int i = 0; i < P; ++i) if (use[i]) { double diff_p = freq[al][i] - global_freq; num += nd[i] * diff_p * diff_p; }
+          double ca, cb;
+          wc_apply(sh, num, global_freq, ca, cb);
+          wa += ca;
+          wb += cb;
+        }
       }
     }
+    emit(0, wa, wb, true);
   }
   int k = 1;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
 #pragma unroll
     for (int j = i + 1; j < P; ++j) {
-      if (use[i] && use[j]) {  // stats.rs:1950-1952
+      double wa = 0.0, wb = 0.0;
+      const bool both = use[i] && use[j];  // stats.rs:1950-1952
+      if (both && valid >= 2) {
         WcShape sh;
         if constexpr (PRE) {
           sh = A.wc_shape[k];
@@ -330,14 +336,23 @@ __device__ __forceinline__ void wc_add_alleles(const SweepArgs& A, const uint32_
             { double diff_p = freq[al][j] - pair_global; num += nd[j] * diff_p * diff_p; }
             double pa, pb;
             wc_apply(sh, num, pair_global, pa, pb);
-            w.a[k] += pa;
-            w.b[k] += pb;
+            wa += pa;
+            wb += pb;
           }
         }
       }
+      emit(k, wa, wb, both);
       ++k;
     }
   }
+}
+
+// allele-at-a-time accumulation (multi-allelic path): the per-allele terms are added to the site's slot sums
+template <int P, int NA, bool PRE>
+__device__ __forceinline__ void wc_add_alleles(const SweepArgs& A, const uint32_t (&n)[P], const uint32_t (&c)[NA][P], WcSite<P>& w) {
+  wc_for_each_slot<P, NA, PRE>(A, n, c, [&](int k, double a, double b, bool has) {
+    if (has) { w.a[k] += a; w.b[k] += b; }
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,9 +583,12 @@ struct LaneTotals {
   unsigned long long pop_unc[P];
   double hud[kHudF64];
   unsigned long long hud_u[kHudU64];
-  double wc_a[(MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1];
-  double wc_b[(MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1];
-  unsigned long long wc_inf[(MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1];
+  // W&C regional sums per slot; for P = 8 (29 slots = 174 registers of accumulators) they are NOT kept per lane: the
+  // host sums the per-site tracks with wc_slot_reduce_kernel instead (kWcLaneTotals)
+  static constexpr bool kWcLaneTotals = (MODE & kModeWc) != 0 && P < 8;
+  double wc_a[kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1];
+  double wc_b[kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1];
+  unsigned long long wc_inf[kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1];
 
   __device__ __forceinline__ void clear() {
 #pragma unroll
@@ -579,7 +597,7 @@ struct LaneTotals {
     for (int i = 0; i < kHudF64; ++i) hud[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < kHudU64; ++i) hud_u[i] = 0;
-    constexpr int NW = (MODE & kModeWc) ? 1 + (P * (P - 1)) / 2 : 1;
+    constexpr int NW = kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { wc_a[i] = 0.0; wc_b[i] = 0.0; wc_inf[i] = 0; }
   }
@@ -719,39 +737,44 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
     constexpr int NW = 1 + (P * (P - 1)) / 2;
     // stats.rs:1987-2031.  pop_sizes_populated == at least one allele present among ALL samples.
     const bool any_allele = t.n_all != 0;
-    uint8_t st[NW];
-    double oa[NW], ob[NW];
-    if (!any_allele) {
+    // one slot: state, stores, regional sums.  A pair has an entry iff both totals > 0 (the overall pass was then not
+    // skipped either: valid_groups >= 2 is implied)
+    auto finish = [&](int k, double a, double b, bool has) {
+      uint8_t st;
+      double oa, ob;
+      if (any_allele && has) { st = wc_classify(a, b); oa = a; ob = b; }
+      else { st = 3; oa = 0.0; ob = 0.0; }
+      if (row_ok) {
+        const int slot = A.wc_slot[k];
+        if (slot >= 0) {
+          if (A.wc_a) site_store(A.wc_a + ((size_t)slot * A.row_count + out_idx), oa);
+          if (A.wc_b) site_store(A.wc_b + ((size_t)slot * A.row_count + out_idx), ob);
+          if (A.wc_state) site_store(A.wc_state + ((size_t)slot * A.row_count + out_idx), st);
+        }
+        if constexpr (LaneTotals<P, MODE>::kWcLaneTotals) {
+          if (st != 3) { T.wc_a[k] += oa; T.wc_b[k] += ob; T.wc_inf[k] += 1; }  // 2172-2203
+        }
+      }
+    };
+    if constexpr (!GENERAL) {
+      // biallelic: allele 0 count = n - alt, allele 1 count = alt; every slot is computed and finished in turn
+      uint32_t cc[2][P];
 #pragma unroll
-      for (int k = 0; k < NW; ++k) { st[k] = 3; oa[k] = 0.0; ob[k] = 0.0; }
+      for (int p = 0; p < P; ++p) { cc[1][p] = t.alt[p]; cc[0][p] = t.n[p] - t.alt[p]; }
+      wc_for_each_slot<P, 2, !MISSING>(A, t.n, cc, finish);
     } else {
-      st[0] = wc_classify(wc.a[0], wc.b[0]);
-      oa[0] = wc.a[0]; ob[0] = wc.b[0];
-      // a pair has an entry iff some allele pass saw both totals > 0 AND the overall pass was not
-      // skipped (valid_groups >= 2 is implied by both totals > 0)
+      finish(0, wc.a[0], wc.b[0], true);
       int k = 1;
 #pragma unroll
       for (int i = 0; i < P; ++i) {
 #pragma unroll
         for (int j = i + 1; j < P; ++j) {
-          if (t.n[i] != 0 && t.n[j] != 0) { st[k] = wc_classify(wc.a[k], wc.b[k]); oa[k] = wc.a[k]; ob[k] = wc.b[k]; }
-          else { st[k] = 3; oa[k] = 0.0; ob[k] = 0.0; }
+          finish(k, wc.a[k], wc.b[k], t.n[i] != 0 && t.n[j] != 0);
           ++k;
         }
       }
     }
-    if (row_ok) {
-#pragma unroll
-      for (int k = 0; k < NW; ++k) {
-        const int slot = A.wc_slot[k];
-        if (slot >= 0) {
-          if (A.wc_a) site_store(A.wc_a + ((size_t)slot * A.row_count + out_idx), oa[k]);
-          if (A.wc_b) site_store(A.wc_b + ((size_t)slot * A.row_count + out_idx), ob[k]);
-          if (A.wc_state) site_store(A.wc_state + ((size_t)slot * A.row_count + out_idx), st[k]);
-        }
-        if (st[k] != 3) { T.wc_a[k] += oa[k]; T.wc_b[k] += ob[k]; T.wc_inf[k] += 1; }  // 2172-2203
-      }
-    }
+    (void)NW;
   }
 }
 
@@ -916,12 +939,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
           if (c1[0] != 0 && c1[1] != 0) hud_dot += ((double)c1[0] * inv1) * ((double)c1[1] * inv2);
         }
       }
-      if constexpr ((MODE & kModeWc) != 0) {
-        uint32_t cc[2][P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) { cc[0][p] = c0[p]; cc[1][p] = c1[p]; }
-        wc_add_alleles<P, 2, !MISSING>(A, mine.n, cc, wc);
-      }
+      // W&C of a biallelic site is computed slot by slot inside site_epilogue (no per-site slot arrays in registers)
     }
 
     const size_t my_rel = tile_row0 + lane;
@@ -937,9 +955,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   if (lane < kMaxU64) s_u64[wave][lane] = 0;
   __syncthreads();
   if constexpr ((MODE & kModeWc) != 0) {
-    constexpr int NW = 1 + (P * (P - 1)) / 2;
+    if constexpr (LaneTotals<P, MODE>::kWcLaneTotals) {
+      constexpr int NW = 1 + (P * (P - 1)) / 2;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) { put_f64(kOffWcA + k, T.wc_a[k]); put_f64(kOffWcB + k, T.wc_b[k]); put_u64(kOffWcInf + k, T.wc_inf[k]); }
+      for (int k = 0; k < NW; ++k) { put_f64(kOffWcA + k, T.wc_a[k]); put_f64(kOffWcB + k, T.wc_b[k]); put_u64(kOffWcInf + k, T.wc_inf[k]); }
+    }
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p) { put_f64(kOffPopF64 + p, T.pop_pi[p]); put_u64(kOffPopSeg + p, T.pop_seg[p]); put_u64(kOffPopUnc + p, T.pop_unc[p]); }
@@ -1457,15 +1477,18 @@ __global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_allele
   }
 }
 
-// Regional sums per slot (calculate_overall_fst_wc, stats.rs:2172-2229): one workgroup per slot, thread t adds sites
-// t, t+256, ... in ascending order, fixed LDS tree: deterministic.
+// Regional sums per slot (calculate_overall_fst_wc, stats.rs:2172-2229).  Grid (slot, chunk): a workgroup sums one chunk
+// of the sites of one slot (thread t takes sites t, t+256, ... of the chunk in ascending order, fixed LDS tree) into
+// partial[slot][chunk]; wc_slot_finalize_kernel adds the chunks in ascending order.  Deterministic for a given launch.
 __global__ __launch_bounds__(256) void wc_slot_reduce_kernel(size_t rows, const double* __restrict__ a, const double* __restrict__ b,
-                                                             const uint8_t* __restrict__ state, double* __restrict__ sum_a,
-                                                             double* __restrict__ sum_b, unsigned long long* __restrict__ informative) {
-  const size_t k = blockIdx.x;
+                                                             const uint8_t* __restrict__ state, double* __restrict__ part_a,
+                                                             double* __restrict__ part_b, unsigned long long* __restrict__ part_inf) {
+  const size_t k = blockIdx.x, chunks = gridDim.y, c = blockIdx.y;
+  const size_t per = (rows + chunks - 1) / chunks;
+  const size_t s0 = c * per, s1 = s0 + per < rows ? s0 + per : rows;
   double va = 0.0, vb = 0.0;
   unsigned long long vi = 0;
-  for (size_t s = threadIdx.x; s < rows; s += 256)
+  for (size_t s = s0 + threadIdx.x; s < s1; s += 256)
     if (state[k * rows + s] != 3) { va += a[k * rows + s]; vb += b[k * rows + s]; ++vi; }
   __shared__ double la[256], lb[256];
   __shared__ unsigned long long li[256];
@@ -1475,7 +1498,18 @@ __global__ __launch_bounds__(256) void wc_slot_reduce_kernel(size_t rows, const 
     if ((int)threadIdx.x < w) { la[threadIdx.x] += la[threadIdx.x + w]; lb[threadIdx.x] += lb[threadIdx.x + w]; li[threadIdx.x] += li[threadIdx.x + w]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { sum_a[k] = la[0]; sum_b[k] = lb[0]; informative[k] = li[0]; }
+  if (threadIdx.x == 0) { part_a[k * chunks + c] = la[0]; part_b[k * chunks + c] = lb[0]; part_inf[k * chunks + c] = li[0]; }
+}
+
+__global__ void wc_slot_finalize_kernel(size_t nslots, size_t chunks, const double* __restrict__ part_a, const double* __restrict__ part_b,
+                                        const unsigned long long* __restrict__ part_inf, double* __restrict__ sum_a,
+                                        double* __restrict__ sum_b, unsigned long long* __restrict__ informative) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nslots) return;
+  double va = 0.0, vb = 0.0;
+  unsigned long long vi = 0;
+  for (size_t c = 0; c < chunks; ++c) { va += part_a[k * chunks + c]; vb += part_b[k * chunks + c]; vi += part_inf[k * chunks + c]; }
+  sum_a[k] = va; sum_b[k] = vb; informative[k] = vi;
 }
 
 }  // namespace fmh
