@@ -549,13 +549,16 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uin
   const uint32_t nvec = mv.nvec;
   const uint32_t a4 = a * 0x01010101u;
   if (row_ok) {
-#pragma unroll 2
-    for (uint32_t v = gl; v < nvec; v += 16) {
-      uint4 g = load_vec(row_ptr + (size_t)v * 16);
+    // the same trip count for every lane of the group (lanes past the row re-read its last vector; their mask
+    // vectors are zero): the 16-lane DPP reduction below must see a converged row
+    for (uint32_t v0 = 0; v0 < nvec; v0 += 16) {
+      const uint32_t v = v0 + (uint32_t)gl;
+      const uint32_t vc = v < nvec ? v : nvec - 1;
+      uint4 g = load_vec(row_ptr + (size_t)vc * 16);
       uint4 e;
       e.x = eq_bytes(g.x, a4); e.y = eq_bytes(g.y, a4); e.z = eq_bytes(g.z, a4); e.w = eq_bytes(g.w, a4);
       if (MISSING) {
-        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)v * 2);
+        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)vc * 2);
         uint4 cb = called_bytes(bits16);
         e.x &= cb.x; e.y &= cb.y; e.z &= cb.z; e.w &= cb.w;
       }

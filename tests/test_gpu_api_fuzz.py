@@ -162,3 +162,56 @@ def test_random_cohort(seed):
     e_pd = R.calculate_pairwise_differences(ov, n, L)
     g_pd = fm.pairwise_differences(dict_variants, n, L)
     assert [(p.sample_i, p.sample_j, p.differences, p.comparable_sites) for p in g_pd] == [(i, j, d, c) for (i, j), d, c in e_pd]
+
+
+NUMPY_CASES = int(os.environ.get("FERROMIC_FUZZ_NUMPY_CASES", "120"))
+
+
+@pytest.mark.parametrize("seed", range(NUMPY_CASES))
+def test_random_numpy_population(seed):
+    """Population.from_numpy over random dtypes / ploidies / missing rates / allele ranges (incl. 255 and empty shapes):
+    summary, dense and sparse arms of lib.rs:777-799 + stats.rs:3435-3599 against the oracle's same selection."""
+    import numpy as np
+
+    rng = np.random.default_rng(5000 + seed)
+    dtype = [np.uint8, np.int8, np.uint16, np.int16][seed % 4]
+    S = int(rng.choice([0, 1, 2, 7, 33]))
+    N = int(rng.integers(1, 9))
+    ploidy = int(rng.choice([1, 2, 2, 2, 3]))
+    max_allele = int(rng.choice([1, 1, 2, 3]))
+    g = rng.integers(0, max_allele + 1, size=(S, N, ploidy)).astype(dtype)
+    if np.dtype(dtype).kind == "i" and rng.random() < 0.6:
+        g[rng.random((S, N, ploidy)) < 0.12] = -1
+    if np.dtype(dtype) in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.int16)) and rng.random() < 0.15 and g.size:
+        g.reshape(-1)[int(rng.integers(0, g.size))] = 255   # the sparse sentinel value as an allele
+    positions = np.cumsum(rng.integers(1, 30, size=S)).astype(rng.choice([np.int64, np.int32, np.uint32, np.uint64]))
+    L = int(positions[-1] - positions[0] + 1) if S else 10
+    names = [f"n{i}" for i in range(N)]
+    sides = range(min(ploidy, 2))
+    all_haps = [(s, side) for s in range(N) for side in sides]
+    cut = int(rng.integers(0, len(all_haps) + 1))
+    h1, h2 = all_haps[:cut], all_haps[cut:]
+    base = fm.Population.from_numpy("all", g, positions, all_haps, L, sample_names=names)
+    p1, p2 = base.with_haplotypes(1, h1), base.with_haplotypes(2, h2)
+    variants, dense = R.convert_numeric_array(g, [int(x) for x in positions])
+    o_all, o1, o2 = (R.population_context_like_lib(i, variants, hl, names, L, dense) for i, hl in enumerate((all_haps, h1, h2)))
+    for a, b in ((base, o_all), (p1, o1), (p2, o2)):
+        assert a.variant_count == S
+        assert a.segregating_sites() == R.count_segregating_sites_for_population(b)
+        assert same_float(a.nucleotide_diversity(), R.calculate_pi_for_population(b))
+    got, exp = call_both(lambda: fm.hudson_fst(p1, p2), lambda: R.calculate_hudson_fst_for_pair(o1, o2))
+    if exp is not None:
+        for f in ("fst", "d_xy", "pi_pop1", "pi_pop2", "pi_xy_avg"):
+            assert same_float(getattr(got, f), getattr(exp, f)), f
+    got, exp = call_both(lambda: fm.hudson_dxy(p1, p2).d_xy, lambda: R.calculate_d_xy_hudson(o1, o2))
+    assert same_float(got, exp)
+    if S:
+        region = (int(positions[0]), int(positions[min(S - 1, 20)]))
+        got, exp = call_both(lambda: fm.hudson_fst_with_sites(p1, p2, region),
+                             lambda: R.calculate_hudson_fst_for_pair_with_sites(o1, o2, R.QueryRegion(*region)))
+        if exp is not None:
+            assert same_float(got[0].fst, exp[0].fst) and len(got[1]) == len(exp[1])
+            for gs, es in zip(got[1], exp[1]):
+                assert (gs.position, gs.n1_called, gs.n2_called) == (es.position, es.n1_called, es.n2_called)
+                assert same_float(gs.fst, es.fst, exact=True) and same_float(gs.d_xy, es.d_xy, exact=True)
+                assert same_float(gs.pi_pop1, es.pi_pop1, exact=True) and same_float(gs.pi_pop2, es.pi_pop2, exact=True)
