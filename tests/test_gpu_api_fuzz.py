@@ -21,7 +21,7 @@ CASES = int(os.environ.get("FERROMIC_FUZZ_CASES", "300"))
 
 def random_cohort(rng: random.Random):
     S = rng.choice([0, 1, 2, 3, 5, 8, 12])
-    N = rng.randint(1, 6)
+    N = rng.randint(1, 6) if rng.random() < 0.8 else rng.randint(7, 14)
     weird = rng.random() < 0.3
     variants = []
     pos = rng.randint(0, 5)
@@ -34,7 +34,7 @@ def random_cohort(rng: random.Random):
             def allele():
                 if weird and rng.random() < 0.03:
                     return 255
-                return rng.choice([0, 0, 1, 1, 2] if weird else [0, 1])
+                return rng.choice(([0, 0, 1, 1, 2] if rng.random() < 0.7 else [0, 1, 3, 5, 6]) if weird else [0, 1])
 
             if r < 0.10:
                 genos.append(None)
@@ -138,10 +138,11 @@ def test_random_cohort(seed):
 
     if names:
         groups = {}
+        top_group = rng.choice([1, 2, 2, 4, 9])   # up to ten haplotype groups: beyond eight the counts path
         for i, name in enumerate(names):
             if rng.random() < 0.85:
                 key = name if rng.random() < 0.7 else name.rsplit("_", 1)[-1]   # alias lookup (process.rs:1198-1241)
-                groups[key] = (rng.randint(0, 2), rng.randint(0, 2))
+                groups[key] = (rng.randint(0, top_group), rng.randint(0, top_group))
         e_wc = R.calculate_fst_wc_haplotype_groups(ov, names, groups, R.QueryRegion(*region))
         g_wc = fm.wc_fst(dict_variants, names, groups, region)
         assert g_wc.overall_fst.state == e_wc.overall_fst.state and g_wc.overall_fst.sites == e_wc.overall_fst.sites
