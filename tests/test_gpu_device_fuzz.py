@@ -27,7 +27,7 @@ def test_random_geometry_counts(dev, seed):
     rng = np.random.default_rng(9000 + seed)
     N = int(rng.choice(WIDTHS))
     S = int(rng.choice(ROWS))
-    ploidy = 2
+    ploidy = int(rng.choice([1, 2, 2, 3]))
     H = N * ploidy
     max_allele = int(rng.choice([1, 1, 2, 3, 4, 7, 9]))
     p_missing = float(rng.choice([0.0, 0.0, 0.03, 0.3]))
