@@ -74,3 +74,33 @@ def test_random_geometry_counts(dev, seed):
                 k += 1
         wm = dev.wc_sweep_many(dm, masks, r0, r1 - r0)   # counts path: same per-site bits as the fused kernel
         assert np.array_equal(wm.a, w.a) and np.array_equal(wm.b, w.b) and np.array_equal(wm.state, w.state)
+
+
+@pytest.mark.parametrize("N,S,max_allele,p_missing", [(600, 300, 1, 0.0), (513, 257, 3, 0.05), (300, 1000, 2, 0.0), (257, 129, 1, 0.2)])
+def test_pairwise_gram_multi_tile(dev, N, S, max_allele, p_missing):
+    """fmh_pairwise_differences across several 256-sample tiles (diagonal and off-diagonal tile pairs, K slices, ragged edges)
+    against the same Gram products in numpy int64: diff = sum_s len_i len_j - sum_a cnt_i(a) cnt_j(a), both = sum_s valid_i valid_j."""
+    rng = np.random.default_rng(N * 7 + S)
+    g = rng.integers(0, max_allele + 1, size=(S, N, 2), dtype=np.uint8)
+    miss = rng.random((S, N, 2)) < p_missing if p_missing > 0 else np.zeros((S, N, 2), dtype=bool)
+    g[miss] = 0
+    words = None
+    if p_missing > 0:
+        bits = np.packbits(miss.reshape(-1), bitorder="little")
+        pad = (-len(bits)) % 8
+        words = np.frombuffer(np.concatenate([bits, np.zeros(pad, np.uint8)]).tobytes(), dtype="<u8").copy()
+    dm = dev.DeviceMatrix.from_host(g.reshape(-1), words, S, N, 2, max_allele)
+    diff, both = dev.pairwise_differences(dm, N)
+    # sparse-model genotype length: the prefix of called alleles (CompressedGenotypes::get)
+    called = ~miss
+    length = called[:, :, 0].astype(np.int64) + (called[:, :, 0] & called[:, :, 1]).astype(np.int64)   # [S][N]
+    valid = (length > 0).astype(np.int64)
+    exp_diff = length.T @ length
+    for a in range(max_allele + 1):
+        in_prefix = np.stack([called[:, :, 0], called[:, :, 0] & called[:, :, 1]], axis=2)
+        cnt = ((g == a) & in_prefix).sum(axis=2).astype(np.int64)
+        exp_diff -= cnt.T @ cnt
+    exp_both = valid.T @ valid
+    iu = np.triu_indices(N, k=1)
+    assert np.array_equal(diff[iu].astype(np.int64), exp_diff[iu])
+    assert np.array_equal(both[iu].astype(np.int64), exp_both[iu])
