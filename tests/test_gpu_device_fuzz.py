@@ -104,3 +104,47 @@ def test_pairwise_gram_multi_tile(dev, N, S, max_allele, p_missing):
     iu = np.triu_indices(N, k=1)
     assert np.array_equal(diff[iu].astype(np.int64), exp_diff[iu])
     assert np.array_equal(both[iu].astype(np.int64), exp_both[iu])
+
+
+def _gram_reference(g):
+    cnt1 = g.sum(axis=2).astype(np.float64)          # biallelic, nothing missing: allele-1 count per (site, sample)
+    cnt0 = 2.0 - cnt1
+    S = g.shape[0]
+    return 4.0 * S - (cnt0.T @ cnt0 + cnt1.T @ cnt1)  # exact in float64 (values << 2^53)
+
+
+def test_pairwise_gram_many_k_slices(dev):
+    """70 000 sites x 300 samples: several K slices per XCD, split-K atomics."""
+    rng = np.random.default_rng(77)
+    S, N = 70_000, 300
+    g = (rng.random((S, N, 2)) < rng.beta(0.8, 0.8, size=(S, 1, 1))).astype(np.uint8)
+    dm = dev.DeviceMatrix.from_host(g.reshape(-1), None, S, N, 2, 1)
+    diff, both = dev.pairwise_differences(dm, N)
+    iu = np.triu_indices(N, k=1)
+    assert np.array_equal(diff[iu].astype(np.float64), _gram_reference(g)[iu])
+    assert (both[iu] == S).all()
+
+
+def test_pairwise_gram_site_slabs():
+    """A planes budget of 4 MiB forces the site axis through many slabs (own process: the budget is read once)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ferromic_amd import device as dev\n"
+        "from tests.test_gpu_device_fuzz import _gram_reference\n"
+        "rng = np.random.default_rng(3)\n"
+        "S, N = 20000, 260\n"
+        "g = (rng.random((S, N, 2)) < 0.3).astype(np.uint8)\n"
+        "dm = dev.DeviceMatrix.from_host(g.reshape(-1), None, S, N, 2, 1)\n"
+        "diff, both = dev.pairwise_differences(dm, N)\n"
+        "iu = np.triu_indices(N, k=1)\n"
+        "assert np.array_equal(diff[iu].astype(np.float64), _gram_reference(g)[iu])\n"
+        "assert (both[iu] == S).all()\n"
+        "print('slabs ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, FMH_PD_PLANES_BYTES=str(4 << 20)))
+    assert res.returncode == 0 and "slabs ok" in res.stdout, res.stderr[-2000:]
