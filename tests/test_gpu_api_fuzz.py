@@ -216,3 +216,51 @@ def test_random_numpy_population(seed):
                 assert (gs.position, gs.n1_called, gs.n2_called) == (es.position, es.n1_called, es.n2_called)
                 assert same_float(gs.fst, es.fst, exact=True) and same_float(gs.d_xy, es.d_xy, exact=True)
                 assert same_float(gs.pi_pop1, es.pi_pop1, exact=True) and same_float(gs.pi_pop2, es.pi_pop2, exact=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FERROMIC_FUZZ_PAIR_CASES", "80"))))
+def test_two_separately_built_numpy_populations(seed):
+    """hudson_* between two Population.from_numpy objects that do NOT share their arrays (same positions): the summaries
+    arm reads each population's own matrix (stats.rs:1554-1623), the per-site arms read population 1's variants for both
+    (3050-3055), the dense arm is not available (different matrices)."""
+    import numpy as np
+
+    rng = np.random.default_rng(7000 + seed)
+    S = int(rng.choice([1, 3, 9, 40]))
+    N1, N2 = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    max_allele = int(rng.choice([1, 1, 1, 2]))
+    dt = [np.int8, np.uint8, np.int16][seed % 3]
+
+    def make(n):
+        g = rng.integers(0, max_allele + 1, size=(S, n, 2)).astype(dt)
+        if np.dtype(dt).kind == "i":
+            g[rng.random((S, n, 2)) < 0.1] = -1
+        return g
+
+    g1, g2 = make(N1), make(N2 if seed % 2 else N1)
+    n2 = g2.shape[1]
+    positions = np.cumsum(rng.integers(1, 30, size=S)).astype(np.int64)
+    L = int(positions[-1] - positions[0] + 1)
+    names1, names2 = [f"a{i}" for i in range(N1)], [f"b{i}" for i in range(n2)]
+    h1 = [(s, side) for s in range(N1) for side in (0, 1)]
+    h2 = [(s, side) for s in range(n2) for side in (0, 1)]
+    p1 = fm.Population.from_numpy(1, g1, positions, h1, L, sample_names=names1)
+    p2 = fm.Population.from_numpy(2, g2, positions, h2, L, sample_names=names2)
+    v1, d1 = R.convert_numeric_array(g1, [int(x) for x in positions])
+    v2, d2 = R.convert_numeric_array(g2, [int(x) for x in positions])
+    o1 = R.population_context_like_lib(1, v1, h1, names1, L, d1)
+    o2 = R.population_context_like_lib(2, v2, h2, names2, L, d2)
+    got, exp = call_both(lambda: fm.hudson_fst(p1, p2), lambda: R.calculate_hudson_fst_for_pair(o1, o2))
+    if exp is not None:
+        for f in ("fst", "d_xy", "pi_pop1", "pi_pop2", "pi_xy_avg"):
+            assert same_float(getattr(got, f), getattr(exp, f)), f
+    got, exp = call_both(lambda: fm.hudson_dxy(p1, p2).d_xy, lambda: R.calculate_d_xy_hudson(o1, o2))
+    assert same_float(got, exp)
+    region = (int(positions[0]), int(positions[-1]))
+    got, exp = call_both(lambda: fm.hudson_fst_with_sites(p1, p2, region),
+                         lambda: R.calculate_hudson_fst_for_pair_with_sites(o1, o2, R.QueryRegion(*region)))
+    if exp is not None:
+        assert same_float(got[0].fst, exp[0].fst) and len(got[1]) == len(exp[1])
+        for gs, es in zip(got[1], exp[1]):
+            assert (gs.position, gs.n1_called, gs.n2_called) == (es.position, es.n1_called, es.n2_called)
+            assert same_float(gs.fst, es.fst, exact=True) and same_float(gs.d_xy, es.d_xy, exact=True)
