@@ -149,7 +149,10 @@ def make_cohort(tmp, seed, n_samples=14, gz=False):
                 a = [(rng.randint(1, amax) if rng.random() < min(max(f + bias, 0.02), 0.98) else 0) for _ in range(2)]
                 gq = rng.choice([99, 60, 45, 31, 30]) if rng.random() > 0.04 else rng.choice([5, 29, "."])
                 sep = "|" if rng.random() > 0.1 else "/"
-                cells.append(f"{a[0]}{sep}{a[1]}:{gq}")
+                if c == "X" and i % 3 == 0 and rng.random() < 0.8:
+                    cells.append(f"{a[0]}:{gq}")          # haploid call (hemizygous X): ragged ploidy inside one row
+                else:
+                    cells.append(f"{a[0]}{sep}{a[1]}:{gq}")
             prefix = "chr" if c != "7" else ""
             lines.append(f"{prefix}{c}\t{pos}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT:GQ\t" + "\t".join(cells) + "\n")
         name = {"1": "chr1.vcf", "7": "cohort.chr7.phased.vcf", "X": "chrX.vcf"}[c]
