@@ -549,10 +549,10 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uin
   const uint32_t nvec = mv.nvec;
   const uint32_t a4 = a * 0x01010101u;
   if (row_ok) {
-    // the same trip count for every lane of the group (lanes past the row re-read its last vector; their mask
-    // vectors are zero): the 16-lane DPP reduction below must see a converged row
-    for (uint32_t v0 = 0; v0 < nvec; v0 += 16) {
-      const uint32_t v = v0 + (uint32_t)gl;
+    // The same trip count for every lane of the group (lanes past the row re-read its last vector; their mask vectors
+    // are zero): the 16-lane DPP reduction below must see a converged row.  Two vectors per lane per trip, written out by
+    // hand: a `#pragma unroll 2` remainder loop on this code lost counts on rows of <= 16 vectors (found by the fuzz).
+    auto one = [&](uint32_t v) {
       const uint32_t vc = v < nvec ? v : nvec - 1;
       uint4 g = load_vec(row_ptr + (size_t)vc * 16);
       uint4 e;
@@ -564,12 +564,16 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uin
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];
+        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row (v < nvec_pad always)
         c[p] = dot4(e.x, m.x, c[p]);
         c[p] = dot4(e.y, m.y, c[p]);
         c[p] = dot4(e.z, m.z, c[p]);
         c[p] = dot4(e.w, m.w, c[p]);
       }
+    };
+    for (uint32_t v0 = 0; v0 < nvec; v0 += 32) {
+      one(v0 + (uint32_t)gl);
+      one(v0 + 16 + (uint32_t)gl);
     }
   }
 #pragma unroll
