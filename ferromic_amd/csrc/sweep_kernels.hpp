@@ -430,50 +430,6 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
   if (MISSING && NEED_ALL) n_all = row16_sum(n_all);
 }
 
-// General row, pass 0: n[p], n_all and an upper bound (bitwise OR) of the called allele values.
-template <int P, bool MISSING>
-__device__ __forceinline__ void count_row_called(const MatrixView& mv, const uint4* __restrict__ lds_mask,
-                                                 uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
-                                                 const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
-                                                 uint32_t (&n)[P], uint32_t& n_all, uint32_t& allele_or) {
-#pragma unroll
-  for (int p = 0; p < P; ++p) n[p] = 0;
-  n_all = 0;
-  allele_or = 0;
-  const uint32_t nvec = mv.nvec;
-  if (row_ok) {
-#pragma unroll 2
-    for (uint32_t v = gl; v < nvec; v += 16) {
-      uint4 g = load_vec(row_ptr + (size_t)v * 16);
-      uint4 cb;
-      if (MISSING) {
-        uint32_t bits16 = *reinterpret_cast<const uint16_t*>(bits_ptr + (size_t)v * 2);
-        cb = called_bytes(bits16);
-        n_all += __builtin_popcount(bits16);
-        // keep only called bytes in the OR (0/1 byte * 0xFF)
-        g.x &= cb.x * 0xFFu; g.y &= cb.y * 0xFFu; g.z &= cb.z * 0xFFu; g.w &= cb.w * 0xFFu;
-      }
-      allele_or |= or_bytes(g.x | g.y | g.z | g.w);
-      if (MISSING) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];
-          n[p] = dot4(m.x & cb.x, 0x01010101u, n[p]);
-          n[p] = dot4(m.y & cb.y, 0x01010101u, n[p]);
-          n[p] = dot4(m.z & cb.z, 0x01010101u, n[p]);
-          n[p] = dot4(m.w & cb.w, 0x01010101u, n[p]);
-        }
-      }
-    }
-  }
-  if (MISSING) {
-#pragma unroll
-    for (int p = 0; p < P; ++p) n[p] = row16_sum(n[p]);
-    n_all = row16_sum(n_all);
-  }
-  allele_or = row16_or(allele_or);
-}
-
 // General row, single pass for alleles 0..3 by bit planes: with s0 = #(bit0 set), s1 = #(bit1 set),
 // s01 = #(both) over the called members, and every called allele < 4 (checked through allele_or),
 //   c3 = s01, c1 = s0 - s01, c2 = s1 - s01, c0 = n - c1 - c2 - c3.
