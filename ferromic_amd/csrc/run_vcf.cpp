@@ -379,9 +379,130 @@ string find_vcf_file(const string& folder, const string& chr) {  // parse.rs:263
 }
 
 // line reader over plain or (multi-member) gzip files
+// BGZF (bgzip / htslib) is a series of independent gzip members of <= 64 KiB, each announcing its compressed size in a
+// 'BC' extra subfield: the blocks of a batch are inflated in parallel, so a .vcf.gz from bgzip is ingested about as fast
+// as plain text.  Any other gzip stream stays on zlib's serial reader.
+struct BgzfSource {
+  int fd = -1;
+  int64_t file_off = 0;
+  bool file_eof = false;
+  vector<unsigned char> raw;  // compressed bytes not yet consumed
+  string out;                 // inflated text of the current batch
+  size_t out_pos = 0;
+
+  static bool is_bgzf(const string& path) {
+    unsigned char h[18];
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    const ssize_t got = pread(fd, h, sizeof h, 0);
+    close(fd);
+    return got == (ssize_t)sizeof h && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+  }
+  explicit BgzfSource(const string& path) : fd(open(path.c_str(), O_RDONLY)) {
+    if (fd < 0) throw Error("cannot open " + path);
+  }
+  ~BgzfSource() { if (fd >= 0) close(fd); }
+
+  bool refill() {  // inflate the next batch of blocks into `out`; false at end of file
+    out.clear();
+    out_pos = 0;
+    for (;;) {
+      if (!file_eof) {
+        const size_t want = (size_t)32 << 20, had = raw.size();
+        raw.resize(had + want);
+        size_t got_total = 0;
+        while (got_total < want) {
+          const ssize_t got = pread(fd, raw.data() + had + got_total, want - got_total, file_off);
+          if (got <= 0) { file_eof = true; break; }
+          got_total += (size_t)got;
+          file_off += got;
+        }
+        raw.resize(had + got_total);
+      }
+      struct Block { size_t data, clen, isize, out_off; };
+      vector<Block> blocks;
+      size_t pos = 0, total = 0;
+      while (pos + 18 <= raw.size()) {
+        const unsigned char* h = raw.data() + pos;
+        if (!(h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4))) throw Error("corrupt BGZF block header");
+        const size_t xlen = h[10] | (h[11] << 8);
+        if (pos + 12 + xlen > raw.size()) break;
+        size_t bsize = 0;
+        for (size_t x = 12; x + 4 <= 12 + xlen;) {  // extra subfields: SI1 SI2 SLEN(2) data
+          const size_t slen = h[x + 2] | (h[x + 3] << 8);
+          if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
+          x += 4 + slen;
+        }
+        if (!bsize || bsize < 12 + xlen + 8) throw Error("BGZF block without a BC size field");
+        if (pos + bsize > raw.size()) break;  // block not complete yet
+        const unsigned char* tail = raw.data() + pos + bsize - 4;
+        const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+        blocks.push_back({pos + 12 + xlen, bsize - 12 - xlen - 8, isize, total});
+        total += isize;
+        pos += bsize;
+      }
+      if (blocks.empty()) {
+        if (file_eof) { if (!raw.empty() && pos < raw.size()) throw Error("truncated BGZF file"); return false; }
+        continue;  // need more bytes for one whole block
+      }
+      out.resize(total);
+      std::atomic<size_t> next{0};
+      std::atomic<bool> bad{false};
+      parallel_for((unsigned)std::min<size_t>(worker_threads(), blocks.size()), [&](unsigned) {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= blocks.size()) break;
+          const Block& b = blocks[i];
+          if (b.isize == 0) continue;
+          z_stream z;
+          memset(&z, 0, sizeof z);
+          if (inflateInit2(&z, -15) != Z_OK) { bad = true; continue; }
+          z.next_in = raw.data() + b.data;
+          z.avail_in = (uInt)b.clen;
+          z.next_out = (Bytef*)&out[b.out_off];
+          z.avail_out = (uInt)b.isize;
+          const int rc = inflate(&z, Z_FINISH);
+          if (rc != Z_STREAM_END || z.avail_out != 0) bad = true;
+          inflateEnd(&z);
+        }
+      });
+      if (bad) throw Error("BGZF block failed to inflate");
+      raw.erase(raw.begin(), raw.begin() + (ptrdiff_t)pos);
+      if (total == 0) { if (file_eof && raw.empty()) return false; continue; }  // only empty (EOF marker) blocks in this batch
+      return true;
+    }
+  }
+  size_t read(char* dst, size_t n) {
+    size_t done = 0;
+    while (done < n) {
+      if (out_pos == out.size() && !refill()) break;
+      const size_t take = std::min(n - done, out.size() - out_pos);
+      memcpy(dst + done, out.data() + out_pos, take);
+      out_pos += take;
+      done += take;
+    }
+    return done;
+  }
+  bool next_line(string& line) {
+    line.clear();
+    for (;;) {
+      if (out_pos == out.size() && !refill()) return !line.empty();
+      const char* base = out.data() + out_pos;
+      const void* nl = memchr(base, '\n', out.size() - out_pos);
+      const size_t take = nl ? (size_t)((const char*)nl - base) + 1 : out.size() - out_pos;
+      line.append(base, take);
+      out_pos += take;
+      if (nl) return true;
+    }
+  }
+};
+
 struct LineReader {
   gzFile f;
-  explicit LineReader(const string& path) : f(gzopen(path.c_str(), "rb")), path_(path) {
+  std::unique_ptr<BgzfSource> bgzf;
+  explicit LineReader(const string& path) : f(nullptr), path_(path) {
+    if (BgzfSource::is_bgzf(path)) { bgzf.reset(new BgzfSource(path)); return; }
+    f = gzopen(path.c_str(), "rb");
     if (!f) throw Error("cannot open " + path);
     gzbuffer(f, 1 << 20);
   }
@@ -390,6 +511,7 @@ struct LineReader {
   int64_t raw_off = 0;
   string path_;
   size_t read(char* dst, size_t n) {  // raw bytes following whatever next() consumed
+    if (bgzf) return bgzf->read(dst, n);
     if (raw_fd < 0 && gzdirect(f)) {  // plain text: skip zlib's copy and read the file itself from here on
       raw_off = (int64_t)gztell(f);
       raw_fd = open(path_.c_str(), O_RDONLY);
@@ -413,6 +535,7 @@ struct LineReader {
     return total;
   }
   bool next(string& out) {
+    if (bgzf) return bgzf->next_line(out);
     out.clear();
     char buf[1 << 16];
     for (;;) {

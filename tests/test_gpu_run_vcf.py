@@ -100,6 +100,21 @@ def test_reference_end_to_end_cases(tmp_path, kats, case):
         assert vals == pytest.approx(e["fst"], abs=1e-6)
 
 
+def write_bgzf(path, data: bytes, block=60_000):
+    """BGZF as bgzip / htslib write it: independent gzip members with a 'BC' extra subfield, plus the empty EOF block."""
+    import struct
+    import zlib
+
+    with open(path, "wb") as fh:
+        for off in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if off is None else data[off:off + block]
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = comp.compress(chunk) + comp.flush()
+            bsize = 12 + 6 + len(body) + 8
+            fh.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            fh.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
 def make_cohort(tmp, seed, n_samples=14, gz=False):
     rng = random.Random(seed)
     names = [f"POP_{'ABC'[i % 3]}_HG{i:05d}" for i in range(n_samples)]
@@ -157,7 +172,9 @@ def make_cohort(tmp, seed, n_samples=14, gz=False):
             lines.append(f"{prefix}{c}\t{pos}\t.\t{ref}\t{alt}\t.\tPASS\t.\tGT:GQ\t" + "\t".join(cells) + "\n")
         name = {"1": "chr1.vcf", "7": "cohort.chr7.phased.vcf", "X": "chrX.vcf"}[c]
         text = header + "".join(lines)
-        if gz and c == "1":
+        if gz == "bgzf" and c == "1":
+            write_bgzf(tmp / "vcfs" / "chr1.vcf.gz", text.encode(), block=rng.choice([700, 5_000, 60_000]))
+        elif gz and c == "1":
             with gzip.open(tmp / "vcfs" / "chr1.vcf.gz", "wt") as fh:
                 fh.write(text)
         else:
@@ -185,10 +202,11 @@ def make_cohort(tmp, seed, n_samples=14, gz=False):
                 config_file=str(tmp / "config.tsv")), names
 
 
-@pytest.mark.parametrize("variant", ["plain", "fst", "fst_mask_allow_exclude", "gz_min_gq"])
+@pytest.mark.parametrize("variant", ["plain", "fst", "fst_mask_allow_exclude", "gz_min_gq", "bgzf"])
 def test_synthetic_cohort(tmp_path, variant):
-    kw, names = make_cohort(tmp_path, seed={"plain": 11, "fst": 12, "fst_mask_allow_exclude": 13, "gz_min_gq": 14}[variant], gz=variant == "gz_min_gq")
-    if variant in ("fst", "fst_mask_allow_exclude", "gz_min_gq"):
+    kw, names = make_cohort(tmp_path, seed={"plain": 11, "fst": 12, "fst_mask_allow_exclude": 13, "gz_min_gq": 14, "bgzf": 15}[variant],
+                            gz="bgzf" if variant == "bgzf" else variant == "gz_min_gq")
+    if variant in ("fst", "fst_mask_allow_exclude", "gz_min_gq", "bgzf"):
         kw["enable_fst"] = True
     if variant == "fst_mask_allow_exclude":
         kw.update(mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"), exclude=[names[3], "HG00007"])
@@ -279,7 +297,7 @@ def test_random_flag_combinations(tmp_path, seed):
     """Seeded random cohorts x random CLI flags (mask / allow / exclude / min_gq / --fst / population CSV / gz input / workers)."""
     rng = random.Random(seed)
     n = rng.randint(6, 22)
-    kw, names = make_cohort(tmp_path, seed=seed, n_samples=n, gz=rng.random() < 0.3)
+    kw, names = make_cohort(tmp_path, seed=seed, n_samples=n, gz=rng.choice([False, False, True, "bgzf"]))
     if rng.random() < 0.7:
         kw["enable_fst"] = True
     if rng.random() < 0.5:

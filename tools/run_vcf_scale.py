@@ -25,7 +25,42 @@ sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")
 
 
-def write_inputs(tmp: str, sites: int, samples: int, seed: int):
+class BgzfWriter:
+    """Streams bytes into BGZF blocks (independent gzip members with a 'BC' size subfield, then the EOF block)."""
+
+    def __init__(self, path, block=65280):
+        self.fh, self.block, self.buf = open(path, "wb"), block, bytearray()
+
+    def _emit(self, chunk: bytes):
+        import struct
+        import zlib
+
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = comp.compress(chunk) + comp.flush()
+        bsize = 12 + 6 + len(body) + 8
+        self.fh.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+        self.fh.write(body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+    def write(self, data: bytes):
+        self.buf += data
+        while len(self.buf) >= self.block:
+            self._emit(bytes(self.buf[:self.block]))
+            del self.buf[:self.block]
+
+    def close(self):
+        if self.buf:
+            self._emit(bytes(self.buf))
+        self._emit(b"")
+        self.fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def write_inputs(tmp: str, sites: int, samples: int, seed: int, compress: str = "none"):
     rng = np.random.default_rng(seed)
     gaps = rng.integers(1, 7, size=sites)
     pos = np.cumsum(gaps)  # 1-based VCF positions
@@ -45,8 +80,11 @@ def write_inputs(tmp: str, sites: int, samples: int, seed: int):
     os.makedirs(os.path.join(tmp, "vcfs"), exist_ok=True)
     half = samples // 2
     geno = np.empty((sites, samples, 2), dtype=np.uint8)
-    vcf_path = os.path.join(tmp, "vcfs", "chr1.vcf")
-    with open(vcf_path, "wb") as fh:
+    vcf_path = os.path.join(tmp, "vcfs", "chr1.vcf" + ("" if compress == "none" else ".gz"))
+    import gzip
+
+    opener = {"none": lambda p: open(p, "wb"), "gzip": lambda p: gzip.open(p, "wb", compresslevel=1), "bgzf": BgzfWriter}[compress]
+    with opener(vcf_path) as fh:
         fh.write(("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n").encode())
         chunk = 4096
         for c0 in range(0, sites, chunk):
@@ -82,10 +120,11 @@ def main() -> int:
     ap.add_argument("--samples", type=int, default=2_500)
     ap.add_argument("--seed", type=int, default=202_500)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--compress", choices=["none", "gzip", "bgzf"], default="none", help="how the synthetic VCF is stored")
     args = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="run_vcf_scale_")
     t0 = time.perf_counter()
-    geno, pos, length, vcf_bytes = write_inputs(tmp, args.sites, args.samples, args.seed)
+    geno, pos, length, vcf_bytes = write_inputs(tmp, args.sites, args.samples, args.seed, args.compress)
     gen_s = time.perf_counter() - t0
 
     out_csv = os.path.join(tmp, "out", "results.csv")
@@ -130,7 +169,7 @@ def main() -> int:
     }
     timing = [l for l in res.stderr.splitlines() if l.startswith("[TIMING]")]
     print(json.dumps({
-        "sites": args.sites, "samples": args.samples, "haplotypes": 2 * args.samples, "vcf_bytes": vcf_bytes,
+        "sites": args.sites, "samples": args.samples, "haplotypes": 2 * args.samples, "vcf_bytes": vcf_bytes, "vcf_storage": args.compress,
         "generate_s": gen_s, "run_vcf_wall_s": cli_s, "vcf_MB_per_s": vcf_bytes / cli_s / 1e6,
         "sites_per_s_end_to_end": args.sites / cli_s, "api_from_numpy_s": api_s,
         "csv_matches_python_api": checks, "all_match": all(checks.values()), "run_vcf_timing": timing,
