@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import dense as D
+from oracle import ferromic_ref as R
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -145,3 +146,31 @@ def test_c3_wc_four_populations_properties(dev):
         assert int(ok.sum()) == int(w4.informative_sites[slot])
         assert H.rel_close(float(w4.a[slot][ok].sum()), float(w4.sum_a[slot]))
         assert H.rel_close(float(w4.b[slot][ok].sum()), float(w4.sum_b[slot]))
+
+
+def test_c3_wc_sampled_sites_against_oracle(dev):
+    """SURVEY 8(d) parity gate for C3: a fixed subsample of sites of a C3-width cohort (2 500 haplotypes, 4 populations)
+    against the oracle's literal per-site W&C (calculate_fst_wc_at_site_with_membership), a and b bit for bit; the
+    regional sums against the oracle's sums over the SAME subsample read back from the GPU tracks."""
+    S, N, P = 200_000, 1250, 4
+    seed = 5_001_250
+    base = thresholds(S, seed)
+    thr = np.stack([base[p % 2] for p in range(P)])
+    pop_of_sample = np.minimum(np.arange(N) * P // N, P - 1).astype(np.uint8)
+    poc = np.repeat(pop_of_sample, 2)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
+    dm.generate(seed, 0, thr, poc, 0)
+    masks = np.stack([poc == p for p in range(P)]).astype(np.uint8)
+    w = dev.wc_sweep(dm, dev.Groups(dm, masks))
+    membership = R.SubpopulationMembership.from_map(N, {(s, side): str(pop_of_sample[s]) for s in range(N) for side in (0, 1)})
+    pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
+    rng = np.random.default_rng(1)
+    rows = np.unique(np.concatenate([[0, 1, S - 1], rng.integers(0, S, size=150)]))
+    for r in rows:
+        hdata, _ = D.generate(1, 2 * N, seed, int(r), np.ascontiguousarray(thr[:, r:r + 1]), poc, 0, 1)
+        g = hdata.reshape(N, 2)
+        overall, _, components, _, pair_components = R.calculate_fst_wc_at_site_with_membership(R.make_variant(int(r), g.tolist()), membership)
+        assert (float(w.a[0][r]), float(w.b[0][r])) == components, r
+        for k, (i, j) in enumerate(pairs, start=1):
+            assert (float(w.a[k][r]), float(w.b[k][r])) == pair_components[f"{i}_vs_{j}"], (r, i, j)
+        assert dev.WC_STATES[w.state[0][r]] == overall.state
