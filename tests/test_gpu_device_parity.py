@@ -36,6 +36,8 @@ SHAPES = [
     (130, 45, 3, 0.0),     # multi-allelic
     (130, 45, 5, 0.1),     # multi-allelic with missing
     (70, 2500, 1, 0.0),    # C4-like width (H = 5000)
+    (40, 5000, 1, 0.0),    # C5 width (H = 10 000)
+    (40, 5000, 1, 0.01),
     (70, 7, 7, 0.0),       # narrow rows (one 16-byte vector), alleles >= 4: the per-allele fallback of the general path
     (70, 8, 5, 0.05),
     (33, 100, 9, 0.0),
