@@ -1856,7 +1856,19 @@ int run(const Args& args) {
       catch (const Error& e) { logmsg("ERROR", "Error processing VCF for " + chr + ": " + e.what()); continue; }
       if (args.ingest_only) {
         tm.reset();
-        printf("[INGEST] chr %s: %zu variants x %zu samples\n", chr.c_str(), vcf.variants.size(), vcf.sample_names.size());
+        // FNV-1a over (position, flags, stride, genotype bytes) of every variant in order: lets a CPU-only test pin the
+        // whole text -> Variant stage against the oracle's parse
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint8_t b) { h ^= b; h *= 1099511628211ull; };
+        for (size_t i = 0; i < vcf.variants.size(); ++i) {
+          const Variant& v = vcf.variants[i];
+          for (int k = 0; k < 8; ++k) mix((uint8_t)((uint64_t)v.position >> (8 * k)));
+          mix(vcf.flags[i]);
+          mix((uint8_t)v.stride);
+          for (uint8_t b : v.data) mix(b);
+        }
+        printf("[INGEST] chr %s: %zu variants x %zu samples digest %016llx\n", chr.c_str(), vcf.variants.size(), vcf.sample_names.size(),
+               (unsigned long long)h);
         continue;
       }
       tm.emplace("regions_statistics_and_writers");

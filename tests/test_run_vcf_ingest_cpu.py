@@ -1,0 +1,54 @@
+"""The text -> Variant stage of the run_vcf binary without a GPU (`--ingest_only` computes no statistic): config / BED /
+FASTA(.fai) / VCF parsing, flags, sorting and the plain, gzip and BGZF readers, pinned to the oracle's parse by a digest
+over every (position, flags, stride, genotype bytes)."""
+
+import os
+import re
+import subprocess
+
+import pytest
+
+from oracle import run_vcf_ref as V
+from tests.test_gpu_run_vcf import BIN, make_cohort
+
+
+def oracle_digests(kw, min_gq=30, mask_file=None, allow_file=None, exclude=()):
+    entries = V.parse_config_file(kw["config_file"])
+    mask = V.parse_regions_file(mask_file) if mask_file else None
+    allow = V.parse_regions_file(allow_file) if allow_file else None
+    by_chr = {}
+    for e in entries:
+        by_chr.setdefault(e.seqname, []).append(e)
+    out = {}
+    for chrom in sorted(by_chr):
+        try:
+            seq = V.read_reference_sequence(kw["reference"], chrom)
+        except Exception:
+            continue
+        final_mask = {k: list(v) for k, v in (mask or {}).items()}
+        final_mask.setdefault(chrom, []).extend(V.find_n_regions(seq))
+        hulls = [(max(e.interval[0] - 3_000_000, 0), min(e.interval[1] + 3_000_000, len(seq))) for e in by_chr[chrom]]
+        variants, flags, names = V.process_vcf(V.find_vcf_file(kw["vcf_folder"], chrom), chrom, V.merge_intervals(hulls), min_gq, final_mask,
+                                               allow, set(exclude))
+        h = 1469598103934665603
+        for v, fl in zip(variants, flags):
+            for b in list(int(v.position).to_bytes(8, "little", signed=True)) + [fl, v.genotypes.stride] + list(v.genotypes.data):
+                h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        out[chrom] = (len(variants), len(names), f"{h:016x}")
+    return out
+
+
+@pytest.mark.parametrize("storage", [False, True, "bgzf"])
+def test_ingest_matches_oracle_parse(tmp_path, storage):
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    kw, names = make_cohort(tmp_path, seed=91, n_samples=17, gz=storage)
+    cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--config_file", kw["config_file"],
+           "--output_file", str(tmp_path / "out" / "o.csv"), "--mask_file", str(tmp_path / "mask.bed"), "--allow_file", str(tmp_path / "allow.tsv"),
+           "--min_gq", "31", "--ingest_only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_THREADS="3"), timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = {m.group(1): (int(m.group(2)), int(m.group(3)), m.group(4))
+           for m in re.finditer(r"\[INGEST\] chr (\S+): (\d+) variants x (\d+) samples digest ([0-9a-f]{16})", res.stdout)}
+    exp = oracle_digests(kw, min_gq=31, mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"))
+    assert got == exp and len(got) == 3
