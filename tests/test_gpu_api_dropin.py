@@ -356,3 +356,48 @@ def test_pairwise_differences_reference_kat():
     exp = {k: (d, c) for k, d, c in R.calculate_pairwise_differences([R.make_variant(v["position"], v["genotypes"]) for v in variants], 3, 10)}
     assert res == exp
     assert res[(0, 1)] == (4, 40) and res[(0, 2)][1] == 36  # one variant lacks sample 2 -> 4 comparisons removed
+
+
+def test_concurrent_python_threads_share_populations():
+    """The module releases the GIL around device calls (lib.rs `py.allow_threads`): threads hammering the same Population
+    objects (lazy uploads, cached summaries, one sweep at a time per device inside the library) must all see the
+    single-threaded answers."""
+    import threading
+
+    rng = np.random.default_rng(17)
+    S, N = 3000, 40
+    g = (rng.random((S, N, 2)) < rng.beta(0.8, 0.8, size=(S, 1, 1))).astype(np.int8)
+    g[rng.random((S, N, 2)) < 0.02] = -1
+    positions = np.cumsum(rng.integers(1, 40, size=S)).astype(np.int64)
+    L = int(positions[-1] - positions[0] + 1)
+    haps = [(s, side) for s in range(N) for side in (0, 1)]
+    names = [f"s{i}" for i in range(N)]
+
+    def fresh():
+        base = fm.Population.from_numpy("all", g, positions, haps, L, sample_names=names)
+        return base, base.with_haplotypes(1, haps[:N]), base.with_haplotypes(2, haps[N:])
+
+    def answers(base, p1, p2):
+        r = fm.hudson_fst(p1, p2)
+        _, sites = fm.hudson_fst_with_sites(p1, p2, (int(positions[100]), int(positions[900])))
+        return (base.segregating_sites(), base.nucleotide_diversity(), p1.nucleotide_diversity(), r.fst, r.d_xy,
+                fm.hudson_dxy(p1, p2).d_xy, len(sites), sites[17].fst, sites[400].d_xy)
+
+    expected = answers(*fresh())
+    shared = fresh()   # untouched: the first uploads and summaries happen under contention
+    results, errors = [], []
+
+    def work():
+        try:
+            for _ in range(6):
+                results.append(answers(*shared))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:1]
+    assert len(results) == 48 and all(r == expected for r in results)
