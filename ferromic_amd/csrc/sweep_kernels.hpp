@@ -1197,10 +1197,10 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
 
 // Gram product of sample-major int8 planes on the matrix cores:
 //   out(i, j) += sign * sum_{p in [plane_begin, plane_begin + plane_count)} sum_{k in chunk} planes[p][i][k] * planes[p][j][k]
-// v_mfma_i32_32x32x32_i8: each lane feeds 16 consecutive K bytes of one row of A and of one row of B.  A and B
-// fragments are cut from LDS images with the SAME (row, k) -> lane rule, so whatever order the instruction walks
-// K inside a step, both operands agree and the sum over K is the plain dot product.  C/D: column = lane & 31
-// (B row), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (A row).
+// v_mfma_i32_16x16x64_i8: each lane feeds 16 consecutive K bytes of one row of A and of one row of B (row = lane & 15,
+// K chunk = lane >> 4).  A and B fragments are cut from LDS images with the SAME (row, k) -> lane rule, so whatever
+// order the instruction walks K inside a step, both operands agree and the sum over K is the plain dot product.
+// C/D: column = lane & 15 (B row), row = 4 * (lane >> 4) + reg (A row).  (The 32x32x32 form measured 4 % slower.)
 // LDS images are byte-for-byte copies of the stage tiles (global_load_lds writes wave-linear), whose 16-byte chunks
 // the planes kernel stored XOR-swizzled by (row >> 1) & 7: 16 consecutive rows of one K chunk then sit in 16
 // different 16-byte slots of the 256-byte bank row, so the fragment reads are conflict-free without padding.
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
 typedef int pd_v4i __attribute__((ext_vector_type(4)));
 typedef int pd_v16i __attribute__((ext_vector_type(16)));
 
-// Workgroup tile 256 x 256 samples: half the operand bytes per MAC of a 128 x 128 tile, whose L2 -> LDS traffic per CU
+// Workgroup tile 256 x 256 samples (16 waves, each 64 x 64 = 4 x 4 MFMA tiles): half the operand bytes per MAC of a 128 x 128 tile, whose L2 -> LDS traffic per CU
 // (not MFMA issue) bounded the first version of this kernel at 26 % of peak.  16 waves (4 x 4 of 64 x 64), one workgroup per CU;
 // the two 64 KiB stage buffers alternate: the global_load_lds of stage s+1 are in flight while stage s feeds the MFMAs,
 // one raw s_barrier per stage (a __syncthreads() would drain the loads before the MFMAs start).
@@ -1229,24 +1229,24 @@ __global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restr
   const int wr = wave >> 2, wc = wave & 3;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  uint32_t offa[2], offb[2], swza[2], swzb[2];
+  uint32_t offa[4], offb[4], swza[4], swzb[4];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) { const uint32_t r = wr * 64 + m * 32 + (lane & 31); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
+  for (int m = 0; m < 4; ++m) { const uint32_t r = wr * 64 + m * 16 + (lane & 15); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
 #pragma unroll
-  for (int n = 0; n < 2; ++n) { const uint32_t r = wc * 64 + n * 32 + (lane & 31); offb[n] = kPdBig * kPdStageK + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
+  for (int n = 0; n < 4; ++n) { const uint32_t r = wc * 64 + n * 16 + (lane & 15); offb[n] = kPdBig * kPdStageK + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
   for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
     uint32_t t = item % tiles, bi = 0;
     while (t >= nt - bi) { t -= nt - bi; ++bi; }
     const uint32_t bj = bi + t;
     const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
     if (k0 >= s_pad) continue;  // uniform for the workgroup
-    pd_v16i acc[2][2];
+    pd_v4i acc[4][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = 0;
     const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
     const size_t stages_per_plane = (k1 - k0) / kPdStageK;
     const size_t n_stages = stages_per_plane * (size_t)plane_count;
@@ -1279,30 +1279,30 @@ __global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restr
       if (stage + 1 < n_stages) issue((int)((stage + 1) & 1));
       const unsigned char* img = pd_lds + (stage & 1) * (size_t)kPdBigStageBytes;
 #pragma unroll
-      for (int ks = 0; ks < kPdStageK / 32; ++ks) {
-        const uint32_t cl = (uint32_t)(ks * 2 + (lane >> 5));
-        pd_v4i fa[2], fb[2];
+      for (int ks = 0; ks < kPdStageK / 64; ++ks) {
+        const uint32_t cl = (uint32_t)(ks * 4 + (lane >> 4));
+        pd_v4i fa[4], fb[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
+        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
+        for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
       }
       // every wave: my loads of the next stage have landed; everybody: done reading this stage's image
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t i = bi * kPdBig + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const uint32_t j = bj * kPdBig + wc * 64 + n * 32 + (lane & 31);
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t i = bi * kPdBig + wr * 64 + m * 16 + 4 * (lane >> 4) + r;
+          const uint32_t j = bj * kPdBig + wc * 64 + n * 16 + (lane & 15);
           if (i < j && j < n_samples) {
             const long long v = acc[m][n][r];
             if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));
