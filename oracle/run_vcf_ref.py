@@ -58,6 +58,34 @@ def _wrap_i64(x: int) -> int:
     return x - (1 << 64) if x >= (1 << 63) else x
 
 
+_I64_MAX = (1 << 63) - 1
+
+
+def from_1based_inclusive(start_inclusive: int, end_inclusive: int) -> Tuple[int, int]:
+    """ZeroBasedHalfOpen::from_1based_inclusive, process.rs:193-206 -> (start, end) 0-based half-open."""
+    a = max(start_inclusive, 1)
+    b = max(end_inclusive, a)
+    return a - 1, b
+
+
+def from_0based_inclusive(start_inclusive: int, end_inclusive: int) -> Tuple[int, int]:
+    """ZeroBasedHalfOpen::from_0based_inclusive, process.rs:210-222 (saturating end + 1)."""
+    a = max(start_inclusive, 0)
+    b = a if end_inclusive < a else max(min(end_inclusive + 1, _I64_MAX), a)
+    return a, b
+
+
+def from_0based_point(p: int) -> Tuple[int, int]:
+    """process.rs:225-231."""
+    a = max(p, 0)
+    return a, a + 1
+
+
+def half_open_len(iv: Tuple[int, int]) -> int:
+    """ZeroBasedHalfOpen::len, process.rs:234-240."""
+    return iv[1] - iv[0] if iv[1] > iv[0] else 0
+
+
 def _trim_start_matches(s: str, prefix: str) -> str:
     while s.startswith(prefix):
         s = s[len(prefix):]

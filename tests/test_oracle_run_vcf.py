@@ -86,3 +86,46 @@ def test_config_parsing_rules(tmp_path):
     assert e.seqname == "3" and e.interval == (200099, 200900)
     assert e.samples_unfiltered == {"A": (0, 0), "B": (0, 0), "C": (0, 1)}
     assert e.samples_filtered == {"C": (0, 1)}  # suffixed genotypes are not exact matches
+
+
+def test_interval_conversions(kats):
+    """src/tests/interval_tests.rs: the 0-/1-based inclusive -> 0-based half-open conversions every coordinate goes through."""
+    k = kats["interval_conversions"]
+    for c in k["from_0based_inclusive"]:
+        iv = V.from_0based_inclusive(*c["args"])
+        assert iv == (c["start"], c["end"]) and V.half_open_len(iv) == c["len"]
+    big = V.from_0based_inclusive((1 << 63) - 1, (1 << 63) - 1)
+    assert big[1] >= big[0] and V.half_open_len(big) == k["from_0based_inclusive_i64_max_len"]
+    for c in k["from_1based_inclusive"]:
+        iv = V.from_1based_inclusive(*c["args"])
+        assert iv == (c["start"], c["end"])
+        if "len" in c:
+            assert V.half_open_len(iv) == c["len"]
+    for c in k["from_0based_point"]:
+        assert V.from_0based_point(c["arg"]) == (c["start"], c["end"]) == V.from_0based_inclusive(c["arg"], c["arg"])
+    assert V.half_open_len(tuple(k["reversed_len"]["interval"])) == k["reversed_len"]["len"]
+    a, b = V.from_0based_inclusive(*k["slice"]["args"])
+    assert k["slice"]["dna"][a:b] == k["slice"]["expect"]
+    assert V.from_0based_inclusive(4, 9) == V.from_1based_inclusive(5, 10)
+
+
+def test_process_variant_reference_cases(kats):
+    """src/tests/filter_tests.rs (GQ filter flags, 1-based -> 0-based) and src/tests/mnp_test.rs (a mixed SNP/MNP ALT is dropped)."""
+    for c in kats["process_variant_cases"]["cases"]:
+        got = V.process_variant(c["line"], c["chrom"], [tuple(r) for r in c["regions"]], c["kept"], c["min_gq"], None, None)
+        if c["expect"] is None:
+            assert got is None, c["name"]
+            continue
+        variant, flags = got
+        assert variant.position == c["expect"]["position"], c["name"]
+        assert (flags == 0) == c["expect"]["flags_zero"], c["name"]
+
+
+def test_sample_name_mapping(kats):
+    """src/tests/sample_mapping_tests.rs: the core ID resolves to the index of the full VCF name."""
+    from oracle import ferromic_ref as R
+
+    k = kats["sample_mapping"]
+    mapping = R.map_sample_names_to_indices(k["samples"])
+    for name, idx in k["expect"].items():
+        assert mapping.get(name) == idx
