@@ -362,3 +362,58 @@ def test_cli_errors(tmp_path):
     res = subprocess.run([BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"]],
                          capture_output=True, text=True)
     assert res.returncode != 0 and "Either --config_file or --chr must be specified" in res.stderr
+
+
+def test_reference_full_pipeline_shape(tmp_path):
+    """src/tests/full_integration_test.rs: 25 chromosomes, 30 config regions of 4 kb (five chromosomes carry two), 8 samples
+    with random haplotype groups, 15 random biallelic variants per region, no filter of any kind.  The reference's own
+    assertions (30 rows, pi > 0 in both groups, filtered == unfiltered, segregating sites > 0) plus equality with the oracle."""
+    rng = random.Random(2024)
+    samples = [f"Sample{i}" for i in range(8)]
+    chroms = [str(i) for i in range(1, 26)]
+    length = 100_000
+    fasta, fai, off = "", "", 0
+    for c in chroms:
+        seq = "ACTACGTACGGATCG" * (length // 15 + 1)
+        seq = seq[:length]
+        hdr = f">chr{c}\n"
+        body = "\n".join(seq[i:i + 100] for i in range(0, length, 100)) + "\n"
+        fai += f"chr{c}\t{length}\t{off + len(hdr)}\t100\t101\n"
+        fasta += hdr + body
+        off += len(hdr) + len(body)
+    (tmp_path / "ref.fa").write_text(fasta)
+    (tmp_path / "ref.fa.fai").write_text(fai)
+    (tmp_path / "ann.gtf").write_text("".join(f'chr{c}\t.\tgene\t1\t1000\t.\t+\t.\tgene_id "g{c}"; gene_name "g{c}";\n' for c in chroms))
+    os.makedirs(tmp_path / "vcfs")
+    usage, regions = {}, {}
+    cfg = "seqnames\tstart\tend\tPOS\torig_ID\tverdict\tcateg\t" + "\t".join(samples) + "\n"
+    for i in range(30):
+        c = chroms[i % 25]
+        start = 1000 + usage.get(c, 0) * 5000   # 0-based half-open [start, start + 4000)
+        usage[c] = usage.get(c, 0) + 1
+        regions.setdefault(c, []).append((start, start + 4000))
+        cells = [f"{rng.randint(0, 1)}|{rng.randint(0, 1)}" for _ in samples]
+        cfg += f"chr{c}\t{start + 1}\t{start + 4000}\t{start}\tinv{i}\tpass\tinv\t" + "\t".join(cells) + "\n"
+    (tmp_path / "config.tsv").write_text(cfg)
+    for c, regs in regions.items():
+        rows = []
+        for a, b in regs:
+            for _ in range(15):
+                pos1 = rng.randrange(a, b) + 1
+                gts = "\t".join(f"{rng.randint(0, 1)}|{rng.randint(0, 1)}:60" for _ in samples)
+                rows.append((pos1, f"chr{c}\t{pos1}\t.\tA\tT\t.\tPASS\t.\tGT:GQ\t{gts}\n"))
+        rows.sort(key=lambda r: r[0])
+        (tmp_path / "vcfs" / f"chr{c}.vcf").write_text(
+            "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples) + "\n" + "".join(r[1] for r in rows))
+    kw = dict(vcf_folder=str(tmp_path / "vcfs"), reference=str(tmp_path / "ref.fa"), gtf=str(tmp_path / "ann.gtf"),
+              config_file=str(tmp_path / "config.tsv"))
+    exp = V.run(output_file=str(tmp_path / "oracle" / "output.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "output.csv"), **kw)
+    compare(got, exp)
+    lines = got["output.csv"].splitlines()
+    assert len(lines) - 1 == 30
+    for line in lines[1:]:
+        row = dict(zip(V.CSV_HEADER, line.split(",")))
+        assert float(row["0_pi"]) > 0.0 and float(row["1_pi"]) > 0.0
+        assert abs(float(row["0_pi"]) - float(row["0_pi_filtered"])) < 1e-9 and abs(float(row["1_pi"]) - float(row["1_pi_filtered"])) < 1e-9
+        assert int(row["0_segregating_sites"]) > 0
