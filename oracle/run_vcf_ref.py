@@ -140,10 +140,29 @@ def parse_region(region: str) -> Tuple[int, int]:  # parse.rs:241-261
     parts = region.split("-")
     if len(parts) != 2:
         raise R.VcfError("InvalidRegion", "Invalid region format. Use start-end")
-    s, e = int(parts[0]), int(parts[1])
+    def parse_i64(text: str, what: str) -> int:  # Rust str::parse::<i64>: optional sign, ASCII digits only
+        body = text[1:] if text[:1] in "+-" else text
+        if not body or not body.isascii() or not body.isdigit() or not -(1 << 63) <= int(text) < (1 << 63):
+            raise R.VcfError("InvalidRegion", f"Invalid {what} position")
+        return int(text)
+
+    s, e = parse_i64(parts[0], "start"), parse_i64(parts[1], "end")
     if s >= e:
         raise R.VcfError("InvalidRegion", "Start position must be less than end position")
     return R._hal_from_1based_inclusive(s, e)
+
+
+def validate_vcf_header(header: str) -> None:
+    """parse.rs:529-543."""
+    req = ["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"]
+    fields = header.split("\t")
+    if len(fields) < len(req) or fields[:len(req)] != req:
+        raise R.VcfError("InvalidVcfFormat", "Invalid VCF header format")
+
+
+def core_sample_id(name: str) -> str:
+    """stats.rs:1010-1012 -> normalize_sample_name_for_lookup (process.rs:1192-1196)."""
+    return name[:-2] if name.endswith("_L") or name.endswith("_R") else name
 
 
 def find_vcf_file(folder: str, chrom: str) -> str:

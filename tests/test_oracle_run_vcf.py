@@ -129,3 +129,50 @@ def test_sample_name_mapping(kats):
     mapping = R.map_sample_names_to_indices(k["samples"])
     for name, idx in k["expect"].items():
         assert mapping.get(name) == idx
+
+
+def test_core_sample_id(kats):
+    for name, core in kats["core_sample_id"]["cases"]:
+        assert V.core_sample_id(name) == core
+
+
+def test_parse_region(kats):
+    from oracle import ferromic_ref as R
+
+    k = kats["parse_region"]
+    for text, (a, b) in k["valid"]:
+        assert V.parse_region(text) == (a, b)
+    for text in k["invalid"]:
+        with pytest.raises(R.VcfError) as info:
+            V.parse_region(text)
+        assert info.value.kind == "InvalidRegion", text
+
+
+def test_validate_vcf_header(kats):
+    from oracle import ferromic_ref as R
+
+    for h in kats["vcf_header"]["valid"]:
+        V.validate_vcf_header(h)
+    for h in kats["vcf_header"]["invalid"]:
+        with pytest.raises(R.VcfError) as info:
+            V.validate_vcf_header(h)
+        assert info.value.kind == "InvalidVcfFormat"
+
+
+def test_find_vcf_file_reference_cases(tmp_path, kats):
+    k = kats["find_vcf_file"]
+    for name in k["files"]:
+        (tmp_path / name).write_text("")
+    for chrom, name in k["expect"].items():
+        assert V.find_vcf_file(str(tmp_path), chrom).endswith(name)
+    for chrom in k["missing"]:
+        with pytest.raises(Exception):
+            V.find_vcf_file(str(tmp_path), chrom)
+    with pytest.raises(Exception):
+        V.find_vcf_file("/non/existent/path", "1")
+
+
+def test_config_with_placeholder_columns(tmp_path, kats):
+    k = kats["config_with_noreads"]
+    (tmp_path / "c.tsv").write_text(k["config"])
+    assert len(V.parse_config_file(str(tmp_path / "c.tsv"))) == k["entries"]

@@ -52,3 +52,18 @@ def test_ingest_matches_oracle_parse(tmp_path, storage):
            for m in re.finditer(r"\[INGEST\] chr (\S+): (\d+) variants x (\d+) samples digest ([0-9a-f]{16})", res.stdout)}
     exp = oracle_digests(kw, min_gq=31, mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"))
     assert got == exp and len(got) == 3
+
+
+def test_cli_region_argument_matches_reference_rules(tmp_path, kats):
+    """--region goes through parse_region (parse.rs:241-261): the reference's valid/invalid cases at the CLI (no GPU needed)."""
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    kw, _ = make_cohort(tmp_path, seed=92, n_samples=6)
+    base = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--output_file", str(tmp_path / "o" / "o.csv"),
+            "--chr", "1", "--ingest_only"]
+    env = dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_THREADS="2")
+    for text in kats["parse_region"]["invalid"]:
+        res = subprocess.run(base + [f"--region={text}"], capture_output=True, text=True, env=env, timeout=120)
+        assert res.returncode != 0 and "InvalidRegion" in res.stderr, (text, res.stderr[-300:])
+    res = subprocess.run(base + ["--region", "1-1000"], capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0 and "[INGEST] chr 1:" in res.stdout, res.stderr[-500:]
