@@ -417,3 +417,33 @@ def test_reference_full_pipeline_shape(tmp_path):
         assert float(row["0_pi"]) > 0.0 and float(row["1_pi"]) > 0.0
         assert abs(float(row["0_pi"]) - float(row["0_pi_filtered"])) < 1e-9 and abs(float(row["1_pi"]) - float(row["1_pi_filtered"])) < 1e-9
         assert int(row["0_segregating_sites"]) > 0
+
+
+def test_group1_example_through_the_cli(tmp_path, kats):
+    """src/tests/stats_tests.rs setup_group1_test / test_group1_*: three samples, haplotype group 1 = {Sample1 R, Sample2 L,
+    Sample3 R} -> 3 haplotypes, 2 segregating sites, theta_W = 2 / H_2 / L."""
+    c = kats["process_variants"]["cases"][0]
+    length = 4000
+    seq = ("ACGT" * (length // 4 + 1))[:length]
+    hdr = ">chr1\n"
+    (tmp_path / "ref.fa").write_text(hdr + "\n".join(seq[i:i + 60] for i in range(0, length, 60)) + "\n")
+    (tmp_path / "ref.fa.fai").write_text(f"chr1\t{length}\t{len(hdr)}\t60\t61\n")
+    (tmp_path / "ann.gtf").write_text('chr1\t.\tCDS\t1\t100\t.\t+\t0\tgene_id "g"; transcript_id "t";\n')
+    os.makedirs(tmp_path / "vcfs")
+    names = c["sample_names"]
+    vcf = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"
+    for v in c["variants"]:
+        vcf += f"chr1\t{v['pos'] + 1}\t.\tA\tT\t.\tPASS\t.\tGT:GQ\t" + "\t".join(f"{g[0]}|{g[1]}:40" for g in v["g"]) + "\n"
+    (tmp_path / "vcfs" / "chr1.vcf").write_text(vcf)
+    a, b = c["interval"]   # 0-based half-open -> 1-based inclusive config columns
+    cfg = "seqnames\tstart\tend\tPOS\torig_ID\tverdict\tcateg\t" + "\t".join(names) + "\n"
+    cfg += f"chr1\t{a + 1}\t{b}\t1\tid\tpass\tinv\t" + "\t".join("|".join(str(x) for x in c["sample_filter"][n]) for n in names) + "\n"
+    (tmp_path / "config.tsv").write_text(cfg)
+    kw = dict(vcf_folder=str(tmp_path / "vcfs"), reference=str(tmp_path / "ref.fa"), gtf=str(tmp_path / "ann.gtf"),
+              config_file=str(tmp_path / "config.tsv"))
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), **kw)
+    compare(got, exp)
+    row = dict(zip(V.CSV_HEADER, got["out.csv"].splitlines()[1].split(",")))
+    assert row["1_num_hap_no_filter"] == "3" and row["1_segregating_sites"] == "2"
+    assert abs(float(row["1_w_theta"]) - 2.0 / 1.5 / (b - a)) < 1e-6

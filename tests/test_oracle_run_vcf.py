@@ -176,3 +176,28 @@ def test_config_with_placeholder_columns(tmp_path, kats):
     k = kats["config_with_noreads"]
     (tmp_path / "c.tsv").write_text(k["config"])
     assert len(V.parse_config_file(str(tmp_path / "c.tsv"))) == k["entries"]
+
+
+def test_process_variants_reference_cases(kats):
+    """src/tests/stats_tests.rs:1016-1481: haplotypes of a config group, segregating sites inside the group, theta_W with
+    n = assigned haplotypes and L = region length unless an adjusted length is given."""
+    from oracle import ferromic_ref as R
+
+    for c in kats["process_variants"]["cases"]:
+        variants = [R.make_variant(v["pos"], v["g"]) for v in c["variants"]]
+        sample_filter = {k: tuple(v) for k, v in c["sample_filter"].items()}
+        res = V.process_variants(variants, c["sample_names"], c["group"], sample_filter, tuple(c["interval"]), c["adjusted_len"],
+                                 c["is_filtered"], frozenset(), None, None)
+        assert res is not None, c["name"]
+        segsites, theta, pi, n_hap, _ = res
+        e = c["expect"]
+        if "n_hap" in e:
+            assert n_hap == e["n_hap"], c["name"]
+        if "segsites" in e:
+            assert segsites == e["segsites"], c["name"]
+        if "theta" in e:
+            num, h, L = e["theta"].split("/")
+            expected = {"2/H2/2001": 2.0 / R.harmonic(2) / 2001.0, "12/11/100": 12.0 / 11.0 / 100.0}[e["theta"]]
+            assert abs(theta - expected) < e["theta_abs_tol"], c["name"]
+        if "inversion_frequency" in e:
+            assert abs(R.calculate_inversion_allele_frequency(sample_filter) - e["inversion_frequency"]) < 1e-6
