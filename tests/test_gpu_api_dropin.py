@@ -401,3 +401,26 @@ def test_concurrent_python_threads_share_populations():
         t.join()
     assert not errors, errors[:1]
     assert len(results) == 48 and all(r == expected for r in results)
+
+
+def test_hudson_reference_property_cases_through_api(kats):
+    """src/tests/hudson_fst_tests.rs:20-298, 1009-1100 through the drop-in module."""
+    k = kats["hudson_properties"]
+    h1, h2 = [tuple(h) for h in k["pop1"]], [tuple(h) for h in k["pop2"]]
+    for c in k["cases"]:
+        variants = [build_variant(v["pos"], v["g"]) for v in c["variants"]]
+        p1 = fm.Population(0, variants, h1, c["L"], k["sample_names"])
+        p2 = fm.Population(1, variants, h2, c["L"], k["sample_names"])
+        if "region" not in c:
+            fst = fm.hudson_fst(p1, p2).fst
+            assert fst is not None and c["fst_min"] <= fst <= c["fst_max"], c["name"]
+            continue
+        outcome, sites = fm.hudson_fst_with_sites(p1, p2, tuple(c["region"]))
+        if "site_position" in c:
+            site = next(s for s in sites if s.position == c["site_position"])
+            assert abs(site.d_xy - c["dxy"]) < c["tol"] and abs(site.pi_pop1 - c["pi1"]) < c["tol"] and abs(site.pi_pop2 - c["pi2"]) < c["tol"]
+            assert abs(outcome.fst - site.fst) < c["tol"]
+        else:
+            assert len(sites) == c["n_sites"]
+            s = sites[0]
+            assert None not in (s.d_xy, s.pi_pop1, s.pi_pop2, s.fst) and c["site_fst_min"] <= s.fst <= c["site_fst_max"]

@@ -299,3 +299,27 @@ def test_dense_paths_agree_with_sparse_random():
             # quirk 4 (stats.rs:1591-1609): the summaries path drops pi_k at sites where the
             # OTHER population has n<2, so pi may differ from the per-population value.
             assert R.calculate_pi_for_population(summ[0]) == pytest.approx(o_s.pi_pop1, rel=1e-12)
+
+
+def test_hudson_reference_property_cases(kats):
+    """src/tests/hudson_fst_tests.rs:20-298, 1009-1100: the reference's range assertions on single-site cohorts."""
+    k = kats["hudson_properties"]
+    h1, h2 = [tuple(h) for h in k["pop1"]], [tuple(h) for h in k["pop2"]]
+    for c in k["cases"]:
+        variants = [R.make_variant(v["pos"], v["g"]) for v in c["variants"]]
+        p1 = R.PopulationContext(0, h1, variants, k["sample_names"], c["L"])
+        p2 = R.PopulationContext(1, h2, variants, k["sample_names"], c["L"])
+        if "region" not in c:
+            fst = R.calculate_hudson_fst_for_pair(p1, p2).fst
+            assert fst is not None and c["fst_min"] <= fst <= c["fst_max"], c["name"]
+            continue
+        outcome, sites = R.calculate_hudson_fst_for_pair_with_sites(p1, p2, R.QueryRegion(*c["region"]))
+        if "site_position" in c:
+            site = next(s for s in sites if s.position == c["site_position"])
+            assert abs(site.d_xy - c["dxy"]) < c["tol"] and abs(site.pi_pop1 - c["pi1"]) < c["tol"] and abs(site.pi_pop2 - c["pi2"]) < c["tol"]
+            assert abs(outcome.fst - site.fst) < c["tol"]
+        else:
+            assert len(sites) == c["n_sites"]
+            s = sites[0]
+            assert s.d_xy is not None and s.pi_pop1 is not None and s.pi_pop2 is not None and s.fst is not None
+            assert c["site_fst_min"] <= s.fst <= c["site_fst_max"]
