@@ -222,14 +222,16 @@ struct fmh_groups {
   uint8_t* masks = nullptr;  // [padded][mask_pitch], zero beyond the row
   size_t pitch = 0;
   size_t mask_pitch = 0;     // pitch rounded up to 2048: covers the kernels' zero-padded mask stride
+  uint16_t* mask_bits = nullptr;  // [padded][mask_pitch / 16]: the same masks as one 16-bit word per 16-byte vector
   uint32_t columns = 0;
   uint64_t sizes[FMH_MAX_GROUPS] = {0};
   std::vector<uint8_t> host_mask;  // [n_groups][columns] as handed in (the wide-matrix W&C route re-batches the groups)
 };
 
-// LDS the sweep needs for P (padded) groups of an `nvec`-vector row; the kernels take at most 150 KiB
-static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 16; }
+// LDS the sweep needs for P (padded) groups of an `nvec`-vector row, masks as bytes (fast) or as bits (8x the width);
+// the kernels take at most 150 KiB.  sweep_lds_bytes() > limit means "does not fit in LDS in either form".
 static const size_t kSweepLdsLimit = 150 * 1024;
+static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 2; }
 
 static int check_dims(size_t variants, size_t samples, size_t ploidy) {
   if (ploidy == 0 || samples == 0) return fail(FMH_ERR_INVALID, "samples and ploidy must be positive");
@@ -470,10 +472,17 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
     }
     g->sizes[p] = cnt;
   }
+  std::vector<uint16_t> bits((size_t)g->padded * (g->mask_pitch / 16), 0);
+  for (int p = 0; p < n_groups; ++p)
+    for (uint32_t h = 0; h < m->columns; ++h)
+      if (staged[(size_t)p * g->mask_pitch + h]) bits[(size_t)p * (g->mask_pitch / 16) + (h >> 4)] |= (uint16_t)(1u << (h & 15));
   hipError_t e = pool_malloc(g->device, (void**)&g->masks, staged.size());
   if (e == hipSuccess) e = hipMemcpy(g->masks, staged.data(), staged.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = pool_malloc(g->device, (void**)&g->mask_bits, bits.size() * 2);
+  if (e == hipSuccess) e = hipMemcpy(g->mask_bits, bits.data(), bits.size() * 2, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     pool_free(g->device, g->masks);
+    pool_free(g->device, g->mask_bits);
     delete g;
     return fail(FMH_ERR_HIP, "group mask upload failed: %s", hipGetErrorString(e));
   }
@@ -485,6 +494,7 @@ extern "C" int fmh_groups_destroy(fmh_groups* g) {
   if (!g) return FMH_OK;
   (void)hipSetDevice(g->device);
   pool_free(g->device, g->masks);
+  pool_free(g->device, g->mask_bits);
   delete g;
   return FMH_OK;
 }
@@ -581,9 +591,9 @@ extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int P, int MODE, bool MISSING, bool GENERAL, bool MASKG = false>
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes>
 static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStream_t st, int* grid_out) {
-  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL, MASKG>;
+  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL, MM>;
   static thread_local int cached_occ[64];
   static thread_local size_t cached_smem[64];
   int dev = 0;
@@ -613,10 +623,10 @@ static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStrea
   return FMH_OK;
 }
 
-template <int P, int MODE, bool MASKG = false>
+template <int P, int MODE, int MM = kMaskLdsBytes>
 static int launch_pm(Workspace* w, const SweepArgs& a, size_t smem, hipStream_t st, bool missing, bool general, int* grid) {
-  if (missing) return general ? launch_one<P, MODE, true, true, MASKG>(w, a, smem, st, grid) : launch_one<P, MODE, true, false, MASKG>(w, a, smem, st, grid);
-  return general ? launch_one<P, MODE, false, true, MASKG>(w, a, smem, st, grid) : launch_one<P, MODE, false, false, MASKG>(w, a, smem, st, grid);
+  if (missing) return general ? launch_one<P, MODE, true, true, MM>(w, a, smem, st, grid) : launch_one<P, MODE, true, false, MM>(w, a, smem, st, grid);
+  return general ? launch_one<P, MODE, false, true, MM>(w, a, smem, st, grid) : launch_one<P, MODE, false, false, MM>(w, a, smem, st, grid);
 }
 
 struct SweepResult {
@@ -643,6 +653,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   a.mv.nvec = m->nvec;
   a.masks = g->masks;
   a.mask_pitch = g->mask_pitch;
+  a.mask_bits = g->mask_bits;
   for (int p = 0; p < 8; ++p) a.group_size[p] = p < g->n_groups ? (uint32_t)g->sizes[p] : 0;
   a.n_groups = g->n_groups;
   a.max_allele = m->max_allele;
@@ -676,19 +687,45 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   a.unroll = env_unroll == 8 ? 8 : 4;
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
   size_t smem = (size_t)P * a.nvec_pad * 16;
-  const bool wide = smem > kSweepLdsLimit;  // the masks do not fit LDS: read them from global memory (L2) instead
-  if (wide) smem = 0;
+  int mask_mode = kMaskLdsBytes;
+  if (smem > kSweepLdsLimit) {  // byte masks do not fit LDS: bits in LDS if those fit, else bytes in global memory (L2)
+    smem = (size_t)P * a.nvec_pad * 2;
+    mask_mode = kMaskLdsBits;
+    if (smem > kSweepLdsLimit) { smem = 0; mask_mode = kMaskGlobalBytes; }
+  }
+  if (const char* force = getenv("FMH_MASK_MODE")) {  // tests and measurements: take a slower mask route than needed
+    const int want = atoi(force);
+    const bool global_ok = P <= 2 && mode != kModeWc;
+    if (want == kMaskLdsBits && mask_mode == kMaskLdsBytes) { smem = (size_t)P * a.nvec_pad * 2; mask_mode = kMaskLdsBits; }
+    if (want == kMaskGlobalBytes && global_ok) { smem = 0; mask_mode = kMaskGlobalBytes; }
+  }
   int grid = 0;
   int rc = FMH_ERR_UNSUPPORTED;
 #define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
-#define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, true>(w, a, smem, st, missing, general, &grid)
-  if (wide) {
+#define BITS(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskLdsBits>(w, a, smem, st, missing, general, &grid)
+#define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskGlobalBytes>(w, a, smem, st, missing, general, &grid)
+  if (mask_mode == kMaskGlobalBytes) {
     // one or two groups per sweep on this route (summaries and W&C re-batch their groups accordingly)
     if (mode == kModeSummary && P == 1) WIDE(1, kModeSummary);
     else if (mode == kModeSummary && P == 2) WIDE(2, kModeSummary);
     else if (mode == (kModeSummary | kModeHudson) && P == 2) WIDE(2, kModeSummary | kModeHudson);
     else if (mode == (kModeSummary | kModeDiversity) && P == 1) WIDE(1, kModeSummary | kModeDiversity);
     else return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
+  } else if (mask_mode == kMaskLdsBits) {
+    if (mode == kModeSummary) {
+      if (P == 1) BITS(1, kModeSummary); else if (P == 2) BITS(2, kModeSummary); else if (P == 4) BITS(4, kModeSummary); else BITS(8, kModeSummary);
+    } else if (mode == (kModeSummary | kModeHudson)) {
+      if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
+      BITS(2, kModeSummary | kModeHudson);
+    } else if (mode == (kModeSummary | kModeDiversity)) {
+      if (P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
+      BITS(1, kModeSummary | kModeDiversity);
+    } else if (mode == kModeWc) {
+      if (P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
+      if (P == 2) BITS(2, kModeWc); else if (P == 4) BITS(4, kModeWc); else BITS(8, kModeWc);
+    } else {
+      return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
+    }
   } else if (mode == kModeSummary) {
     if (P == 1) CASE(1, kModeSummary); else if (P == 2) CASE(2, kModeSummary); else if (P == 4) CASE(4, kModeSummary); else CASE(8, kModeSummary);
   } else if (mode == (kModeSummary | kModeHudson)) {
@@ -703,6 +740,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   } else {
     return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
   }
+#undef BITS
 #undef WIDE
 #undef CASE
   FMH_TRY(rc);

@@ -63,6 +63,7 @@ struct SweepArgs {
   MatrixView mv;
   const uint8_t* masks;   // device [P][mask_pitch] 0/1 bytes, zero beyond the row
   size_t mask_pitch;      // bytes per mask: pitch rounded up to 2048 (>= nvec_pad * 16)
+  const uint16_t* mask_bits;  // device [P][mask_pitch / 16]: bit b of word v = column 16 v + b is a member
   uint32_t group_size[8]; // mask popcounts
   uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
   int unroll;             // vectors per lane issued back to back (4 or 8)
@@ -373,13 +374,24 @@ __device__ __forceinline__ uint4 called_bytes(uint32_t bits16) {
   return v;
 }
 
+// Where a sweep keeps its membership masks.  Bytes in LDS are the fast form (one ds_read_b128 per vector and group);
+// when P masks of the row width exceed the LDS budget the masks are kept as BITS in LDS (one 16-bit word per vector,
+// expanded to 0/1 bytes in registers: 8x the width for ~16 VALU ops per vector and group); beyond that, bytes in
+// global memory (L2), for one or two groups.
+constexpr int kMaskLdsBytes = 0, kMaskGlobalBytes = 1, kMaskLdsBits = 2;
+template <int MM>
+__device__ __forceinline__ uint4 mask_vec(const void* base, uint32_t idx) {
+  if constexpr (MM == kMaskLdsBits) return called_bytes(reinterpret_cast<const uint16_t*>(base)[idx]);
+  else return reinterpret_cast<const uint4*>(base)[idx];
+}
+
 // Biallelic row: alt[p] = sum of allele bytes over called members, n[p] = called members.
 // The row is consumed in batches of U vectors per lane: the U global loads are issued back to back
 // (U KiB in flight per wave) before the first dot4, so memory-level parallelism does not depend on
 // occupancy alone.  LDS masks are zero-padded to nvec_pad (a multiple of 16*U) and the load address
 // is clamped to the last vector of the row, so the loop is uniform and branch-free.
-template <int P, bool MISSING, bool NEED_ALL, int U>
-__device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+template <int P, bool MISSING, bool NEED_ALL, int U, int MM>
+__device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const void* __restrict__ lds_mask,
                                                     uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
                                                     const uint8_t* __restrict__ bits_ptr, int gl,
                                                     uint32_t (&alt)[P], uint32_t (&n)[P], uint32_t& n_all) {
@@ -407,7 +419,7 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
+        uint4 m = mask_vec<MM>(lds_mask, (uint32_t)p * nvec_pad + v);  // zero beyond the row
         if (MISSING) {
           m.x &= cb.x; m.y &= cb.y; m.z &= cb.z; m.w &= cb.w;
           n[p] = dot4(m.x, 0x01010101u, n[p]);
@@ -435,8 +447,8 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
 //   c3 = s01, c1 = s0 - s01, c2 = s1 - s01, c0 = n - c1 - c2 - c3.
 // Also returns n[p], n_all and the OR of the called allele values.  Loads are batched like the
 // biallelic core (U vectors in flight per lane).
-template <int P, bool MISSING, int U>
-__device__ __forceinline__ void count_row_planes(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+template <int P, bool MISSING, int U, int MM>
+__device__ __forceinline__ void count_row_planes(const MatrixView& mv, const void* __restrict__ lds_mask,
                                                  uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
                                                  const uint8_t* __restrict__ bits_ptr, int gl, uint32_t (&n)[P],
                                                  uint32_t& n_all, uint32_t& allele_or, uint32_t (&s0)[P],
@@ -473,7 +485,7 @@ __device__ __forceinline__ void count_row_planes(const MatrixView& mv, const uin
       const uint4 bb = make_uint4(b0.x & b1.x, b0.y & b1.y, b0.z & b1.z, b0.w & b1.w);
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
+        uint4 m = mask_vec<MM>(lds_mask, (uint32_t)p * nvec_pad + v);  // zero beyond the row
         if (MISSING) {
           m.x &= cb.x; m.y &= cb.y; m.z &= cb.z; m.w &= cb.w;
           n[p] = dot4(m.x, 0x01010101u, n[p]); n[p] = dot4(m.y, 0x01010101u, n[p]);
@@ -495,8 +507,8 @@ __device__ __forceinline__ void count_row_planes(const MatrixView& mv, const uin
 }
 
 // General row, pass per allele value a: c[p] = called members carrying allele a.
-template <int P, bool MISSING>
-__device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uint4* __restrict__ lds_mask,
+template <int P, bool MISSING, int MM>
+__device__ __forceinline__ void count_row_allele(const MatrixView& mv, const void* __restrict__ lds_mask,
                                                  uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
                                                  const uint8_t* __restrict__ bits_ptr, bool row_ok, int gl,
                                                  uint32_t a, uint32_t (&c)[P]) {
@@ -520,7 +532,7 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const uin
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row (v < nvec_pad always)
+        uint4 m = mask_vec<MM>(lds_mask, (uint32_t)p * nvec_pad + v);  // zero beyond the row (v < nvec_pad always)
         c[p] = dot4(e.x, m.x, c[p]);
         c[p] = dot4(e.y, m.y, c[p]);
         c[p] = dot4(e.z, m.z, c[p]);
@@ -744,18 +756,26 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
 // ------------------------------------------------------------------------------------------------
 // the sweep kernel
 // ------------------------------------------------------------------------------------------------
-// MASKG = the membership masks are read from global memory (L2-resident) instead of LDS: the route for rows so wide
-// that P masks exceed the LDS budget (more than 153 600 haplotypes for one group, 76 800 for a Hudson pair).
-template <int P, int MODE, bool MISSING, bool GENERAL, bool MASKG = false>
+// MM = where the membership masks live (kMaskLdsBytes / kMaskGlobalBytes / kMaskLdsBits, see mask_vec).
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   const MatrixView mv = A.mv;
   const uint32_t nvec = mv.nvec;
   uint32_t nvec_pad = A.nvec_pad;
-  const uint4* lds_mask;
-  if constexpr (MASKG) {
-    lds_mask = reinterpret_cast<const uint4*>(A.masks);
+  const void* lds_mask;
+  if constexpr (MM == kMaskGlobalBytes) {
+    lds_mask = A.masks;
     nvec_pad = (uint32_t)(A.mask_pitch / 16);  // the stride between the masks of two groups, in vectors
+  } else if constexpr (MM == kMaskLdsBits) {
+    // one 16-bit word per vector and group, zero beyond the row (the host lays them out with the same padded stride)
+    uint16_t* staged = reinterpret_cast<uint16_t*>(smem);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec_pad; i += kBlock) {
+      const uint32_t p = i / nvec_pad, v = i - p * nvec_pad;
+      staged[i] = v < nvec ? A.mask_bits[(size_t)p * (A.mask_pitch / 16) + v] : (uint16_t)0;
+    }
+    __syncthreads();
+    lds_mask = staged;
   } else {
     // stage the P membership masks into LDS (16 B per thread per step), zero-padded to nvec_pad
     uint4* staged = reinterpret_cast<uint4*>(smem);
@@ -803,8 +823,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       if constexpr (!GENERAL) {
         uint32_t alt[P], n[P], n_all;
         // rows past the end are clamped to the last row (their results are discarded by row_ok)
-        if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
-        else count_row_biallelic<P, MISSING, NEED_ALL, 4>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+        if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+        else count_row_biallelic<P, MISSING, NEED_ALL, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
         if (own) {
 #pragma unroll
           for (int p = 0; p < P; ++p) {
@@ -815,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         }
       } else {
         uint32_t n[P], n_all, aor, s0[P], s1[P], s01[P];
-        count_row_planes<P, MISSING, 4>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+        count_row_planes<P, MISSING, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
         if (!MISSING) {
 #pragma unroll
           for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
@@ -878,7 +898,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         } else {
           for (uint32_t a = 0; a <= bound; ++a) {
             uint32_t c[P];
-            count_row_allele<P, MISSING>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
+            count_row_allele<P, MISSING, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
             if (own) consume(a, c);
           }
         }

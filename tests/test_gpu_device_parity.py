@@ -121,7 +121,7 @@ SPARSE_CASES = [
     (150, 21, 1, 0.15, 0.05, 2),
     (90, 33, 3, 0.1, 0.1, 1),
     (40, 300, 2, 0.02, 0.0, 0),
-    (5, 90_000, 1, 0.02, 0.0, 0),  # 180 000 columns: wide route for the Hudson pair and the one-group diversity sweep
+    (5, 90_000, 1, 0.02, 0.0, 0),  # 180 000 columns: bit masks in LDS for the Hudson pair and the one-group diversity sweep
 ]
 
 
@@ -184,7 +184,7 @@ WC_CASES = [
     (100, 40, 4, 1, 0.05, 0.0, 1, 4),
     (80, 30, 3, 3, 0.1, 0.05, 1, 2),
     (60, 50, 5, 2, 0.05, 0.0, 0, 5),
-    (4, 60_000, 3, 1, 0.02, 0.0, 0, 7),  # 120 000 columns: W&C re-batches to two groups per (wide) counting sweep
+    (4, 60_000, 3, 1, 0.02, 0.0, 0, 7),  # 120 000 columns: fused W&C with bit masks in LDS
 ]
 
 
@@ -328,3 +328,76 @@ def test_rows_wider_than_lds_for_all_masks(dev):
             k8 = slot8[(keep[x], keep[y])]
             assert np.array_equal(w4.a[k4], w.a[k8]) and np.array_equal(w4.b[k4], w.b[k8])
             k4 += 1
+
+
+def test_mask_routes_agree(dev, monkeypatch):
+    """The sweep keeps the group masks as bytes in LDS, as bits in LDS (rows too wide for bytes) or as bytes in global
+    memory (rows too wide for bits); FMH_MASK_MODE forces the slower routes on rows that do not need them.  All three
+    must give the same bits, with and without missing calls, on the biallelic and the general counting paths."""
+    rng = np.random.default_rng(4242)
+    for (S, N, max_allele, p_missing) in ((70, 900, 1, 0.0), (70, 901, 1, 0.03), (40, 1300, 3, 0.02), (33, 777, 6, 0.0)):
+        m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
+        dm = upload(dev, m)
+        cut = N // 3
+        lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, N - 5))]
+        g2 = dev.Groups.from_haplotype_lists(dm, lists)
+        g1 = dev.Groups.from_haplotype_lists(dm, lists[:1])
+        thirds = [H.haps_for_samples(range(i, N, 3)) for i in range(3)]
+        g3 = dev.Groups.from_haplotype_lists(dm, thirds)
+
+        def run():
+            hs = dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE)
+            dv = dev.diversity_sites(dm, g1)
+            w = dev.wc_sweep(dm, g3)
+            ps = dev.population_summaries(dm, g3, dev.FORMULA_SUMMARY)
+            return hs, dv, w, ps
+
+        monkeypatch.delenv("FMH_MASK_MODE", raising=False)
+        base = run()
+        for forced in ("2", "1"):
+            monkeypatch.setenv("FMH_MASK_MODE", forced)
+            got = run()
+            for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+                H.assert_bits_equal(got[0].sites[k], base[0].sites[k], f"{k} mode {forced}")
+            assert got[0].totals == base[0].totals and got[0].pop == base[0].pop
+            H.assert_bits_equal(got[1].pi, base[1].pi, "site pi")
+            H.assert_bits_equal(got[1].theta, base[1].theta, "site theta")
+            assert np.array_equal(got[2].a, base[2].a, equal_nan=True) and np.array_equal(got[2].b, base[2].b, equal_nan=True)
+            assert np.array_equal(got[2].state, base[2].state) and np.array_equal(got[2].group_called, base[2].group_called)
+            assert np.array_equal(got[3].alt, base[3].alt) and np.array_equal(got[3].called, base[3].called)
+            assert got[3].totals == base[3].totals
+        monkeypatch.delenv("FMH_MASK_MODE", raising=False)
+
+
+def test_eight_groups_on_rows_beyond_the_bit_mask_budget(dev):
+    """160 000 haplotypes x 8 groups: even as bits the eight masks pass the LDS budget (8 x 10 048 x 2 B > 150 KiB),
+    so W&C goes through the counts path in batches of four groups; a fused four-group sweep (bit masks) must give the
+    same numbers on the slots they share."""
+    rng = np.random.default_rng(77)
+    S, N, G = 6, 80_000, 8
+    m = H.random_dense_matrix(rng, S, N, 2, 1, 0.01)
+    dm = upload(dev, m)
+    pop_of_sample = rng.integers(0, G, size=N)
+    lists = [H.haps_for_samples(np.nonzero(pop_of_sample == g)[0].tolist()) for g in range(G)]
+    masks = np.stack([dev.Groups.mask_from_haplotypes(dm, hl) for hl in lists])
+    groups = dev.Groups(dm, masks)
+    got = dev.population_summaries(dm, groups, dev.FORMULA_SUMMARY)
+    w = dev.wc_sweep(dm, groups)
+    assert np.array_equal(w.group_called, got.called)
+    keep = [1, 2, 4, 7]
+    w4 = dev.wc_sweep(dm, dev.Groups(dm, masks[keep]))
+    slot8, k = {}, 1
+    for i in range(G):
+        for j in range(i + 1, G):
+            slot8[(i, j)] = k
+            k += 1
+    k4 = 1
+    for x in range(4):
+        for y in range(x + 1, 4):
+            k8 = slot8[(keep[x], keep[y])]
+            assert np.array_equal(w4.a[k4], w.a[k8], equal_nan=True) and np.array_equal(w4.b[k4], w.b[k8], equal_nan=True)
+            k4 += 1
+    for g in (0, 5):
+        exp = R.build_dense_population_summary(m, lists[g])
+        assert np.array_equal(got.alt[g], np.array(exp.alt_counts, dtype=np.uint32))
+        assert np.array_equal(got.called[g], np.array(exp.called_counts, dtype=np.uint32))

@@ -26,7 +26,7 @@ CONFIGS = {
     "C5": (2_000_000, 10_000, 2, "hudson", 0.0),
     "C3h": (5_000_000, 2_500, 4, "summaries", 0.0),
     "C2x10": (10_000_000, 1_000, 2, "hudson", 0.0),  # C2 rows, 10x the sites: separates fixed launch cost from per-row efficiency
-    "WIDE": (100_000, 200_000, 2, "hudson", 0.0),  # masks beyond the LDS budget: global-mask route
+    "WIDE": (100_000, 200_000, 2, "hudson", 0.0),  # byte masks beyond the LDS budget: bit masks in LDS (FMH_MASK_MODE=1: global)
 }
 
 
