@@ -108,6 +108,7 @@ SYMBOLS = {
     "fmh_device_release_scratch": (_i, [_i]),
     "fmh_copy_to_host": (_i, [_i, _vp, _vp, _sz, _vp]),
     "fmh_copy_to_device": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "fmh_device_zero": (_i, [_i, _vp, _sz, _vp]),
     "fmh_stream_synchronize": (_i, [_i, _vp]),
     "fmh_matrix_create": (_i, [_vp, _vp, _sz, _sz, _sz, _u8, _i, _P(_vp)]),
     "fmh_matrix_alloc": (_i, [_sz, _sz, _sz, _i, _u8, _i, _P(_vp)]),

@@ -193,6 +193,11 @@ extern "C" int fmh_copy_to_device(int device, void* d_dst, const void* h_src, si
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return FMH_OK;
 }
+extern "C" int fmh_device_zero(int device, void* d_ptr, size_t bytes, void* stream) {
+  FMH_TRY(use_device(device));
+  if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, (hipStream_t)stream));
+  return FMH_OK;
+}
 extern "C" int fmh_stream_synchronize(int device, void* stream) {
   FMH_TRY(use_device(device));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

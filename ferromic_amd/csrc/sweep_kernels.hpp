@@ -117,6 +117,11 @@ __device__ __forceinline__ uint32_t dpp(uint32_t x) {
 // all-reduce (sum) inside one 16-lane DPP row: xor-1, xor-2 via quad_perm, then row_half_mirror,
 // then row_mirror.  Every lane of the row ends with the row total.
 __device__ __forceinline__ uint32_t row16_sum(uint32_t x) {
+  // gfx950 hazard: a v_dot4 result read by a DPP op needs 3 wait states.  hipcc (ROCm 7.2) leaves only the 2 of its
+  // VALU->DPP rule when the last dot4 of a loop and the reduction sit in different basic blocks; the reduction then
+  // misses that dot4 (found by the counting fuzz: one-group general sweeps lost bytes 12..15 of the last vectors).
+  // Every value reduced here is a dot4 accumulator, so the wait states are spelled out, tied to the value.
+  asm volatile("s_nop 3" : "+v"(x));
   x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
   x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
   x += dpp<0x141>(x);  // row_half_mirror
@@ -518,8 +523,7 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const voi
   const uint32_t a4 = a * 0x01010101u;
   if (row_ok) {
     // The same trip count for every lane of the group (lanes past the row re-read its last vector; their mask vectors
-    // are zero): the 16-lane DPP reduction below must see a converged row.  Two vectors per lane per trip, written out by
-    // hand: a `#pragma unroll 2` remainder loop on this code lost counts on rows of <= 16 vectors (found by the fuzz).
+    // are zero): the 16-lane DPP reduction below must see a converged row.  Two vectors per lane per trip.
     auto one = [&](uint32_t v) {
       const uint32_t vc = v < nvec ? v : nvec - 1;
       uint4 g = load_vec(row_ptr + (size_t)vc * 16);

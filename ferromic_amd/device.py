@@ -306,10 +306,9 @@ def pairwise_differences(m: DeviceMatrix, n_samples: int):
     """fmh_pairwise_differences -> (diff, both) as [n, n] uint64 arrays (upper triangle filled)."""
     n = int(n_samples)
     d_diff, d_both = DeviceBuffer(m.device, 8 * n * n), DeviceBuffer(m.device, 8 * n * n)
-    zero = np.zeros(n * n, dtype=np.uint64)
     lib = _abi.load()
     if n:
-        _abi.check(lib.fmh_copy_to_device(m.device, d_diff.ptr, _ptr(zero), zero.nbytes, None))
-        _abi.check(lib.fmh_copy_to_device(m.device, d_both.ptr, _ptr(zero), zero.nbytes, None))
+        _abi.check(lib.fmh_device_zero(m.device, d_diff.ptr, 8 * n * n, None))
+        _abi.check(lib.fmh_device_zero(m.device, d_both.ptr, 8 * n * n, None))
     _abi.check(lib.fmh_pairwise_differences(m._h, n, d_diff.ptr, d_both.ptr, None))
     return d_diff.to_numpy(np.uint64, n * n).reshape(n, n), d_both.to_numpy(np.uint64, n * n).reshape(n, n)

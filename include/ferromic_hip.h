@@ -70,6 +70,8 @@ int fmh_device_alloc(int device, size_t bytes, void** d_out);
 int fmh_device_free(int device, void* d_ptr);
 int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
 int fmh_copy_to_device(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
+/* zero-fills device memory, stream-ordered (no synchronisation): accumulators such as fmh_pairwise_differences' outputs */
+int fmh_device_zero(int device, void* d_ptr, size_t bytes, void* stream);
 int fmh_stream_synchronize(int device, void* stream);
 /* Frees the scratch the library keeps between calls on `device` (the sample-major planes of
  * fmh_pairwise_differences, up to 8 GiB); it is re-created on demand. */
@@ -248,7 +250,7 @@ int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_mask, int n_g
  *                     (len_i*len_j - sum_a cnt_i(a)*cnt_j(a)),
  *   d_both[i*n + j] = number of sites where both genotypes are Some
  * (comparable sites = L*h_i*h_j - (variants - both)*h_i*h_j is host arithmetic, stats.rs:4182-4208).
- * Both buffers must be zeroed by the caller.  Needs ploidy <= 127 (int8 MFMA operands); one allele-count plane per allele value 0..max_allele.
+ * The call ADDS into both buffers (several matrices of the same samples can be accumulated): zero them first (fmh_device_zero).  Needs ploidy <= 127 (int8 MFMA operands); one allele-count plane per allele value 0..max_allele.
  */
 int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
                              unsigned long long* d_both, void* stream);
