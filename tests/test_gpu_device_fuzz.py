@@ -81,6 +81,62 @@ def test_random_geometry_counts(dev, seed):
         assert np.array_equal(wm.a, w.a) and np.array_equal(wm.b, w.b) and np.array_equal(wm.state, w.state)
 
 
+@pytest.mark.parametrize("seed", range(CASES))
+def test_random_geometry_hudson_and_diversity(dev, seed):
+    """The two-group Hudson sweep and the one-group diversity sweep over the same random geometries: counts exactly,
+    per-site pi / theta / D_xy against the formulas evaluated in numpy float64 (1e-12: same operations, other order)."""
+    rng = np.random.default_rng(77000 + seed)
+    N = int(rng.choice(WIDTHS))
+    S = int(rng.choice(ROWS))
+    ploidy = int(rng.choice([1, 2, 2, 3]))
+    H = N * ploidy
+    max_allele = int(rng.choice([1, 1, 2, 3, 4, 7, 9]))
+    p_missing = float(rng.choice([0.0, 0.0, 0.03, 0.3]))
+    data = rng.integers(0, max_allele + 1, size=(S, H), dtype=np.uint8)
+    data[rng.random((S, H)) < 0.5] = 0
+    data[0, 0] = max_allele
+    miss = rng.random((S, H)) < p_missing if p_missing > 0 else np.zeros((S, H), dtype=bool)
+    data[miss] = 0
+    words = None
+    if p_missing > 0:
+        bits = np.packbits(miss.reshape(-1), bitorder="little")
+        pad = (-len(bits)) % 8
+        words = np.frombuffer(np.concatenate([bits, np.zeros(pad, np.uint8)]).tobytes(), dtype="<u8").copy()
+    dm = dev.DeviceMatrix.from_host(data.reshape(-1), words, S, N, ploidy, max_allele)
+    masks = (rng.random((2, H)) < rng.choice([0.1, 0.5, 0.9])).astype(np.uint8)
+    masks[0, 0] = 1
+    counts = np.stack([np.stack([(((data == a) & ~miss) * masks[g][None, :]).sum(axis=1) for g in range(2)])
+                       for a in range(max_allele + 1)]).astype(np.float64)           # [A][2][S]
+    n = counts.sum(axis=0)                                                            # [2][S]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        freq = counts / n[None]
+        pi = np.where(n >= 2, n / (n - 1.0) * (1.0 - (freq ** 2).sum(axis=0)), np.nan)
+        dxy = np.where((n[0] > 0) & (n[1] > 0), np.clip(1.0 - (freq[:, 0] * freq[:, 1]).sum(axis=0), 0.0, 1.0), np.nan)
+    distinct = (counts > 0).sum(axis=0)
+
+    def close(got, exp, what):
+        assert np.array_equal(np.isnan(got), np.isnan(exp)), what
+        ok = ~np.isnan(exp)
+        assert np.allclose(got[ok], exp[ok], rtol=1e-12, atol=1e-13), what
+
+    hs = dev.hudson_sweep(dm, dev.Groups(dm, masks), dev.FORMULA_DENSE)
+    assert np.array_equal(hs.sites["called"], n.astype(np.uint32))
+    if max_allele >= 1:
+        assert np.array_equal(hs.sites["alt"], counts[1].astype(np.uint32))
+    close(hs.sites["dxy"], dxy, "dxy")
+    close(hs.sites["pi1"], pi[0], "pi1")
+    close(hs.sites["pi2"], pi[1], "pi2")
+    for g in range(2):
+        assert hs.pop[g]["segregating_sites"] == int((distinct[g] >= 2).sum())
+    dv = dev.diversity_sites(dm, dev.Groups(dm, masks[:1]))
+    assert np.array_equal(dv.called, n[0].astype(np.uint32))
+    assert np.array_equal(dv.distinct, distinct[0].astype(np.uint32))
+    close(dv.pi, pi[0], "site pi")
+    harmonic = np.concatenate([[0.0], np.cumsum(1.0 / np.arange(1, H + 2))])
+    theta = np.where(n[0] >= 2, np.where(distinct[0] >= 2, 1.0 / harmonic[np.maximum(n[0].astype(int) - 1, 1)], 0.0), np.nan)
+    close(dv.theta, theta, "site theta")
+
+
 @pytest.mark.parametrize("N,S,max_allele,p_missing", [(600, 300, 1, 0.0), (513, 257, 3, 0.05), (300, 1000, 2, 0.0), (257, 129, 1, 0.2)])
 def test_pairwise_gram_multi_tile(dev, N, S, max_allele, p_missing):
     """fmh_pairwise_differences across several 256-sample tiles (diagonal and off-diagonal tile pairs, K slices, ragged edges)
