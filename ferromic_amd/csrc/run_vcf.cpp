@@ -164,8 +164,12 @@ string trim_start_matches(string s, const string& p) {
 }
 bool ends_with(const string& s, const string& x) { return s.size() >= x.size() && s.compare(s.size() - x.size(), x.size(), x) == 0; }
 bool starts_with(const string& s, const string& x) { return s.compare(0, x.size(), x) == 0; }
+// Rust str::parse::<i64>: optional sign, ASCII digits only (strtoll alone would also take leading whitespace)
 bool parse_i64(const string& s, int64_t* out) {
-  if (s.empty()) return false;
+  size_t i = (!s.empty() && (s[0] == '+' || s[0] == '-')) ? 1 : 0;
+  if (i >= s.size()) return false;
+  for (size_t k = i; k < s.size(); ++k)
+    if (s[k] < '0' || s[k] > '9') return false;
   char* end = nullptr;
   errno = 0;
   long long v = strtoll(s.c_str(), &end, 10);
@@ -1867,6 +1871,13 @@ int run(const Args& args) {
           mix((uint8_t)v.stride);
           for (uint8_t b : v.data) mix(b);
         }
+        if (getenv("FERROMIC_INGEST_DUMP"))  // one line per variant, for diffing against the oracle's parse
+          for (size_t i = 0; i < vcf.variants.size(); ++i) {
+            const Variant& v = vcf.variants[i];
+            printf("[VARIANT] %lld %u %zu ", (long long)v.position, (unsigned)vcf.flags[i], (size_t)v.stride);
+            for (uint8_t b : v.data) printf("%02x", b);
+            printf("\n");
+          }
         printf("[INGEST] chr %s: %zu variants x %zu samples digest %016llx\n", chr.c_str(), vcf.variants.size(), vcf.sample_names.size(),
                (unsigned long long)h);
         continue;

@@ -33,10 +33,8 @@ def parse_regions_file(path: str) -> Dict[str, List[Tuple[int, int]]]:
             if len(fields) < 3:
                 continue
             chrom = _trim_start_matches(fields[0], "chr")
-            try:
-                raw_start = int(fields[1])
-                raw_end = int(fields[2])
-            except ValueError:
+            raw_start, raw_end = _parse_i64(fields[1]), _parse_i64(fields[2])
+            if raw_start is None or raw_end is None:
                 continue
             if is_bed:
                 iv = (_as_usize(raw_start), _as_usize(raw_end))
@@ -114,17 +112,18 @@ def parse_config_file(path: str) -> List[ConfigEntry]:
         if len(record) != len(headers):
             raise R.VcfError("Parse", f"Mismatched number of fields in record on line {line_num + 2}")
         seqname = _trim_start_matches(record[0].strip(), "chr")
-        try:
-            start_pos, end_pos = int(record[1]), int(record[2])
-        except ValueError:
-            raise R.VcfError("Parse", "Invalid start") from None
+        start_pos, end_pos = _parse_i64(record[1]), _parse_i64(record[2])
+        if start_pos is None:
+            raise R.VcfError("Parse", "Invalid start")
+        if end_pos is None:
+            raise R.VcfError("Parse", "Invalid end")
         interval = R._hal_from_1based_inclusive(start_pos, end_pos)
         unf: Dict[str, Tuple[int, int]] = {}
         fil: Dict[str, Tuple[int, int]] = {}
         for i, fld in enumerate(record[7:]):
             name = sample_names[i]
             g = fld.split("_")[0]
-            if len(g) >= 3 and g[1] == "|" and g[0].isdigit() and g[2].isdigit():
+            if len(g) >= 3 and g[1] == "|" and g[0] in "0123456789" and g[2] in "0123456789":
                 left, right = int(g[0]), int(g[2])
                 if left <= 1 and right <= 1:
                     unf[name] = (left, right)
@@ -225,7 +224,8 @@ def find_vcf_file(folder: str, chrom: str) -> str:
 
 
 def open_text(path: str):
-    return gzip.open(path, "rt") if path.endswith(".gz") else open(path)
+    # newline="\n": lines end at LF only and keep a CR, as BufRead::read_line does
+    return gzip.open(path, "rt", newline="\n") if path.endswith(".gz") else open(path, newline="\n")
 
 
 def read_fai(reference_path: str) -> Dict[str, Tuple[int, int, int, int]]:
@@ -300,6 +300,15 @@ def _normalize_chr_prefix(c: str) -> str:
     return c
 
 
+def _parse_i64(s: str) -> Optional[int]:
+    """str::parse::<i64>: optional sign, ASCII digits only (no whitespace, no underscores), range checked."""
+    body = s[1:] if s[:1] in ("+", "-") else s
+    if not body or not body.isascii() or not body.isdigit():
+        return None
+    v = int(s)
+    return v if -(1 << 63) <= v < (1 << 63) else None
+
+
 def _parse_u8(s: str) -> Optional[int]:
     if s.startswith("+"):
         s = s[1:]
@@ -328,10 +337,9 @@ def process_variant(line: str, chrom: str, regions, kept_cols, min_gq: int, allo
     vcf_chr = _normalize_chr_prefix(fields[0].strip())
     if vcf_chr != _normalize_chr_prefix(chrom.strip()):
         return None
-    try:
-        pos1 = int(fields[1])
-    except ValueError:
-        raise R.VcfError("Parse", "Invalid position") from None
+    pos1 = _parse_i64(fields[1])
+    if pos1 is None:
+        raise R.VcfError("Parse", "Invalid position")
     if pos1 < 1:
         raise R.VcfError("Parse", f"Invalid 1-based pos: {pos1}")
     pos0 = pos1 - 1
