@@ -447,3 +447,19 @@ def test_group1_example_through_the_cli(tmp_path, kats):
     row = dict(zip(V.CSV_HEADER, got["out.csv"].splitlines()[1].split(",")))
     assert row["1_num_hap_no_filter"] == "3" and row["1_segregating_sites"] == "2"
     assert abs(float(row["1_w_theta"]) - 2.0 / 1.5 / (b - a)) < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FERROMIC_FUZZ_PIPELINE_CASES", "10"))))
+def test_adversarial_text_full_pipeline(tmp_path, seed):
+    """The adversarial VCF text of tests/test_run_vcf_ingest_fuzz_cpu.py (ragged ploidy, triploid and haploid calls, alleles
+    up to 255, half-missing calls, duplicate and unsorted positions, broken lines) through the WHOLE binary - matrices,
+    GPU sweeps, all writers - against the oracle pipeline."""
+    from tests.test_run_vcf_ingest_fuzz_cpu import build
+
+    kw = build(tmp_path, 7000 + seed)
+    kw.update(enable_fst=True, min_gq=[30, 0, 46][seed % 3])
+    if seed % 2:
+        kw.update(mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"))
+    exp = V.run(output_file=str(tmp_path / "oracle" / "out.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "out.csv"), **kw)
+    compare(got, exp)
