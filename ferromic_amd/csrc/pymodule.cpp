@@ -22,6 +22,7 @@
 #include <optional>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ferromic_hip.h"
@@ -358,9 +359,37 @@ struct Store {
 };
 
 // DenseGenotypeMatrix built by from_numpy (lib.rs:1208-1224): per-allele missing flags
+// byte array without vector's zero fill (a 1 GB matrix is written exactly once, by several threads)
+struct ByteBuf {
+  std::unique_ptr<uint8_t[]> p;
+  size_t n = 0;
+  void resize(size_t k) { p.reset(k ? new uint8_t[k] : nullptr); n = k; }  // contents unspecified
+  uint8_t* data() { return p.get(); }
+  const uint8_t* data() const { return p.get(); }
+  size_t size() const { return n; }
+  uint8_t& operator[](size_t i) { return p[i]; }
+  const uint8_t& operator[](size_t i) const { return p[i]; }
+};
+
+// fn(begin, end, worker) over [0, total) on up to 16 host threads (callers hold the GIL; fn touches no Python object)
+template <class F>
+void parallel_ranges(size_t total, F fn) {
+  const size_t grain = (size_t)4 << 20;
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t workers = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (total + grain - 1) / grain);
+  if (workers <= 1) { fn((size_t)0, total, (size_t)0); return; }
+  vector<std::thread> pool;
+  const size_t step = (total + workers - 1) / workers;
+  for (size_t w = 0; w < workers; ++w) {
+    const size_t b = std::min(total, w * step), e = std::min(total, b + step);
+    pool.emplace_back([=, &fn] { fn(b, e, w); });
+  }
+  for (auto& t : pool) t.join();
+}
+
 struct Dense {
   int64_t variants = 0, samples = 0, ploidy = 0;
-  vector<uint8_t> g;     // [S][N][P], negatives stored as 0
+  ByteBuf g;             // [S][N][P], negatives stored as 0
   vector<uint8_t> neg;   // empty = nothing missing, else one flag per entry
   int max_allele = 0;
   shared_ptr<DevMatrix> device;
@@ -510,30 +539,50 @@ vector<int64_t> extract_positions(const py::handle& obj, int64_t expected_len) {
 
 // build_variants_from_numpy + convert_numeric_array, lib.rs:1082-1227
 template <class T>
-void convert_block(const py::array& arr, vector<uint8_t>& g, vector<uint8_t>& neg, bool* any_neg) {
+void convert_block(const py::array& arr, ByteBuf& g, vector<uint8_t>& neg, bool* any_neg, int* max_allele) {
   auto a = py::array_t<T, py::array::c_style | py::array::forcecast>(arr);
   const T* src = a.data();
   const size_t total = (size_t)a.size();
-  *any_neg = false;
-  if constexpr (std::is_same<T, uint8_t>::value) {  // uint8 can never be missing (lib.rs:1086-1090): one copy
-    g.assign(src, src + total);
-    return;
-  }
   g.resize(total);
-  bool negs = false;
-  for (size_t i = 0; i < total; ++i) {
-    const T v = src[i];
-    if constexpr (sizeof(T) > 1) {
-      if ((std::is_signed<T>::value ? (int64_t)v : (int64_t)(uint64_t)v) > 255) value_error("allele values must be <= 255");
+  uint8_t* dst = g.data();
+  uint8_t w_max[16] = {0};
+  uint8_t w_neg[16] = {0}, w_big[16] = {0};
+  // one pass per thread: copy / narrow, byte maximum, and whether anything is negative (uint8 can never be missing,
+  // lib.rs:1086-1090) or beyond u8
+  parallel_ranges(total, [&](size_t b, size_t e, size_t w) {
+    uint8_t mx = 0;
+    bool negs = false, big = false;
+    if constexpr (std::is_same<T, uint8_t>::value) {
+      memcpy(dst + b, src + b, e - b);
+      for (size_t i = b; i < e; ++i) mx = src[i] > mx ? src[i] : mx;
+    } else {
+      for (size_t i = b; i < e; ++i) {
+        const T v = src[i];
+        if constexpr (sizeof(T) > 1) {
+          if ((std::is_signed<T>::value ? (int64_t)v : (int64_t)(uint64_t)v) > 255) { big = true; dst[i] = 0; continue; }
+        }
+        if (std::is_signed<T>::value && v < 0) { negs = true; dst[i] = 0; }
+        else { dst[i] = (uint8_t)v; mx = dst[i] > mx ? dst[i] : mx; }
+      }
     }
-    if (std::is_signed<T>::value && v < 0) { negs = true; g[i] = 0; }
-    else g[i] = (uint8_t)v;
+    w_max[w] = mx; w_neg[w] = negs; w_big[w] = big;
+  });
+  bool negs = false;
+  int mx = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w_big[w]) value_error("allele values must be <= 255");
+    negs = negs || w_neg[w];
+    mx = std::max<int>(mx, w_max[w]);
   }
   if (negs) {
     neg.resize(total);
-    for (size_t i = 0; i < total; ++i) neg[i] = std::is_signed<T>::value && src[i] < 0 ? 1 : 0;
+    uint8_t* flags = neg.data();
+    parallel_ranges(total, [&](size_t b, size_t e, size_t) {
+      for (size_t i = b; i < e; ++i) flags[i] = std::is_signed<T>::value && src[i] < 0 ? 1 : 0;
+    });
   }
   *any_neg = negs;
+  *max_allele = mx;
 }
 
 std::pair<shared_ptr<Store>, shared_ptr<Dense>> convert_numeric_array(const py::handle& genotypes, const py::handle& positions) {
@@ -548,18 +597,13 @@ std::pair<shared_ptr<Store>, shared_ptr<Dense>> convert_numeric_array(const py::
   vector<int64_t> pos = extract_positions(positions, S);
   auto dense = std::make_shared<Dense>();
   bool any_neg = false;
-  if (u8) convert_block<uint8_t>(arr, dense->g, dense->neg, &any_neg);
-  else if (i8) convert_block<int8_t>(arr, dense->g, dense->neg, &any_neg);
-  else if (u16) convert_block<uint16_t>(arr, dense->g, dense->neg, &any_neg);
-  else convert_block<int16_t>(arr, dense->g, dense->neg, &any_neg);
+  int mx = 0;
+  if (u8) convert_block<uint8_t>(arr, dense->g, dense->neg, &any_neg, &mx);
+  else if (i8) convert_block<int8_t>(arr, dense->g, dense->neg, &any_neg, &mx);
+  else if (u16) convert_block<uint16_t>(arr, dense->g, dense->neg, &any_neg, &mx);
+  else convert_block<int16_t>(arr, dense->g, dense->neg, &any_neg, &mx);
   dense->variants = S; dense->samples = N; dense->ploidy = P;
-  {
-    uint8_t mx = 0;  // plain byte max: vectorises
-    const uint8_t* gp = dense->g.data();
-    const size_t total = dense->g.size();
-    for (size_t i = 0; i < total; ++i) mx = gp[i] > mx ? gp[i] : mx;
-    dense->max_allele = mx;
-  }
+  dense->max_allele = mx;
 
   auto st = std::make_shared<Store>();
   st->S = S;
