@@ -15,7 +15,7 @@ echo "[3/8] pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch $O/c4_pmc_fetch_summary.csv
 echo "[4/8] pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write.log
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_write $O/c4_pmc_write_summary.csv
-echo "[5/8] other configs"; python3 $R/tools/measure_configs.py C2 C3 C4m C5 C3h 2>/dev/null | grep '^{' > $O/other_configs.jsonl
+echo "[5/8] other configs"; python3 $R/tools/measure_configs.py C2 C3 C4m C5 C3h WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
 echo "[6/8] multi-allelic path"; python3 $R/tools/measure_general.py 2>/dev/null | grep '^{' | grep hudson > $O/general_path.jsonl
 echo "[7/8] pairwise"; python3 $R/tools/measure_pairwise.py 1000000x2500 200000x500 2>/dev/null | grep '^{' > $O/pairwise.jsonl
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pd_trace -o pd -- python3 $R/tools/measure_pairwise.py 1000000x2500 > /dev/null 2> $O/pd_trace.log
