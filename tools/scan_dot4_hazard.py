@@ -4,7 +4,7 @@
 2 when the last dot4 of a loop and the reduction sat in different basic blocks - the reduction then missed that dot4.
 
 Compiles the device code of ferromic_amd/csrc/abi.hip to assembly (hipcc, no GPU needed) and walks every v_dot4:
-following the fall-through path (s_nop N counts N + 1 wait states, every other instruction 1), a read of the result by
+following fall-through paths and branch targets (s_nop N counts N + 1 wait states, every other instruction 1), a read of the result by
 anything but the accumulator operand of another v_dot4 within fewer than 3 wait states is reported.
 Exit code 1 when anything is reported.  Usage: tools/scan_dot4_hazard.py [existing.s]
 """
@@ -39,7 +39,7 @@ def regs(tok: str) -> set:
 
 
 def scan(path: str):
-    func, ins = None, []
+    func, ins, labels = None, [], {}
     for no, line in enumerate(open(path), 1):
         s = line.strip()
         if not s or s.startswith(";"):
@@ -48,17 +48,21 @@ def scan(path: str):
         if m:
             func = m.group(1)
             continue
-        if s.startswith(".") or s.endswith(":"):
-            continue  # directives and labels: fall through
-        ins.append((no, func, s.split(";")[0].strip()))
-    findings, dots = [], 0
-    for k, (no, fn, text) in enumerate(ins):
-        if not text.startswith("v_dot4"):
+        m = re.match(r"^(\.LBB\w+):", s)
+        if m:
+            labels[m.group(1)] = len(ins)  # the next instruction
             continue
-        dots += 1
-        dest = regs(text.split(None, 1)[1].split(",")[0])
-        waits, j = 0, k + 1
+        if s.startswith(".") or s.endswith(":"):
+            continue  # directives
+        ins.append((no, func, s.split(";")[0].strip()))
+
+    def walk(start, fn, dest, waits, findings, seen):
+        """Follows fall-through AND branch targets from instruction index `start` until NEEDED wait states have passed."""
+        j = start
         while j < len(ins) and waits < NEEDED and ins[j][1] == fn:
+            if (j, waits) in seen:
+                return
+            seen.add((j, waits))
             t = ins[j][2]
             parts = t.split(None, 1)
             op = parts[0]
@@ -67,7 +71,7 @@ def scan(path: str):
                 j += 1
                 continue
             if op == "s_endpgm":
-                break
+                return
             toks = parts[1].split(",") if len(parts) > 1 else []
             has_dest = not (op.startswith(("global_store", "buffer_store", "flat_store", "ds_write", "v_cmp", "s_")))
             srcs = set()
@@ -78,13 +82,25 @@ def scan(path: str):
             if srcs & dest:
                 accumulate = op.startswith("v_dot4") and len(toks) == 4 and regs(toks[3]) & dest and not ((regs(toks[1]) | regs(toks[2])) & dest)
                 if not accumulate:
-                    findings.append((fn, no, waits, t))
-                break
+                    findings.append((fn, ins[j][0], waits, t))
+                return
             if has_dest and toks and regs(toks[0]) & dest:
-                break  # overwritten
+                return  # overwritten
+            if op.startswith(("s_cbranch", "s_branch")) and toks and toks[0].strip() in labels:
+                walk(labels[toks[0].strip()], fn, dest, waits + 1, findings, seen)
+                if op == "s_branch":
+                    return
             waits += 1
             j += 1
-    return dots, findings
+
+    findings, dots = [], 0
+    for k, (no, fn, text) in enumerate(ins):
+        if not text.startswith("v_dot4"):
+            continue
+        dots += 1
+        dest = regs(text.split(None, 1)[1].split(",")[0])
+        walk(k + 1, fn, dest, 0, findings, set())
+    return dots, sorted(set(findings))
 
 
 def main() -> int:
