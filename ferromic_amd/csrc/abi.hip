@@ -17,6 +17,8 @@
 
 #include "../../include/ferromic_hip.h"
 #include "sweep_kernels.hpp"
+#include "pairwise_kernels.hpp"
+#include "wc_counts_kernels.hpp"
 
 using namespace fmh;
 
@@ -1067,9 +1069,12 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   hipStream_t st = (hipStream_t)stream;
   const int n_alleles = (int)m->max_allele + 1;
   const bool missing = m->bits != nullptr;
-  const int n_planes = missing ? n_alleles + 2 : n_alleles;  // + genotype length, + valid flag only when calls can be missing
+  // biallelic and nothing missing: one plane (allele 1) and an all-ones row after the last sample (pairwise_kernels.hpp)
+  static const bool env_two_planes = getenv("FMH_PD_TWO_PLANES") != nullptr;  // measurements / tests: the general route
+  const bool single = !missing && n_alleles == 2 && !env_two_planes;
+  const int n_planes = single ? 1 : (missing ? n_alleles + 2 : n_alleles);  // + genotype length, + valid flag only when calls can be missing
   const size_t tile_edge = kPdBig;
-  const size_t n_pad = round_up(n_samples, kPdBig);
+  const size_t n_pad = round_up(n_samples + (single ? 1 : 0), kPdBig);
   // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
   static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
   size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK);
@@ -1087,6 +1092,16 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   }
   uint8_t* planes = w->pd_planes;
   hipError_t e = hipSuccess;
+  DeviceScratch scratch;
+  scratch.device = m->device;
+  unsigned long long *d_gram = nullptr, *d_totals = nullptr;
+  if (single) {
+    const size_t gram_bytes = n_samples * n_samples * sizeof(unsigned long long), totals_bytes = n_samples * sizeof(unsigned long long);
+    FMH_TRY(scratch.get(&d_gram, n_samples * n_samples));
+    FMH_TRY(scratch.get(&d_totals, n_samples));
+    HIP_TRY(hipMemsetAsync(d_gram, 0, gram_bytes, st));
+    HIP_TRY(hipMemsetAsync(d_totals, 0, totals_bytes, st));
+  }
   const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
   static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
   for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
@@ -1099,7 +1114,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     const size_t planes_smem = (size_t)kPdStageK * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
     if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute((const void*)pd_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
     hipLaunchKernelGGL(pd_planes_kernel, dim3((unsigned)(s_pad / kPdStageK), (unsigned)(n_pad / sb)), dim3(256), planes_smem, st, mv,
-                       rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, n_planes, sb, planes, n_pad, s_pad);
+                       rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
     if ((e = hipGetLastError()) != hipSuccess) break;
     // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
     // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
@@ -1122,11 +1137,15 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     if (k_chunk < k_floor) k_chunk = k_floor;
     if (k_chunk > k_cap) k_chunk = k_cap;
     j = ((s_pad + k_chunk - 1) / k_chunk + 7) / 8;
-    auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst) {
+    auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst, unsigned long long* totals = nullptr) {
       hipLaunchKernelGGL(pd_gram256_kernel, dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
-                         k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst);
+                         k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
       return hipGetLastError();
     };
+    if (single) {
+      if ((e = gram(0, 1, 0, d_gram, d_totals)) != hipSuccess) break;
+      continue;
+    }
     // diff = sum len_i len_j - sum_a cnt_i(a) cnt_j(a)
     if ((e = gram(0, n_alleles, 1, d_diff)) != hipSuccess) break;
     if (missing) {
@@ -1134,7 +1153,12 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
       if ((e = gram(n_alleles + 1, 1, 0, d_both)) != hipSuccess) break;
     }
   }
-  if (e == hipSuccess && !missing) {
+  if (e == hipSuccess && single) {
+    const size_t total = n_samples * n_samples;
+    hipLaunchKernelGGL(pd_single_plane_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_diff, d_both, d_gram, d_totals,
+                       (uint32_t)n_samples, (unsigned long long)m->ploidy, (unsigned long long)m->variants);
+    e = hipGetLastError();
+  } else if (e == hipSuccess && !missing) {
     const size_t total = n_samples * n_samples;
     hipLaunchKernelGGL(pd_constant_terms_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_diff, d_both, (uint32_t)n_samples,
                        (unsigned long long)m->variants * m->ploidy * m->ploidy, (unsigned long long)m->variants);

@@ -1,0 +1,277 @@
+// pairwise_kernels.hpp — gfx950 kernels of fmh_pairwise_differences: sample-major int8 planes + the int8 MFMA Gram product.
+// Include after sweep_kernels.hpp (MatrixView, load_vec).
+#pragma once
+
+namespace fmh {
+
+// ------------------------------------------------------------------------------------------------
+// pairwise differences (calculate_pairwise_differences, stats.rs:4106-4231)
+//   diff(i, j) = sum over sites where both genotypes are Some of  len_i*len_j - sum_a cnt_i(a)*cnt_j(a)
+//   both(i, j) = number of sites where both genotypes are Some
+// Step 1 turns the site-major matrix into sample-major int8 planes (K = sites contiguous); step 2 is a
+// tiled Gram product on the int8 matrix cores (v_mfma_i32_16x16x64_i8) with split-K and exact integer atomics.
+// Biallelic cohorts without missing calls need ONE plane: with a = cnt_i(1), b = cnt_j(1) and cnt(0) = ploidy - cnt(1),
+//   len_i*len_j - cnt_i(0)*cnt_j(0) - cnt_i(1)*cnt_j(1) = ploidy*(a + b) - 2ab,
+// so diff(i, j) = ploidy*(T_i + T_j) - 2*G(i, j) with G the Gram product of plane 1 and T_i = sum over sites of cnt_i(1),
+// which the same product delivers as G(i, ones) against an all-ones row appended after the last sample.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPdTile = 64;
+constexpr int kPdBlock = 128;   // samples per planes-kernel workgroup
+constexpr int kPdStageK = 128;  // K bytes (sites) per Gram stage
+
+// planes[p][site / 128][sample][site % 128]: p = 0..A-1 allele counts, then (only when calls can be missing)
+// p = A genotype length and p = A+1 valid (length > 0).  K-blocked so that one Gram stage (128 samples x 128 K
+// bytes) is one contiguous 16 KiB run.  Plane p holds allele value p + allele_base (single-plane mode: allele 1 only);
+// with ones_row the row after the last sample is 1 at every real site.
+// Workgroup = one K block (128 sites) x SB samples: the raw genotype bytes (and called bits) of the tile are staged
+// in LDS with coalesced row reads, then every thread turns (sample, 16 consecutive sites) into one 16-byte store
+// per plane; a sample's 128 bytes and the SB samples of the tile are contiguous in the output.
+__global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, size_t row_count, uint32_t samples,
+                                                        uint32_t ploidy, int n_alleles, int n_planes, int allele_base, int ones_row,
+                                                        uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
+  extern __shared__ __align__(16) unsigned char pd_smem[];
+  const uint32_t rowb = sb * ploidy;           // genotype bytes per site in the tile (multiple of 4)
+  const uint32_t bitb = (rowb + 7) / 8 + 1;    // called-bit bytes per site in the tile (+1: unaligned start)
+  uint8_t* raw = pd_smem;                      // [128][rowb]
+  uint8_t* cbits = pd_smem + (size_t)kPdStageK * rowb;  // [128][bitb]
+  const size_t kb = blockIdx.x, site0 = kb * kPdStageK;
+  const uint32_t samp0 = blockIdx.y * sb;
+  const size_t col0 = (size_t)samp0 * ploidy;  // first column of the tile (multiple of 4)
+  if ((rowb & 15) == 0 && (col0 & 15) == 0) {
+    // 16-byte row pieces, eight loads in flight per thread before the first LDS store
+    const uint32_t vecs = rowb / 16, total = (uint32_t)kPdStageK * vecs;
+    for (uint32_t base = 0; base < total; base += 256 * 8) {
+      uint4 tmp[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t w = base + q * 256 + threadIdx.x;
+        const uint32_t r = w / vecs, c = (w - r * vecs) * 16;
+        tmp[q] = make_uint4(0, 0, 0, 0);
+        if (w < total && site0 + r < row_count && col0 + c + 16 <= mv.pitch) tmp[q] = load_vec(mv.data + (site0 + r) * mv.pitch + col0 + c);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t w = base + q * 256 + threadIdx.x;
+        const uint32_t r = w / vecs, c = (w - r * vecs) * 16;
+        if (w < total) *reinterpret_cast<uint4*>(raw + (size_t)r * rowb + c) = tmp[q];
+      }
+    }
+  } else {
+    const uint32_t words = rowb / 4;
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * words; w += 256) {
+      const uint32_t r = w / words, c = (w - r * words) * 4;
+      uint32_t v = 0;
+      if (site0 + r < row_count && col0 + c + 4 <= mv.pitch) v = *reinterpret_cast<const uint32_t*>(mv.data + (site0 + r) * mv.pitch + col0 + c);
+      *reinterpret_cast<uint32_t*>(raw + (size_t)r * rowb + c) = v;
+    }
+  }
+  const uint32_t bit0 = (uint32_t)(col0 & 7);
+  if (mv.bits) {
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * bitb; w += 256) {
+      const uint32_t r = w / bitb, c = w - r * bitb;
+      uint8_t v = 0;
+      if (site0 + r < row_count && (col0 >> 3) + c < mv.bits_pitch) v = mv.bits[(site0 + r) * mv.bits_pitch + (col0 >> 3) + c];
+      cbits[(size_t)r * bitb + c] = v;
+    }
+  }
+  __syncthreads();
+  const size_t k_blocks = s_pad / kPdStageK;
+  const bool diploid_complete = ploidy == 2 && !mv.bits;  // the common case: one 16-bit LDS read per genotype, no loops
+  for (int p = 0; p < n_planes; ++p) {
+    for (uint32_t v = threadIdx.x; v < sb * 8; v += 256) {
+      const uint32_t s = v % sb, chunk = v / sb;
+      const uint32_t smp = samp0 + s;
+      uint32_t out[4] = {0, 0, 0, 0};
+      const uint32_t pa = (uint32_t)(p + allele_base);
+      if (ones_row && smp == samples) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (site0 + chunk * 16 + i < row_count) out[i >> 2] |= 1u << (8 * (i & 3));
+      } else if (diploid_complete) {
+        if (smp < samples) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t r = chunk * 16 + i;
+            const uint32_t g = *reinterpret_cast<const uint16_t*>(raw + (size_t)r * rowb + s * 2);
+            uint32_t val = ((g & 0xFFu) == pa ? 1u : 0u) + ((g >> 8) == pa ? 1u : 0u);
+            if (site0 + r >= row_count) val = 0;
+            out[i >> 2] |= val << (8 * (i & 3));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t r = chunk * 16 + i;
+          // genotype length: CompressedGenotypes::get stops at the first missing allele (process.rs:479-496)
+          uint32_t len = 0;
+          if (smp < samples && site0 + r < row_count) {
+            if (mv.bits) {
+              for (uint32_t k = 0; k < ploidy; ++k) {
+                const uint32_t h = bit0 + s * ploidy + k;
+                if (((cbits[(size_t)r * bitb + (h >> 3)] >> (h & 7)) & 1u) == 0) break;
+                ++len;
+              }
+            } else {
+              len = ploidy;
+            }
+          }
+          uint32_t val;
+          if (pa < (uint32_t)n_alleles) {
+            val = 0;
+            const uint8_t* g = raw + (size_t)r * rowb + s * ploidy;
+            for (uint32_t k = 0; k < len; ++k) val += g[k] == (uint8_t)pa ? 1u : 0u;
+          } else {
+            val = pa == (uint32_t)n_alleles ? len : (len > 0 ? 1u : 0u);
+          }
+          out[i >> 2] |= val << (8 * (i & 3));
+        }
+      }
+      // 16-byte chunk positions are XOR-swizzled by (sample >> 1) & 7 for the Gram kernel's unpadded LDS image
+      *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+  }
+}
+
+// Gram product of sample-major int8 planes on the matrix cores:
+//   out(i, j) += sign * sum_{p in [plane_begin, plane_begin + plane_count)} sum_{k in chunk} planes[p][i][k] * planes[p][j][k]
+// v_mfma_i32_16x16x64_i8: each lane feeds 16 consecutive K bytes of one row of A and of one row of B (row = lane & 15,
+// K chunk = lane >> 4).  A and B fragments are cut from LDS images with the SAME (row, k) -> lane rule, so whatever
+// order the instruction walks K inside a step, both operands agree and the sum over K is the plain dot product.
+// C/D: column = lane & 15 (B row), row = 4 * (lane >> 4) + reg (A row).  (The 32x32x32 form measured 4 % slower.)
+// LDS images are byte-for-byte copies of the stage tiles (global_load_lds writes wave-linear), whose 16-byte chunks
+// the planes kernel stored XOR-swizzled by (row >> 1) & 7: 16 consecutive rows of one K chunk then sit in 16
+// different 16-byte slots of the 256-byte bank row, so the fragment reads are conflict-free without padding.
+// Persistent and XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so the group blockIdx.x & 7 shares one L2.
+// Each XCD owns `slices_per_xcd` K slices; its workgroups take (slice, tile pair) items tile-fastest, so at any moment
+// they are walking the same K range over different tile pairs and every stage tile fetched from HBM by one of them
+// is an L2 hit for the others that need it.
+typedef int pd_v4i __attribute__((ext_vector_type(4)));
+typedef int pd_v16i __attribute__((ext_vector_type(16)));
+
+// Workgroup tile 256 x 256 samples (16 waves, each 64 x 64 = 4 x 4 MFMA tiles): half the operand bytes per MAC of a 128 x 128 tile, whose L2 -> LDS traffic per CU
+// (not MFMA issue) bounded the first version of this kernel at 26 % of peak.  16 waves (4 x 4 of 64 x 64), one workgroup per CU;
+// the two 64 KiB stage buffers alternate: the global_load_lds of stage s+1 are in flight while stage s feeds the MFMAs,
+// one raw s_barrier per stage (a __syncthreads() would drain the loads before the MFMAs start).
+constexpr int kPdBig = 256;
+constexpr int kPdBigStageBytes = 2 * kPdBig * kPdStageK;  // A image + B image of one stage
+
+__global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
+                                                          int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
+                                                          int negate, unsigned long long* __restrict__ out,
+                                                          unsigned long long* __restrict__ totals) {
+  extern __shared__ __align__(16) unsigned char pd_lds[];  // [2 buffers][A 32 KiB | B 32 KiB]
+  const uint32_t nt = (uint32_t)(n_pad / kPdBig);
+  const uint32_t tiles = nt * (nt + 1) / 2;
+  const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  uint32_t offa[4], offb[4], swza[4], swzb[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const uint32_t r = wr * 64 + m * 16 + (lane & 15); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { const uint32_t r = wc * 64 + n * 16 + (lane & 15); offb[n] = kPdBig * kPdStageK + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
+  for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
+    uint32_t t = item % tiles, bi = 0;
+    while (t >= nt - bi) { t -= nt - bi; ++bi; }
+    const uint32_t bj = bi + t;
+    const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
+    if (k0 >= s_pad) continue;  // uniform for the workgroup
+    pd_v4i acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = 0;
+    const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
+    const size_t stages_per_plane = (k1 - k0) / kPdStageK;
+    const size_t n_stages = stages_per_plane * (size_t)plane_count;
+    const size_t k_blocks = s_pad / kPdStageK;
+    const size_t kb0 = k0 / kPdStageK;
+    const size_t tile_stride = n_pad * kPdStageK;
+    const uint8_t* pa = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bi * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
+    const uint8_t* pb = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bj * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
+    const size_t plane_skip = (k_blocks - stages_per_plane) * tile_stride;
+    size_t in_plane = 0;
+    // 1024 threads x 16 B = 16 KiB per instruction: two per operand image; wave-uniform LDS bases
+    auto issue = [&](int buf) {
+      if (in_plane == stages_per_plane) { pa += plane_skip; pb += plane_skip; in_plane = 0; }
+      ++in_plane;
+      unsigned char* la = pd_lds + (size_t)buf * kPdBigStageBytes + (size_t)wave * 1024;
+      unsigned char* lb = la + kPdBig * kPdStageK;
+      __builtin_amdgcn_global_load_lds((gptr_t)(pa), (lptr_t)(la), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pa + 16384), (lptr_t)(la + 16384), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb), (lptr_t)(lb), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb + 16384), (lptr_t)(lb + 16384), 16, 0, 0);
+      pa += tile_stride;
+      pb += tile_stride;
+    };
+    if (n_stages) {
+      issue(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    for (size_t stage = 0; stage < n_stages; ++stage) {
+      if (stage + 1 < n_stages) issue((int)((stage + 1) & 1));
+      const unsigned char* img = pd_lds + (stage & 1) * (size_t)kPdBigStageBytes;
+#pragma unroll
+      for (int ks = 0; ks < kPdStageK / 64; ++ks) {
+        const uint32_t cl = (uint32_t)(ks * 4 + (lane >> 4));
+        pd_v4i fa[4], fb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+      }
+      // every wave: my loads of the next stage have landed; everybody: done reading this stage's image
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t i = bi * kPdBig + wr * 64 + m * 16 + 4 * (lane >> 4) + r;
+          const uint32_t j = bj * kPdBig + wc * 64 + n * 16 + (lane & 15);
+          if (i < j && j < n_samples) {
+            const long long v = acc[m][n][r];
+            if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));
+          } else if (totals && j == n_samples && i < n_samples) {  // the all-ones row: per-sample totals of the plane
+            const long long v = acc[m][n][r];
+            if (v != 0) atomicAdd(&totals[i], (unsigned long long)v);
+          }
+        }
+  }
+}
+
+// Without missing data every genotype has `ploidy` alleles: sum over sites of len_i * len_j = rows * ploidy^2 and every
+// site counts for every pair, so those two Gram products collapse into constants.
+__global__ void pd_constant_terms_kernel(unsigned long long* __restrict__ diff, unsigned long long* __restrict__ both,
+                                         uint32_t n_samples, unsigned long long add_diff, unsigned long long add_both) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_samples * n_samples;
+  if (idx >= total) return;
+  const uint32_t i = (uint32_t)(idx / n_samples), j = (uint32_t)(idx % n_samples);
+  if (i < j) { diff[idx] += add_diff; both[idx] += add_both; }
+}
+
+// Single-plane mode: diff(i, j) += ploidy*(T_i + T_j) - 2*G(i, j), both(i, j) += sites.
+__global__ void pd_single_plane_finish_kernel(unsigned long long* __restrict__ diff, unsigned long long* __restrict__ both,
+                                              const unsigned long long* __restrict__ gram, const unsigned long long* __restrict__ totals,
+                                              uint32_t n_samples, unsigned long long ploidy, unsigned long long sites) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_samples * n_samples;
+  if (idx >= total) return;
+  const uint32_t i = (uint32_t)(idx / n_samples), j = (uint32_t)(idx % n_samples);
+  if (i < j) { diff[idx] += ploidy * (totals[i] + totals[j]) - 2ull * gram[idx]; both[idx] += sites; }
+}
+
+}  // namespace fmh

@@ -1101,402 +1101,4 @@ __global__ void max_allele_kernel(const uint8_t* __restrict__ data, size_t pitch
   if ((threadIdx.x & 63) == 0) atomicMax(out, best);
 }
 
-// ------------------------------------------------------------------------------------------------
-// pairwise differences (calculate_pairwise_differences, stats.rs:4106-4231)
-//   diff(i, j) = sum over sites where both genotypes are Some of  len_i*len_j - sum_a cnt_i(a)*cnt_j(a)
-//   both(i, j) = number of sites where both genotypes are Some
-// Step 1 turns the site-major matrix into sample-major int8 planes (K = sites contiguous); step 2 is a
-// tiled Gram product on the int8 matrix cores (v_mfma_i32_32x32x32_i8) with split-K and exact integer atomics.
-// ------------------------------------------------------------------------------------------------
-constexpr int kPdTile = 64;
-constexpr int kPdBlock = 128;   // samples per planes-kernel workgroup
-constexpr int kPdStageK = 128;  // K bytes (sites) per Gram stage
-
-// planes[p][site / 128][sample][site % 128]: p = 0..A-1 allele counts, then (only when calls can be missing)
-// p = A genotype length and p = A+1 valid (length > 0).  K-blocked so that one Gram stage (128 samples x 128 K
-// bytes) is one contiguous 16 KiB run.
-// Workgroup = one K block (128 sites) x SB samples: the raw genotype bytes (and called bits) of the tile are staged
-// in LDS with coalesced row reads, then every thread turns (sample, 16 consecutive sites) into one 16-byte store
-// per plane; a sample's 128 bytes and the SB samples of the tile are contiguous in the output.
-__global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, size_t row_count, uint32_t samples,
-                                                        uint32_t ploidy, int n_alleles, int n_planes, uint32_t sb,
-                                                        uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
-  extern __shared__ __align__(16) unsigned char pd_smem[];
-  const uint32_t rowb = sb * ploidy;           // genotype bytes per site in the tile (multiple of 4)
-  const uint32_t bitb = (rowb + 7) / 8 + 1;    // called-bit bytes per site in the tile (+1: unaligned start)
-  uint8_t* raw = pd_smem;                      // [128][rowb]
-  uint8_t* cbits = pd_smem + (size_t)kPdStageK * rowb;  // [128][bitb]
-  const size_t kb = blockIdx.x, site0 = kb * kPdStageK;
-  const uint32_t samp0 = blockIdx.y * sb;
-  const size_t col0 = (size_t)samp0 * ploidy;  // first column of the tile (multiple of 4)
-  if ((rowb & 15) == 0 && (col0 & 15) == 0) {
-    // 16-byte row pieces, eight loads in flight per thread before the first LDS store
-    const uint32_t vecs = rowb / 16, total = (uint32_t)kPdStageK * vecs;
-    for (uint32_t base = 0; base < total; base += 256 * 8) {
-      uint4 tmp[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const uint32_t w = base + q * 256 + threadIdx.x;
-        const uint32_t r = w / vecs, c = (w - r * vecs) * 16;
-        tmp[q] = make_uint4(0, 0, 0, 0);
-        if (w < total && site0 + r < row_count && col0 + c + 16 <= mv.pitch) tmp[q] = load_vec(mv.data + (site0 + r) * mv.pitch + col0 + c);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const uint32_t w = base + q * 256 + threadIdx.x;
-        const uint32_t r = w / vecs, c = (w - r * vecs) * 16;
-        if (w < total) *reinterpret_cast<uint4*>(raw + (size_t)r * rowb + c) = tmp[q];
-      }
-    }
-  } else {
-    const uint32_t words = rowb / 4;
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * words; w += 256) {
-      const uint32_t r = w / words, c = (w - r * words) * 4;
-      uint32_t v = 0;
-      if (site0 + r < row_count && col0 + c + 4 <= mv.pitch) v = *reinterpret_cast<const uint32_t*>(mv.data + (site0 + r) * mv.pitch + col0 + c);
-      *reinterpret_cast<uint32_t*>(raw + (size_t)r * rowb + c) = v;
-    }
-  }
-  const uint32_t bit0 = (uint32_t)(col0 & 7);
-  if (mv.bits) {
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * bitb; w += 256) {
-      const uint32_t r = w / bitb, c = w - r * bitb;
-      uint8_t v = 0;
-      if (site0 + r < row_count && (col0 >> 3) + c < mv.bits_pitch) v = mv.bits[(site0 + r) * mv.bits_pitch + (col0 >> 3) + c];
-      cbits[(size_t)r * bitb + c] = v;
-    }
-  }
-  __syncthreads();
-  const size_t k_blocks = s_pad / kPdStageK;
-  const bool diploid_complete = ploidy == 2 && !mv.bits;  // the common case: one 16-bit LDS read per genotype, no loops
-  for (int p = 0; p < n_planes; ++p) {
-    for (uint32_t v = threadIdx.x; v < sb * 8; v += 256) {
-      const uint32_t s = v % sb, chunk = v / sb;
-      const uint32_t smp = samp0 + s;
-      uint32_t out[4] = {0, 0, 0, 0};
-      if (diploid_complete) {
-        if (smp < samples) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const uint32_t r = chunk * 16 + i;
-            const uint32_t g = *reinterpret_cast<const uint16_t*>(raw + (size_t)r * rowb + s * 2);
-            uint32_t val = ((g & 0xFFu) == (uint32_t)p ? 1u : 0u) + ((g >> 8) == (uint32_t)p ? 1u : 0u);
-            if (site0 + r >= row_count) val = 0;
-            out[i >> 2] |= val << (8 * (i & 3));
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t r = chunk * 16 + i;
-          // genotype length: CompressedGenotypes::get stops at the first missing allele (process.rs:479-496)
-          uint32_t len = 0;
-          if (smp < samples && site0 + r < row_count) {
-            if (mv.bits) {
-              for (uint32_t k = 0; k < ploidy; ++k) {
-                const uint32_t h = bit0 + s * ploidy + k;
-                if (((cbits[(size_t)r * bitb + (h >> 3)] >> (h & 7)) & 1u) == 0) break;
-                ++len;
-              }
-            } else {
-              len = ploidy;
-            }
-          }
-          uint32_t val;
-          if (p < n_alleles) {
-            val = 0;
-            const uint8_t* g = raw + (size_t)r * rowb + s * ploidy;
-            for (uint32_t k = 0; k < len; ++k) val += g[k] == (uint8_t)p ? 1u : 0u;
-          } else {
-            val = p == n_alleles ? len : (len > 0 ? 1u : 0u);
-          }
-          out[i >> 2] |= val << (8 * (i & 3));
-        }
-      }
-      // 16-byte chunk positions are XOR-swizzled by (sample >> 1) & 7 for the Gram kernel's unpadded LDS image
-      *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
-    }
-  }
-}
-
-// Gram product of sample-major int8 planes on the matrix cores:
-//   out(i, j) += sign * sum_{p in [plane_begin, plane_begin + plane_count)} sum_{k in chunk} planes[p][i][k] * planes[p][j][k]
-// v_mfma_i32_16x16x64_i8: each lane feeds 16 consecutive K bytes of one row of A and of one row of B (row = lane & 15,
-// K chunk = lane >> 4).  A and B fragments are cut from LDS images with the SAME (row, k) -> lane rule, so whatever
-// order the instruction walks K inside a step, both operands agree and the sum over K is the plain dot product.
-// C/D: column = lane & 15 (B row), row = 4 * (lane >> 4) + reg (A row).  (The 32x32x32 form measured 4 % slower.)
-// LDS images are byte-for-byte copies of the stage tiles (global_load_lds writes wave-linear), whose 16-byte chunks
-// the planes kernel stored XOR-swizzled by (row >> 1) & 7: 16 consecutive rows of one K chunk then sit in 16
-// different 16-byte slots of the 256-byte bank row, so the fragment reads are conflict-free without padding.
-// Persistent and XCD-aware: workgroups are dealt to the 8 XCDs round-robin, so the group blockIdx.x & 7 shares one L2.
-// Each XCD owns `slices_per_xcd` K slices; its workgroups take (slice, tile pair) items tile-fastest, so at any moment
-// they are walking the same K range over different tile pairs and every stage tile fetched from HBM by one of them
-// is an L2 hit for the others that need it.
-typedef int pd_v4i __attribute__((ext_vector_type(4)));
-typedef int pd_v16i __attribute__((ext_vector_type(16)));
-
-// Workgroup tile 256 x 256 samples (16 waves, each 64 x 64 = 4 x 4 MFMA tiles): half the operand bytes per MAC of a 128 x 128 tile, whose L2 -> LDS traffic per CU
-// (not MFMA issue) bounded the first version of this kernel at 26 % of peak.  16 waves (4 x 4 of 64 x 64), one workgroup per CU;
-// the two 64 KiB stage buffers alternate: the global_load_lds of stage s+1 are in flight while stage s feeds the MFMAs,
-// one raw s_barrier per stage (a __syncthreads() would drain the loads before the MFMAs start).
-constexpr int kPdBig = 256;
-constexpr int kPdBigStageBytes = 2 * kPdBig * kPdStageK;  // A image + B image of one stage
-
-__global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
-                                                          int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
-                                                          int negate, unsigned long long* __restrict__ out) {
-  extern __shared__ __align__(16) unsigned char pd_lds[];  // [2 buffers][A 32 KiB | B 32 KiB]
-  const uint32_t nt = (uint32_t)(n_pad / kPdBig);
-  const uint32_t tiles = nt * (nt + 1) / 2;
-  const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  uint32_t offa[4], offb[4], swza[4], swzb[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) { const uint32_t r = wr * 64 + m * 16 + (lane & 15); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
-#pragma unroll
-  for (int n = 0; n < 4; ++n) { const uint32_t r = wc * 64 + n * 16 + (lane & 15); offb[n] = kPdBig * kPdStageK + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
-  for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
-    uint32_t t = item % tiles, bi = 0;
-    while (t >= nt - bi) { t -= nt - bi; ++bi; }
-    const uint32_t bj = bi + t;
-    const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
-    if (k0 >= s_pad) continue;  // uniform for the workgroup
-    pd_v4i acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][n][r] = 0;
-    const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
-    const size_t stages_per_plane = (k1 - k0) / kPdStageK;
-    const size_t n_stages = stages_per_plane * (size_t)plane_count;
-    const size_t k_blocks = s_pad / kPdStageK;
-    const size_t kb0 = k0 / kPdStageK;
-    const size_t tile_stride = n_pad * kPdStageK;
-    const uint8_t* pa = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bi * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
-    const uint8_t* pb = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bj * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
-    const size_t plane_skip = (k_blocks - stages_per_plane) * tile_stride;
-    size_t in_plane = 0;
-    // 1024 threads x 16 B = 16 KiB per instruction: two per operand image; wave-uniform LDS bases
-    auto issue = [&](int buf) {
-      if (in_plane == stages_per_plane) { pa += plane_skip; pb += plane_skip; in_plane = 0; }
-      ++in_plane;
-      unsigned char* la = pd_lds + (size_t)buf * kPdBigStageBytes + (size_t)wave * 1024;
-      unsigned char* lb = la + kPdBig * kPdStageK;
-      __builtin_amdgcn_global_load_lds((gptr_t)(pa), (lptr_t)(la), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pa + 16384), (lptr_t)(la + 16384), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb), (lptr_t)(lb), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb + 16384), (lptr_t)(lb + 16384), 16, 0, 0);
-      pa += tile_stride;
-      pb += tile_stride;
-    };
-    if (n_stages) {
-      issue(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    for (size_t stage = 0; stage < n_stages; ++stage) {
-      if (stage + 1 < n_stages) issue((int)((stage + 1) & 1));
-      const unsigned char* img = pd_lds + (stage & 1) * (size_t)kPdBigStageBytes;
-#pragma unroll
-      for (int ks = 0; ks < kPdStageK / 64; ++ks) {
-        const uint32_t cl = (uint32_t)(ks * 4 + (lane >> 4));
-        pd_v4i fa[4], fb[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
-      }
-      // every wave: my loads of the next stage have landed; everybody: done reading this stage's image
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t i = bi * kPdBig + wr * 64 + m * 16 + 4 * (lane >> 4) + r;
-          const uint32_t j = bj * kPdBig + wc * 64 + n * 16 + (lane & 15);
-          if (i < j && j < n_samples) {
-            const long long v = acc[m][n][r];
-            if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));
-          }
-        }
-  }
-}
-
-// Without missing data every genotype has `ploidy` alleles: sum over sites of len_i * len_j = rows * ploidy^2 and every
-// site counts for every pair, so those two Gram products collapse into constants.
-__global__ void pd_constant_terms_kernel(unsigned long long* __restrict__ diff, unsigned long long* __restrict__ both,
-                                         uint32_t n_samples, unsigned long long add_diff, unsigned long long add_both) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)n_samples * n_samples;
-  if (idx >= total) return;
-  const uint32_t i = (uint32_t)(idx / n_samples), j = (uint32_t)(idx % n_samples);
-  if (i < j) { diff[idx] += add_diff; both[idx] += add_both; }
-}
-
-// ------------------------------------------------------------------------------------------------
-// W&C for any number of groups (calculate_fst_wc_at_site_with_membership, stats.rs:1814-2032), from count tables.
-// The fused sweep keeps P <= 8 groups in registers; beyond that the counting is done by summary sweeps over
-// batches of 8 groups (same kernels, same HBM traffic per batch) and this kernel does the per-site arithmetic:
-// one site per thread, groups and pairs in loops, the same wc_shape / wc_apply operand order as the fused path.
-//   called[g][site], alt[g][site] (biallelic: c1 = alt, c0 = called - alt) or acounts[a][g][site] (general),
-//   n_all[site] = called entries over ALL columns (pop_sizes_populated, stats.rs:1987).
-// Outputs [(1 + G(G-1)/2)][rows]: a, b, state; slot 0 = overall, pairs in (0,1),(0,2),... order.
-// ------------------------------------------------------------------------------------------------
-struct WcManyShape {
-  WcShape sh;
-  __device__ void from(const uint32_t* __restrict__ called, size_t rows, size_t site, int gi, int gj, int G) {
-    // r groups with data, visited in group order (overall: all groups; pair: gi, gj)
-    sh.s2_den = 0.0; sh.rm1_over_r = 0.0; sh.nbar_m1 = 0.0; sh.a_den = 1.0; sh.b_fac = 0.0; sh.live = 0; sh.s2_ok = 0;
-    int r_i = 0;
-    unsigned long long total_h = 0;
-    auto visit = [&](auto&& fn) {
-      if (gi >= 0) { fn(called[(size_t)gi * rows + site]); fn(called[(size_t)gj * rows + site]); }
-      else for (int g = 0; g < G; ++g) { const uint32_t v = called[(size_t)g * rows + site]; if (v != 0) fn(v); }
-    };
-    visit([&](uint32_t v) { ++r_i; total_h += v; });
-    const double r = (double)r_i;
-    if (r < 2.0) return;
-    const double n_bar = (double)total_h / r;
-    if ((n_bar - 1.0) < 1e-9) return;
-    double sum_sq_diff_n = 0.0;
-    visit([&](uint32_t v) { double diff = (double)v - n_bar; sum_sq_diff_n += diff * diff; });
-    const double c_squared = (r > 0.0 && n_bar > 0.0) ? sum_sq_diff_n / (r * n_bar * n_bar) : 0.0;
-    sh.s2_ok = ((r - 1.0) > 1e-9 && n_bar > 1e-9) ? 1 : 0;
-    sh.s2_den = (r - 1.0) * n_bar;
-    sh.rm1_over_r = (r - 1.0) / r;
-    sh.nbar_m1 = n_bar - 1.0;
-    sh.a_den = 1.0 - (c_squared / (r - 1.0));
-    sh.b_fac = n_bar / (n_bar - 1.0);
-    sh.live = 1;
-  }
-};
-
-__global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_alleles, size_t rows, const uint32_t* __restrict__ called,
-                                                             const uint32_t* __restrict__ alt, const uint32_t* __restrict__ acounts,
-                                                             const uint32_t* __restrict__ n_all, double* __restrict__ out_a,
-                                                             double* __restrict__ out_b, uint8_t* __restrict__ out_state) {
-  const size_t site = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (site >= rows) return;
-  const size_t nslots = 1 + (size_t)G * (G - 1) / 2;
-  auto count_of = [&](int a, int g) -> uint32_t {
-    if (acounts) return acounts[((size_t)a * G + g) * rows + site];
-    const uint32_t c1 = alt[(size_t)g * rows + site];
-    return a == 1 ? c1 : called[(size_t)g * rows + site] - c1;
-  };
-  if (n_all[site] == 0) {  // no allele among all samples: InsufficientData everywhere (stats.rs:1987-2003)
-    for (size_t k = 0; k < nslots; ++k) { out_a[k * rows + site] = 0.0; out_b[k * rows + site] = 0.0; out_state[k * rows + site] = 3; }
-    return;
-  }
-  WcManyShape ms;
-  // ---- overall (stats.rs:1893-1946) ----
-  {
-    double wa = 0.0, wb = 0.0;
-    int valid = 0;
-    unsigned long long total_called = 0;
-    for (int g = 0; g < G; ++g) { const uint32_t v = called[(size_t)g * rows + site]; if (v != 0) { ++valid; total_called += v; } }
-    if (valid >= 2) {
-      ms.from(called, rows, site, -1, -1, G);
-      if (ms.sh.live) {
-        for (int a = 0; a < n_alleles; ++a) {
-          unsigned long long total_target = 0;
-          for (int g = 0; g < G; ++g) if (called[(size_t)g * rows + site] != 0) total_target += count_of(a, g);
-          const double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
-          double num = 0.0;
-          for (int g = 0; g < G; ++g) {
-            const uint32_t v = called[(size_t)g * rows + site];
-            if (v == 0) continue;
-            const double nd = (double)v;
-            const double diff_p = (double)count_of(a, g) / nd - global_freq;
-            num += nd * diff_p * diff_p;
-          }
-          double ca, cb;
-          wc_apply(ms.sh, num, global_freq, ca, cb);
-          wa += ca;
-          wb += cb;
-        }
-      }
-    }
-    out_a[site] = wa;
-    out_b[site] = wb;
-    out_state[site] = wc_classify(wa, wb);
-  }
-  // ---- pairs (stats.rs:1948-1985) ----
-  size_t k = 1;
-  for (int i = 0; i < G; ++i) {
-    const uint32_t ni = called[(size_t)i * rows + site];
-    for (int j = i + 1; j < G; ++j, ++k) {
-      const uint32_t nj = called[(size_t)j * rows + site];
-      if (ni == 0 || nj == 0) { out_a[k * rows + site] = 0.0; out_b[k * rows + site] = 0.0; out_state[k * rows + site] = 3; continue; }
-      double wa = 0.0, wb = 0.0;
-      ms.from(called, rows, site, i, j, G);
-      if (ms.sh.live) {
-        const unsigned long long pair_total = (unsigned long long)ni + nj;
-        const double ndi = (double)ni, ndj = (double)nj;
-        for (int a = 0; a < n_alleles; ++a) {
-          const uint32_t ci = count_of(a, i), cj = count_of(a, j);
-          const double pair_global = pair_total > 0 ? (double)((unsigned long long)ci + cj) / (double)pair_total : 0.0;
-          double num = 0.0;
-          { const double diff_p = (double)ci / ndi - pair_global; num += ndi * diff_p * diff_p; }
-          { const double diff_p = (double)cj / ndj - pair_global; num += ndj * diff_p * diff_p; }
-          double pa, pb;
-          wc_apply(ms.sh, num, pair_global, pa, pb);
-          wa += pa;
-          wb += pb;
-        }
-      }
-      out_a[k * rows + site] = wa;
-      out_b[k * rows + site] = wb;
-      out_state[k * rows + site] = wc_classify(wa, wb);
-    }
-  }
-}
-
-// Regional sums per slot (calculate_overall_fst_wc, stats.rs:2172-2229).  Grid (slot, chunk): a workgroup sums one chunk
-// of the sites of one slot (thread t takes sites t, t+256, ... of the chunk in ascending order, fixed LDS tree) into
-// partial[slot][chunk]; wc_slot_finalize_kernel adds the chunks in ascending order.  Deterministic for a given launch.
-__global__ __launch_bounds__(256) void wc_slot_reduce_kernel(size_t rows, const double* __restrict__ a, const double* __restrict__ b,
-                                                             const uint8_t* __restrict__ state, double* __restrict__ part_a,
-                                                             double* __restrict__ part_b, unsigned long long* __restrict__ part_inf) {
-  const size_t k = blockIdx.x, chunks = gridDim.y, c = blockIdx.y;
-  const size_t per = (rows + chunks - 1) / chunks;
-  const size_t s0 = c * per, s1 = s0 + per < rows ? s0 + per : rows;
-  double va = 0.0, vb = 0.0;
-  unsigned long long vi = 0;
-  for (size_t s = s0 + threadIdx.x; s < s1; s += 256)
-    if (state[k * rows + s] != 3) { va += a[k * rows + s]; vb += b[k * rows + s]; ++vi; }
-  __shared__ double la[256], lb[256];
-  __shared__ unsigned long long li[256];
-  la[threadIdx.x] = va; lb[threadIdx.x] = vb; li[threadIdx.x] = vi;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) { la[threadIdx.x] += la[threadIdx.x + w]; lb[threadIdx.x] += lb[threadIdx.x + w]; li[threadIdx.x] += li[threadIdx.x + w]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { part_a[k * chunks + c] = la[0]; part_b[k * chunks + c] = lb[0]; part_inf[k * chunks + c] = li[0]; }
-}
-
-__global__ void wc_slot_finalize_kernel(size_t nslots, size_t chunks, const double* __restrict__ part_a, const double* __restrict__ part_b,
-                                        const unsigned long long* __restrict__ part_inf, double* __restrict__ sum_a,
-                                        double* __restrict__ sum_b, unsigned long long* __restrict__ informative) {
-  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nslots) return;
-  double va = 0.0, vb = 0.0;
-  unsigned long long vi = 0;
-  for (size_t c = 0; c < chunks; ++c) { va += part_a[k * chunks + c]; vb += part_b[k * chunks + c]; vi += part_inf[k * chunks + c]; }
-  sum_a[k] = va; sum_b[k] = vb; informative[k] = vi;
-}
-
 }  // namespace fmh

@@ -209,3 +209,33 @@ def test_pairwise_gram_site_slabs():
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, FMH_PD_PLANES_BYTES=str(4 << 20)))
     assert res.returncode == 0 and "slabs ok" in res.stdout, res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("N", [255, 256, 300, 512])
+def test_pairwise_single_plane_and_general_routes_agree(N):
+    """Biallelic cohorts without missing calls take the one-plane Gram (diff = ploidy (T_i + T_j) - 2 G_ij, T from an
+    all-ones row after the last sample - also when N is a multiple of the 256-sample tile and the row opens a new tile);
+    FMH_PD_TWO_PLANES forces the general two-plane route.  Both must equal numpy (own processes: the switch is read once).
+    Ploidy 1 and 3 go through the per-allele loop of the planes kernel instead of the diploid fast path."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ferromic_amd import device as dev\n"
+        "rng = np.random.default_rng(%d)\n"
+        "for ploidy, S in ((2, 3000), (1, 700), (3, 900)):\n"
+        "    g = (rng.random((S, %d, ploidy)) < rng.beta(0.8, 0.8, size=(S, 1, 1))).astype(np.uint8)\n"
+        "    dm = dev.DeviceMatrix.from_host(g.reshape(-1), None, S, %d, ploidy, 1)\n"
+        "    diff, both = dev.pairwise_differences(dm, %d)\n"
+        "    c1 = g.sum(axis=2).astype(np.int64); c0 = ploidy - c1\n"
+        "    exp = S * ploidy * ploidy - c0.T @ c0 - c1.T @ c1\n"
+        "    iu = np.triu_indices(%d, k=1)\n"
+        "    assert np.array_equal(diff[iu].astype(np.int64), exp[iu]), ploidy\n"
+        "    assert (both[iu] == S).all()\n"
+        "print('routes ok')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, N, N, N, N)
+    for env in ({}, {"FMH_PD_TWO_PLANES": "1"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert res.returncode == 0 and "routes ok" in res.stdout, (env, res.stderr[-2000:])

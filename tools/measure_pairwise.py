@@ -24,9 +24,12 @@ def main():
         dt = time.perf_counter() - t0
         n_pad = -(-N // 256) * 256
         tiles = (n_pad // 256) * (n_pad // 256 + 1) // 2
-        macs = tiles * 256 * 256 * S * 2  # two allele-count planes; length/valid terms are constants without missing data
+        planes = 2 if os.environ.get("FMH_PD_TWO_PLANES") else 1  # biallelic, nothing missing: one plane (+ an all-ones row)
+        n_pad = -(-(N + (planes == 1)) // 256) * 256
+        tiles = (n_pad // 256) * (n_pad // 256 + 1) // 2
+        macs = tiles * 256 * 256 * S * planes
         print(json.dumps({"case": f"pairwise {S}x{N}", "seconds": dt, "sample_pair_sites_per_s": N * (N - 1) / 2 * S / dt,
-                          "mfma_TMAC_per_s": macs / dt / 1e12}), flush=True)
+                          "mfma_TMAC_per_s": macs / dt / 1e12, "planes": planes}), flush=True)
         dm.close()
 
 
