@@ -1118,11 +1118,16 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     if ((e = hipGetLastError()) != hipSuccess) break;
     // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
     // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
+    static const int env_waves = getenv("FMH_PD_WAVES") ? atoi(getenv("FMH_PD_WAVES")) : 16;  // 16 = 4 x 4 waves of 64 x 64 (default), 8 = 2 x 4 of 128 x 64: same speed
+    const bool wide_waves = env_waves == 8;
+    const void* gram_fn = wide_waves ? (const void*)pd_gram256_kernel<2, 4> : (const void*)pd_gram256_kernel<4, 4>;
+    const int gram_threads = wide_waves ? 512 : 1024;
     static thread_local int gram_occ[64];
     if (gram_occ[m->device] == 0) {
       int occ = 0;
-      hipError_t oe = hipFuncSetAttribute((const void*)pd_gram256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPdBigStageBytes);
-      if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel, 1024, 2 * kPdBigStageBytes);
+      hipError_t oe = hipFuncSetAttribute(gram_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPdBigStageBytes);
+      if (oe == hipSuccess) oe = wide_waves ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<2, 4>, gram_threads, 2 * kPdBigStageBytes)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4>, gram_threads, 2 * kPdBigStageBytes);
       if (oe != hipSuccess || occ < 1) occ = 1;
       static const int env_occ = getenv("FMH_PD_OCC") ? atoi(getenv("FMH_PD_OCC")) : 0;
       if (env_occ > 0 && occ > env_occ) occ = env_occ;
@@ -1138,8 +1143,12 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     if (k_chunk > k_cap) k_chunk = k_cap;
     j = ((s_pad + k_chunk - 1) / k_chunk + 7) / 8;
     auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst, unsigned long long* totals = nullptr) {
-      hipLaunchKernelGGL(pd_gram256_kernel, dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
-                         k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
+      if (wide_waves)
+        hipLaunchKernelGGL((pd_gram256_kernel<2, 4>), dim3(grid), dim3(512), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
+                           k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
+      else
+        hipLaunchKernelGGL((pd_gram256_kernel<4, 4>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
+                           k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
       return hipGetLastError();
     };
     if (single) {

@@ -155,34 +155,42 @@ typedef int pd_v16i __attribute__((ext_vector_type(16)));
 constexpr int kPdBig = 256;
 constexpr int kPdBigStageBytes = 2 * kPdBig * kPdStageK;  // A image + B image of one stage
 
-__global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
-                                                          int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
-                                                          int negate, unsigned long long* __restrict__ out,
-                                                          unsigned long long* __restrict__ totals) {
+// WM x WN waves per workgroup; a wave owns a (256 / WM) x (256 / WN) block of the tile = MT x NT MFMA tiles.  4 x 4 waves
+// (64 x 64 each) read 256 KiB of LDS per stage per CU, 2 x 4 waves (128 x 64 each) 192 KiB; both run the 1 M x 2 500 case
+// in 6.2 ms, so LDS reads are not what bounds the kernel - the L2 -> LDS fill is (64 KiB per stage per CU).
+template <int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
+                                                                  int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
+                                                                  int negate, unsigned long long* __restrict__ out,
+                                                                  unsigned long long* __restrict__ totals) {
+  constexpr int THREADS = WM * WN * 64;
+  constexpr int MT = kPdBig / WM / 16, NT = kPdBig / WN / 16;
+  constexpr int kImageBytes = kPdBig * kPdStageK;          // one operand image of a stage: 32 KiB
+  constexpr int kLoadsPerImage = kImageBytes / (THREADS * 16);
   extern __shared__ __align__(16) unsigned char pd_lds[];  // [2 buffers][A 32 KiB | B 32 KiB]
   const uint32_t nt = (uint32_t)(n_pad / kPdBig);
   const uint32_t tiles = nt * (nt + 1) / 2;
   const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WN, wc = wave % WN;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  uint32_t offa[4], offb[4], swza[4], swzb[4];
+  uint32_t offa[MT], offb[NT], swza[MT], swzb[NT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) { const uint32_t r = wr * 64 + m * 16 + (lane & 15); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
+  for (int m = 0; m < MT; ++m) { const uint32_t r = wr * (MT * 16) + m * 16 + (lane & 15); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
 #pragma unroll
-  for (int n = 0; n < 4; ++n) { const uint32_t r = wc * 64 + n * 16 + (lane & 15); offb[n] = kPdBig * kPdStageK + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
+  for (int n = 0; n < NT; ++n) { const uint32_t r = wc * (NT * 16) + n * 16 + (lane & 15); offb[n] = kImageBytes + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
   for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
     uint32_t t = item % tiles, bi = 0;
     while (t >= nt - bi) { t -= nt - bi; ++bi; }
     const uint32_t bj = bi + t;
     const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
     if (k0 >= s_pad) continue;  // uniform for the workgroup
-    pd_v4i acc[4][4];
+    pd_v4i acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[m][n][r] = 0;
     const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
@@ -195,16 +203,16 @@ __global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restr
     const uint8_t* pb = planes + (((size_t)plane_begin * k_blocks + kb0) * n_pad + (size_t)bj * kPdBig) * kPdStageK + (size_t)threadIdx.x * 16;
     const size_t plane_skip = (k_blocks - stages_per_plane) * tile_stride;
     size_t in_plane = 0;
-    // 1024 threads x 16 B = 16 KiB per instruction: two per operand image; wave-uniform LDS bases
+    // THREADS x 16 B per instruction, kLoadsPerImage per operand image; wave-uniform LDS bases
     auto issue = [&](int buf) {
       if (in_plane == stages_per_plane) { pa += plane_skip; pb += plane_skip; in_plane = 0; }
       ++in_plane;
       unsigned char* la = pd_lds + (size_t)buf * kPdBigStageBytes + (size_t)wave * 1024;
-      unsigned char* lb = la + kPdBig * kPdStageK;
-      __builtin_amdgcn_global_load_lds((gptr_t)(pa), (lptr_t)(la), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pa + 16384), (lptr_t)(la + 16384), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb), (lptr_t)(lb), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(pb + 16384), (lptr_t)(lb + 16384), 16, 0, 0);
+      unsigned char* lb = la + kImageBytes;
+#pragma unroll
+      for (int q = 0; q < kLoadsPerImage; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(pa + q * THREADS * 16), (lptr_t)(la + q * THREADS * 16), 16, 0, 0);
+#pragma unroll
+      for (int q = 0; q < kLoadsPerImage; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(pb + q * THREADS * 16), (lptr_t)(lb + q * THREADS * 16), 16, 0, 0);
       pa += tile_stride;
       pb += tile_stride;
     };
@@ -219,28 +227,28 @@ __global__ __launch_bounds__(1024) void pd_gram256_kernel(const uint8_t* __restr
 #pragma unroll
       for (int ks = 0; ks < kPdStageK / 64; ++ks) {
         const uint32_t cl = (uint32_t)(ks * 4 + (lane >> 4));
-        pd_v4i fa[4], fb[4];
+        pd_v4i fa[MT], fb[NT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
+        for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
+        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
       }
       // every wave: my loads of the next stage have landed; everybody: done reading this stage's image
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const uint32_t i = bi * kPdBig + wr * 64 + m * 16 + 4 * (lane >> 4) + r;
-          const uint32_t j = bj * kPdBig + wc * 64 + n * 16 + (lane & 15);
+          const uint32_t i = bi * kPdBig + wr * (MT * 16) + m * 16 + 4 * (lane >> 4) + r;
+          const uint32_t j = bj * kPdBig + wc * (NT * 16) + n * 16 + (lane & 15);
           if (i < j && j < n_samples) {
             const long long v = acc[m][n][r];
             if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));
