@@ -1075,14 +1075,19 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   const int n_planes = single ? 1 : (missing ? n_alleles + 2 : n_alleles);  // + genotype length, + valid flag only when calls can be missing
   const size_t tile_edge = kPdBig;
   const size_t n_pad = round_up(n_samples + (single ? 1 : 0), kPdBig);
+  // counts 0..4 are exact in FP4 (e2m1): twice the MFMA rate of int8 at half the plane bytes (pairwise_kernels.hpp)
+  static const bool env_int8 = getenv("FMH_PD_INT8") != nullptr;  // measurements / tests: the int8 route
+  const bool fp4 = m->ploidy <= 4 && !env_int8;
+  const size_t spb = fp4 ? 2 : 1;            // sites per byte of a plane row
+  const size_t ksites = kPdStageK * spb;     // sites per K block = per Gram stage
   // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
   static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
-  size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK);
-  slab = std::min(round_up(m->variants, kPdStageK), slab / kPdStageK * kPdStageK);
+  size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK) / kPdStageK * ksites;
+  slab = std::min(round_up(m->variants, ksites), slab);
   Workspace* w = nullptr;
   FMH_TRY(workspace(m->device, &w));
   std::lock_guard<std::mutex> busy(w->in_use);
-  const size_t planes_bytes = (size_t)n_planes * n_pad * slab;
+  const size_t planes_bytes = (size_t)n_planes * n_pad * slab / spb;
   if (w->pd_planes_bytes < planes_bytes) {
     if (w->pd_planes) (void)hipFree(w->pd_planes);
     w->pd_planes = nullptr;
@@ -1106,48 +1111,54 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
   for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
     const size_t rows = std::min(slab, m->variants - row0);
-    const size_t s_pad = round_up(rows, kPdStageK);
+    const size_t s_pad = round_up(rows, ksites);  // sites
+    const size_t k_bytes = s_pad / spb;           // K bytes per sample in this slab
     MatrixView mv{m->data + row0 * m->pitch, m->bits ? m->bits + row0 * m->bits_pitch : nullptr, m->pitch, m->bits_pitch, m->columns, m->nvec};
-    // samples per planes workgroup: the tile's raw bytes (128 sites x sb x ploidy) stay within 64 KiB of LDS
+    // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 64 KiB of LDS
     uint32_t sb = kPdBlock;
-    while ((size_t)sb * m->ploidy > 512 && sb > 4) sb /= 2;
-    const size_t planes_smem = (size_t)kPdStageK * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
-    if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute((const void*)pd_planes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
-    hipLaunchKernelGGL(pd_planes_kernel, dim3((unsigned)(s_pad / kPdStageK), (unsigned)(n_pad / sb)), dim3(256), planes_smem, st, mv,
-                       rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
+    while ((size_t)sb * m->ploidy * ksites > 64 * 1024 && sb > 4) sb /= 2;
+    const size_t planes_smem = ksites * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
+    const void* planes_fn = fp4 ? (const void*)pd_planes_kernel<true> : (const void*)pd_planes_kernel<false>;
+    if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute(planes_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
+    const dim3 planes_grid((unsigned)(s_pad / ksites), (unsigned)(n_pad / sb));
+    if (fp4)
+      hipLaunchKernelGGL(pd_planes_kernel<true>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
+                         n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
+    else
+      hipLaunchKernelGGL(pd_planes_kernel<false>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
+                         n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
     if ((e = hipGetLastError()) != hipSuccess) break;
     // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
     // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
-    static const int env_waves = getenv("FMH_PD_WAVES") ? atoi(getenv("FMH_PD_WAVES")) : 16;  // 16 = 4 x 4 waves of 64 x 64 (default), 8 = 2 x 4 of 128 x 64: same speed
-    const bool wide_waves = env_waves == 8;
-    const void* gram_fn = wide_waves ? (const void*)pd_gram256_kernel<2, 4> : (const void*)pd_gram256_kernel<4, 4>;
-    const int gram_threads = wide_waves ? 512 : 1024;
-    static thread_local int gram_occ[64];
-    if (gram_occ[m->device] == 0) {
+    static thread_local int gram_occ[64][2];
+    if (gram_occ[m->device][fp4] == 0) {
       int occ = 0;
-      hipError_t oe = hipFuncSetAttribute(gram_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPdBigStageBytes);
-      if (oe == hipSuccess) oe = wide_waves ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<2, 4>, gram_threads, 2 * kPdBigStageBytes)
-                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4>, gram_threads, 2 * kPdBigStageBytes);
+      hipError_t oe = hipFuncSetAttribute(fp4 ? (const void*)pd_gram256_kernel<4, 4, true> : (const void*)pd_gram256_kernel<4, 4, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPdBigStageBytes);
+      if (oe == hipSuccess) oe = fp4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4, true>, 1024, 2 * kPdBigStageBytes)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4, false>, 1024, 2 * kPdBigStageBytes);
       if (oe != hipSuccess || occ < 1) occ = 1;
       static const int env_occ = getenv("FMH_PD_OCC") ? atoi(getenv("FMH_PD_OCC")) : 0;
       if (env_occ > 0 && occ > env_occ) occ = env_occ;
-      gram_occ[m->device] = occ;
+      gram_occ[m->device][fp4] = occ;
     }
-    const unsigned grid = (unsigned)std::max(8, w->cus * gram_occ[m->device] / 8 * 8);  // persistent: every workgroup resident
+    const unsigned grid = (unsigned)std::max(8, w->cus * gram_occ[m->device][fp4] / 8 * 8);  // persistent: every workgroup resident
     const size_t slots = grid / 8;
-    size_t j = env_chunk ? std::max<size_t>(1, (s_pad + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
-    const size_t k_cap = (((size_t)1 << 31) - 1) / (m->ploidy * m->ploidy) / kPdStageK * kPdStageK;
-    size_t k_chunk = round_up((s_pad + 8 * j - 1) / (8 * j), kPdStageK);
-    const size_t k_floor = std::min<size_t>(s_pad, 4096);  // at least 32 stages per item unless the slab is shorter
+    size_t j = env_chunk ? std::max<size_t>(1, (k_bytes + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
+    // an item's accumulators must stay exact: int32 for the int8 route, integers up to 2^24 in f32 for FP4 (counts <= ploidy)
+    const size_t cap_sites = (fp4 ? ((size_t)1 << 24) : (((size_t)1 << 31) - 1)) / (m->ploidy * m->ploidy);
+    const size_t k_cap = std::max<size_t>(cap_sites / spb / kPdStageK, 1) * kPdStageK;
+    size_t k_chunk = round_up((k_bytes + 8 * j - 1) / (8 * j), kPdStageK);
+    const size_t k_floor = std::min<size_t>(k_bytes, 4096);  // at least 32 stages per item unless the slab is shorter
     if (k_chunk < k_floor) k_chunk = k_floor;
     if (k_chunk > k_cap) k_chunk = k_cap;
-    j = ((s_pad + k_chunk - 1) / k_chunk + 7) / 8;
+    j = ((k_bytes + k_chunk - 1) / k_chunk + 7) / 8;
     auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst, unsigned long long* totals = nullptr) {
-      if (wide_waves)
-        hipLaunchKernelGGL((pd_gram256_kernel<2, 4>), dim3(grid), dim3(512), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
+      if (fp4)
+        hipLaunchKernelGGL((pd_gram256_kernel<4, 4, true>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
                            k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
       else
-        hipLaunchKernelGGL((pd_gram256_kernel<4, 4>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, s_pad, plane_begin, plane_count,
+        hipLaunchKernelGGL((pd_gram256_kernel<4, 4, false>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
                            k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
       return hipGetLastError();
     };

@@ -2,6 +2,8 @@
 // Include after sweep_kernels.hpp (MatrixView, load_vec).
 #pragma once
 
+#include <type_traits>
+
 namespace fmh {
 
 // ------------------------------------------------------------------------------------------------
@@ -17,7 +19,14 @@ namespace fmh {
 // ------------------------------------------------------------------------------------------------
 constexpr int kPdTile = 64;
 constexpr int kPdBlock = 128;   // samples per planes-kernel workgroup
-constexpr int kPdStageK = 128;  // K bytes (sites) per Gram stage
+constexpr int kPdStageK = 128;  // K BYTES per sample per Gram stage: 128 sites as int8, 256 sites as FP4 (two per byte)
+
+// FP4 route (ploidy <= 4): the planes hold e2m1 codes of the counts 0..4 (0, 1, 2, 3, 4 are exact in e2m1) and the
+// Gram product runs on v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales - twice the MFMA rate of int8 at half the
+// bytes per site, which is what counts for a kernel bound by its L2 -> LDS fill.  Products are integers <= 16 and the
+// f32 accumulators hold sums <= 2^24 exactly (the host caps the K chunk of an item accordingly), so the result is as
+// exact as the int8 route (checked on the device: tools/microbench/fp4_gram_probe.hip, the pairwise parity tests).
+__device__ __forceinline__ uint32_t pd_fp4_code(uint32_t count) { return (0x65420u >> (4 * count)) & 0xFu; }
 
 // planes[p][site / 128][sample][site % 128]: p = 0..A-1 allele counts, then (only when calls can be missing)
 // p = A genotype length and p = A+1 valid (length > 0).  K-blocked so that one Gram stage (128 samples x 128 K
@@ -26,20 +35,23 @@ constexpr int kPdStageK = 128;  // K bytes (sites) per Gram stage
 // Workgroup = one K block (128 sites) x SB samples: the raw genotype bytes (and called bits) of the tile are staged
 // in LDS with coalesced row reads, then every thread turns (sample, 16 consecutive sites) into one 16-byte store
 // per plane; a sample's 128 bytes and the SB samples of the tile are contiguous in the output.
+template <bool FP4>
 __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, size_t row_count, uint32_t samples,
                                                         uint32_t ploidy, int n_alleles, int n_planes, int allele_base, int ones_row,
                                                         uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
   extern __shared__ __align__(16) unsigned char pd_smem[];
+  constexpr uint32_t KS = FP4 ? 2 * kPdStageK : kPdStageK;  // sites per K block
+  constexpr uint32_t PER = KS / 8;                          // sites per 16-byte chunk of the output row
   const uint32_t rowb = sb * ploidy;           // genotype bytes per site in the tile (multiple of 4)
   const uint32_t bitb = (rowb + 7) / 8 + 1;    // called-bit bytes per site in the tile (+1: unaligned start)
   uint8_t* raw = pd_smem;                      // [128][rowb]
-  uint8_t* cbits = pd_smem + (size_t)kPdStageK * rowb;  // [128][bitb]
-  const size_t kb = blockIdx.x, site0 = kb * kPdStageK;
+  uint8_t* cbits = pd_smem + (size_t)KS * rowb;  // [KS][bitb]
+  const size_t kb = blockIdx.x, site0 = kb * KS;
   const uint32_t samp0 = blockIdx.y * sb;
   const size_t col0 = (size_t)samp0 * ploidy;  // first column of the tile (multiple of 4)
   if ((rowb & 15) == 0 && (col0 & 15) == 0) {
     // 16-byte row pieces, eight loads in flight per thread before the first LDS store
-    const uint32_t vecs = rowb / 16, total = (uint32_t)kPdStageK * vecs;
+    const uint32_t vecs = rowb / 16, total = KS * vecs;
     for (uint32_t base = 0; base < total; base += 256 * 8) {
       uint4 tmp[8];
 #pragma unroll
@@ -58,7 +70,7 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
     }
   } else {
     const uint32_t words = rowb / 4;
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * words; w += 256) {
+    for (uint32_t w = threadIdx.x; w < KS * words; w += 256) {
       const uint32_t r = w / words, c = (w - r * words) * 4;
       uint32_t v = 0;
       if (site0 + r < row_count && col0 + c + 4 <= mv.pitch) v = *reinterpret_cast<const uint32_t*>(mv.data + (site0 + r) * mv.pitch + col0 + c);
@@ -67,7 +79,7 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
   }
   const uint32_t bit0 = (uint32_t)(col0 & 7);
   if (mv.bits) {
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kPdStageK * bitb; w += 256) {
+    for (uint32_t w = threadIdx.x; w < KS * bitb; w += 256) {
       const uint32_t r = w / bitb, c = w - r * bitb;
       uint8_t v = 0;
       if (site0 + r < row_count && (col0 >> 3) + c < mv.bits_pitch) v = mv.bits[(site0 + r) * mv.bits_pitch + (col0 >> 3) + c];
@@ -75,7 +87,11 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
     }
   }
   __syncthreads();
-  const size_t k_blocks = s_pad / kPdStageK;
+  const size_t k_blocks = s_pad / KS;
+  auto put = [](uint32_t (&out)[4], int i, uint32_t val) {
+    if constexpr (FP4) out[i >> 3] |= pd_fp4_code(val) << (4 * (i & 7));
+    else out[i >> 2] |= val << (8 * (i & 3));
+  };
   const bool diploid_complete = ploidy == 2 && !mv.bits;  // the common case: one 16-bit LDS read per genotype, no loops
   for (int p = 0; p < n_planes; ++p) {
     for (uint32_t v = threadIdx.x; v < sb * 8; v += 256) {
@@ -85,23 +101,23 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
       const uint32_t pa = (uint32_t)(p + allele_base);
       if (ones_row && smp == samples) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (site0 + chunk * 16 + i < row_count) out[i >> 2] |= 1u << (8 * (i & 3));
+        for (int i = 0; i < (int)PER; ++i)
+          if (site0 + chunk * PER + i < row_count) put(out, i, 1u);
       } else if (diploid_complete) {
         if (smp < samples) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const uint32_t r = chunk * 16 + i;
+          for (int i = 0; i < (int)PER; ++i) {
+            const uint32_t r = chunk * PER + i;
             const uint32_t g = *reinterpret_cast<const uint16_t*>(raw + (size_t)r * rowb + s * 2);
             uint32_t val = ((g & 0xFFu) == pa ? 1u : 0u) + ((g >> 8) == pa ? 1u : 0u);
             if (site0 + r >= row_count) val = 0;
-            out[i >> 2] |= val << (8 * (i & 3));
+            put(out, i, val);
           }
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t r = chunk * 16 + i;
+        for (int i = 0; i < (int)PER; ++i) {
+          const uint32_t r = chunk * PER + i;
           // genotype length: CompressedGenotypes::get stops at the first missing allele (process.rs:479-496)
           uint32_t len = 0;
           if (smp < samples && site0 + r < row_count) {
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
           } else {
             val = pa == (uint32_t)n_alleles ? len : (len > 0 ? 1u : 0u);
           }
-          out[i >> 2] |= val << (8 * (i & 3));
+          put(out, i, val);
         }
       }
       // 16-byte chunk positions are XOR-swizzled by (sample >> 1) & 7 for the Gram kernel's unpadded LDS image
@@ -147,6 +163,8 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
 // is an L2 hit for the others that need it.
 typedef int pd_v4i __attribute__((ext_vector_type(4)));
 typedef int pd_v16i __attribute__((ext_vector_type(16)));
+typedef int pd_v8i __attribute__((ext_vector_type(8)));
+typedef float pd_v4f __attribute__((ext_vector_type(4)));
 
 // Workgroup tile 256 x 256 samples (16 waves, each 64 x 64 = 4 x 4 MFMA tiles): half the operand bytes per MAC of a 128 x 128 tile, whose L2 -> LDS traffic per CU
 // (not MFMA issue) bounded the first version of this kernel at 26 % of peak.  16 waves (4 x 4 of 64 x 64), one workgroup per CU;
@@ -158,7 +176,8 @@ constexpr int kPdBigStageBytes = 2 * kPdBig * kPdStageK;  // A image + B image o
 // WM x WN waves per workgroup; a wave owns a (256 / WM) x (256 / WN) block of the tile = MT x NT MFMA tiles.  4 x 4 waves
 // (64 x 64 each) read 256 KiB of LDS per stage per CU, 2 x 4 waves (128 x 64 each) 192 KiB; both run the 1 M x 2 500 case
 // in 6.2 ms, so LDS reads are not what bounds the kernel - the L2 -> LDS fill is (64 KiB per stage per CU).
-template <int WM, int WN>
+// s_pad and k_chunk are in K BYTES per sample (= sites for int8, sites / 2 for FP4).
+template <int WM, int WN, bool FP4>
 __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
                                                                   int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
                                                                   int negate, unsigned long long* __restrict__ out,
@@ -186,7 +205,8 @@ __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t*
     const uint32_t bj = bi + t;
     const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
     if (k0 >= s_pad) continue;  // uniform for the workgroup
-    pd_v4i acc[MT][NT];
+    typedef typename std::conditional<FP4, pd_v4f, pd_v4i>::type acc_t;
+    acc_t acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -235,7 +255,16 @@ __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t*
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NT; ++n) {
+            if constexpr (FP4) {
+              // 32 e2m1 values per lane in the first four dwords (cbsz = blgp = 4), E8M0 scales 127 = 2^0
+              const pd_v8i a8 = {fa[m][0], fa[m][1], fa[m][2], fa[m][3], 0, 0, 0, 0};
+              const pd_v8i b8 = {fb[n][0], fb[n][1], fb[n][2], fb[n][3], 0, 0, 0, 0};
+              acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[m][n], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            } else {
+              acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            }
+          }
       }
       // every wave: my loads of the next stage have landed; everybody: done reading this stage's image
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

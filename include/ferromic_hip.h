@@ -250,7 +250,8 @@ int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_mask, int n_g
  *                     (len_i*len_j - sum_a cnt_i(a)*cnt_j(a)),
  *   d_both[i*n + j] = number of sites where both genotypes are Some
  * (comparable sites = L*h_i*h_j - (variants - both)*h_i*h_j is host arithmetic, stats.rs:4182-4208).
- * The call ADDS into both buffers (several matrices of the same samples can be accumulated): zero them first (fmh_device_zero).  Needs ploidy <= 127 (int8 MFMA operands); one allele-count plane per allele value 0..max_allele.
+ * The call ADDS into both buffers (several matrices of the same samples can be accumulated): zero them first (fmh_device_zero).  Needs ploidy <= 127 (int8 MFMA operands; ploidy <= 4 runs on FP4 MFMA, equally exact);
+ * one allele-count plane per allele value 0..max_allele, a single plane when the matrix is biallelic with nothing missing.
  */
 int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
                              unsigned long long* d_both, void* stream);

@@ -236,6 +236,35 @@ def test_pairwise_single_plane_and_general_routes_agree(N):
         "    assert (both[iu] == S).all()\n"
         "print('routes ok')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, N, N, N, N)
-    for env in ({}, {"FMH_PD_TWO_PLANES": "1"}):
+    for env in ({}, {"FMH_PD_TWO_PLANES": "1"}, {"FMH_PD_INT8": "1"}, {"FMH_PD_INT8": "1", "FMH_PD_TWO_PLANES": "1"}):
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert res.returncode == 0 and "routes ok" in res.stdout, (env, res.stderr[-2000:])
+
+
+def test_pairwise_fp4_sums_beyond_f32_integers_are_split():
+    """The FP4 Gram accumulates in f32, exact only up to 2^24: with every genotype 1|1 over 4.5 M sites a pair's
+    product sum is 18 M > 2^24, so the host must cut K into items below the cap even when asked for one huge chunk
+    (FMH_PD_KCHUNK).  Multi-allelic data with missing calls takes the same route through all its planes."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from ferromic_amd import device as dev\n"
+        "S, N = 4_500_000, 6\n"
+        "g = np.ones((S, N, 2), dtype=np.uint8)\n"
+        "g[:, 4, :] = 0\n"
+        "g[::3, 5, 0] = 0\n"
+        "dm = dev.DeviceMatrix.from_host(g.reshape(-1), None, S, N, 2, 1)\n"
+        "diff, both = dev.pairwise_differences(dm, N)\n"
+        "c1 = g.sum(axis=2).astype(np.int64); c0 = 2 - c1\n"
+        "exp = S * 4 - c0.T @ c0 - c1.T @ c1\n"
+        "iu = np.triu_indices(N, k=1)\n"
+        "assert np.array_equal(diff[iu].astype(np.int64), exp[iu]), (diff[iu], exp[iu])\n"
+        "assert (both[iu] == S).all()\n"
+        "print('cap ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"FMH_PD_KCHUNK": "100000000"}, {"FMH_PD_KCHUNK": "100000000", "FMH_PD_TWO_PLANES": "1"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert res.returncode == 0 and "cap ok" in res.stdout, (env, res.stderr[-2000:])

@@ -29,7 +29,8 @@ def main():
         tiles = (n_pad // 256) * (n_pad // 256 + 1) // 2
         macs = tiles * 256 * 256 * S * planes
         print(json.dumps({"case": f"pairwise {S}x{N}", "seconds": dt, "sample_pair_sites_per_s": N * (N - 1) / 2 * S / dt,
-                          "mfma_TMAC_per_s": macs / dt / 1e12, "planes": planes}), flush=True)
+                          "mfma_TMAC_per_s": macs / dt / 1e12, "planes": planes,
+                          "operands": "int8" if os.environ.get("FMH_PD_INT8") else "fp4"}), flush=True)
         dm.close()
 
 
