@@ -1114,9 +1114,12 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     const size_t s_pad = round_up(rows, ksites);  // sites
     const size_t k_bytes = s_pad / spb;           // K bytes per sample in this slab
     MatrixView mv{m->data + row0 * m->pitch, m->bits ? m->bits + row0 * m->bits_pitch : nullptr, m->pitch, m->bits_pitch, m->columns, m->nvec};
-    // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 64 KiB of LDS
-    uint32_t sb = kPdBlock;
-    while ((size_t)sb * m->ploidy * ksites > 64 * 1024 && sb > 4) sb /= 2;
+    // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
+    // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
+    // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
+    static const uint32_t env_sb = getenv("FMH_PD_SB") ? (uint32_t)atoi(getenv("FMH_PD_SB")) : 0;  // measurements
+    uint32_t sb = env_sb ? env_sb : kPdBlock;
+    while ((size_t)sb * m->ploidy * ksites > 32 * 1024 && sb > 4) sb /= 2;
     const size_t planes_smem = ksites * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
     const void* planes_fn = fp4 ? (const void*)pd_planes_kernel<true> : (const void*)pd_planes_kernel<false>;
     if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute(planes_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
