@@ -99,6 +99,8 @@ def main() -> int:
     ap.add_argument("--cpu-sample-sites", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--layout", choices=["packed", "bytes"], default="packed",
+                    help="resident layout of the cohort: bit-packed planes (what fmh_matrix_create keeps for alleles 0..3) or the u8 rows")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
                     help="all ranks share cuda:0 (with --backend gloo): exercises the sharded code path on a one-GPU box")
     args = ap.parse_args()
@@ -147,6 +149,10 @@ def main() -> int:
     t0 = time.perf_counter()
     dm.generate(seed, first_site, thr, poc, 0)
     gen_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if args.layout == "packed":
+        dm.pack(release_bytes=True)  # the resident image fmh_matrix_create keeps: one bit per haplotype, u8 rows freed
+    pack_s = time.perf_counter() - t0
     masks = np.stack([(poc == 0), (poc == 1)]).astype(np.uint8)
     groups = device.Groups(dm, masks)
 
@@ -193,14 +199,18 @@ def main() -> int:
     totals = state["totals"]
     total_sites = S * world
     value = total_sites * args.steps / elapsed
-    b_site = H + W_OUT_HUDSON
+    # algorithmic bytes per site of the kernel that runs: the genotype row as it is resident in HBM (one bit per
+    # haplotype when packed, one byte in the u8 layout) + the 56 B of per-site tracks it writes
+    packed = args.layout == "packed"
+    b_site_u8 = H + W_OUT_HUDSON
+    b_site = ((H + 7) // 8 if packed else H) + W_OUT_HUDSON
     avg_kernel_s = (kernel_ms.value / 1e3) / max(launches.value, 1)
     achieved = b_site * S / avg_kernel_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath)).get(f"{S}x{H}")
+            rec = json.load(open(tpath)).get(f"{S}x{H}:{args.layout}")
             if rec:
                 traffic = rec["hbm_bytes_per_launch"]
         except Exception:
@@ -217,17 +227,20 @@ def main() -> int:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8",
+        "dtype": "u1" if packed else "u8",
         "data": "synthetic",
         "config": {
             "workload": f"C4 fused per-site pi + Hudson FST sweep: {S} sites x {H} haplotypes per GPU, 2 populations, "
-                        "biallelic, no missing data, matrix resident in HBM",
+                        "biallelic, no missing data, matrix resident in HBM "
+                        + ("bit-packed (1 bit per haplotype, the layout fmh_matrix_create keeps)" if packed else "as u8 rows"),
             "sites_per_gpu": S,
             "haplotypes": H,
             "populations": 2,
             "parallelism": f"region-sharded x{world} (one slab per GPU, one {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of 20 accumulators per step)",
             "seed": seed,
             "generate_s": gen_s,
+            "pack_s": pack_s,
+            "layout": args.layout,
         },
         "roofline": {
             "bound": "hbm",
@@ -236,9 +249,13 @@ def main() -> int:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic>",
+            "kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, " + ("packed>" if packed else "u8>"),
             "kernel_ms_avg": avg_kernel_s * 1e3,
             "algorithmic_bytes_per_site": b_site,
+            # the same sites/s priced at SURVEY 8(d)'s u8-layout figure (H + 56 B/site): what a sweep over u8 rows would
+            # have to move per second to keep up - above the HBM peak when the packed layout does its job
+            "u8_layout_bytes_per_site": b_site_u8,
+            "u8_layout_equivalent_GBs": b_site_u8 * S / avg_kernel_s / 1e9,
         },
         "results": {
             "hudson_fst": totals.numerator_sum / totals.denominator_sum if totals.denominator_sum > 1e-12 else None,

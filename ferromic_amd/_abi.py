@@ -118,6 +118,7 @@ SYMBOLS = {
     "fmh_matrix_device_ptrs": (_i, [_vp, _P(_vp), _P(_vp)]),
     "fmh_matrix_download": (_i, [_vp, _vp, _vp]),
     "fmh_matrix_scan_max_allele": (_i, [_vp, _P(_u8), _vp]),
+    "fmh_matrix_pack": (_i, [_vp, _i]),
     "fmh_matrix_generate": (_i, [_vp, _u64, _u64, _vp, _vp, _i, _u32, _vp]),
     "fmh_groups_create": (_i, [_vp, _vp, _i, _P(_vp)]),
     "fmh_groups_destroy": (_i, [_vp]),

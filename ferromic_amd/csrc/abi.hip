@@ -218,6 +218,12 @@ struct fmh_matrix {
   uint32_t columns = 0, nvec = 0;
   uint8_t max_allele = 0;
   bool owns = true;
+  bool has_missing = false;  // a called mask exists (bits and / or pc)
+  // bit-packed image (fmh_matrix_pack): p0 = allele & 1, p1 = allele >> 1 (max_allele 2..3), pc = called bits; plane_pitch
+  // bytes per row, pvec = ceil(columns / 128) 16-byte vectors.  data / bits may have been released (nullptr).
+  uint8_t *p0 = nullptr, *p1 = nullptr, *pc = nullptr;
+  size_t plane_pitch = 0;
+  uint32_t pvec = 0;
 };
 
 static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -265,6 +271,7 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
   m->nvec = (uint32_t)(round_up(m->columns, 16) / 16);
   m->bits_pitch = with_missing ? round_up(m->pitch / 8, 4) : 0;
   m->max_allele = max_allele;
+  m->has_missing = with_missing != 0;
   const size_t bytes = variants * m->pitch;
   hipError_t e = pool_malloc(device, (void**)&m->data, bytes);
   if (e == hipSuccess && with_missing) {
@@ -280,10 +287,128 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
   return FMH_OK;
 }
 
+// ---- bit-packed image -------------------------------------------------------------------------------------------
+// Rows wider than this keep the byte layout: their masks would not fit LDS even as bits for two groups.
+static const uint32_t kPackMaxColumns = 600000;
+static bool layout_bytes_forced() {  // read per call: tests flip it
+  const char* v = getenv("FMH_LAYOUT");
+  return v && strcmp(v, "bytes") == 0;
+}
+static bool packable(uint8_t max_allele, uint32_t columns) { return max_allele <= 3 && columns <= kPackMaxColumns; }
+
+static int alloc_planes(fmh_matrix* m) {
+  m->plane_pitch = round_up(((size_t)m->columns + 7) / 8, 16);
+  m->pvec = (uint32_t)(m->plane_pitch / 16);
+  const size_t bytes = std::max<size_t>(m->variants, 1) * m->plane_pitch;
+  hipError_t e = pool_malloc(m->device, (void**)&m->p0, bytes);
+  if (e == hipSuccess && m->max_allele >= 2) e = pool_malloc(m->device, (void**)&m->p1, bytes);
+  if (e == hipSuccess && m->has_missing) e = pool_malloc(m->device, (void**)&m->pc, bytes);
+  if (e != hipSuccess) {
+    pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->pc);
+    m->p0 = m->p1 = m->pc = nullptr;
+    return fail(FMH_ERR_HIP, "hipMalloc of the %zu-byte packed planes failed: %s", bytes, hipGetErrorString(e));
+  }
+  return FMH_OK;
+}
+static void free_planes(fmh_matrix* m) {
+  pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->pc);
+  m->p0 = m->p1 = m->pc = nullptr;
+}
+// byte rows (and, when `bits` is given, their called rows) -> planes rows [row0, row0 + rows)
+static hipError_t pack_rows(fmh_matrix* m, const uint8_t* data, size_t pitch, const uint8_t* bits, size_t bits_pitch, size_t row0, size_t rows,
+                            hipStream_t st) {
+  if (rows == 0) return hipSuccess;
+  const size_t total = rows * (m->plane_pitch / 4);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
+  const size_t off = row0 * m->plane_pitch;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, data, pitch, bits, bits_pitch, rows, m->columns, m->p0 + off,
+                     m->p1 ? m->p1 + off : nullptr, m->pc ? m->pc + off : nullptr, m->plane_pitch);
+  return hipGetLastError();
+}
+// planes rows [row0, row0 + rows) -> byte rows of `pitch` bytes
+static hipError_t unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* data, size_t pitch, hipStream_t st) {
+  if (rows == 0) return hipSuccess;
+  const size_t total = rows * (pitch / 16);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
+  const size_t off = row0 * m->plane_pitch;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, st, m->p0 + off, m->p1 ? m->p1 + off : nullptr, m->plane_pitch, rows, data, pitch);
+  return hipGetLastError();
+}
+
+extern "C" int fmh_matrix_pack(fmh_matrix* m, int release_bytes) {
+  if (!m) return fail(FMH_ERR_INVALID, "matrix is NULL");
+  if (!m->data) return m->p0 ? FMH_OK : fail(FMH_ERR_INVALID, "matrix has no byte image to pack");
+  if (!packable(m->max_allele, m->columns))
+    return fail(FMH_ERR_UNSUPPORTED, "the packed layout holds alleles 0..3 on rows of at most %u columns (max_allele %u, %u columns)", kPackMaxColumns,
+                (unsigned)m->max_allele, m->columns);
+  FMH_TRY(use_device(m->device));
+  if (m->p0 && ((m->max_allele >= 2) != (m->p1 != nullptr))) free_planes(m);  // max_allele changed since the last pack
+  if (!m->p0) FMH_TRY(alloc_planes(m));
+  hipError_t e = pack_rows(m, m->data, m->pitch, m->bits, m->bits_pitch, 0, m->variants, 0);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(FMH_ERR_HIP, "packing failed: %s", hipGetErrorString(e));
+  if (release_bytes && m->owns) {
+    pool_free(m->device, m->data);
+    pool_free(m->device, m->bits);
+    m->data = nullptr;
+    m->bits = nullptr;
+  }
+  return FMH_OK;
+}
+
 extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing, size_t variants, size_t samples,
                                  size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out) {
   if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
   if (!h_data && variants) return fail(FMH_ERR_INVALID, "h_data is NULL");
+  FMH_TRY(check_dims(variants, samples, ploidy));
+  const bool packed = packable(max_allele, (uint32_t)(samples * ploidy)) && !layout_bytes_forced();
+  if (packed) {
+    // the resident image is the packed one: the bytes pass through a staging slab and are never kept
+    *out = nullptr;
+    FMH_TRY(use_device(device));
+    fmh_matrix* m = new fmh_matrix();
+    m->device = device;
+    m->variants = variants; m->samples = samples; m->ploidy = ploidy;
+    m->columns = (uint32_t)(samples * ploidy);
+    m->pitch = round_up(m->columns, 16);
+    m->nvec = (uint32_t)(m->pitch / 16);
+    m->max_allele = max_allele;
+    m->has_missing = h_missing != nullptr;
+    auto bail = [&](int code) { fmh_matrix_destroy(m); return code; };
+    if (alloc_planes(m) != FMH_OK) return bail(FMH_ERR_HIP);
+    if (variants == 0) { *out = m; return FMH_OK; }
+    hipError_t e = hipSuccess;
+    if (h_missing) {
+      const size_t words = (variants * (size_t)m->columns + 63) / 64;
+      unsigned long long* d_words = nullptr;
+      e = pool_malloc(device, (void**)&d_words, words * 8);
+      if (e == hipSuccess) e = hipMemcpy(d_words, h_missing, words * 8, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemset(m->pc, 0, variants * m->plane_pitch);
+      if (e == hipSuccess) {
+        const size_t total = variants * m->plane_pitch;
+        const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+        hipLaunchKernelGGL(missing_to_called_rows, dim3(blocks), dim3(256), 0, 0, d_words, variants, m->columns, m->pc, m->plane_pitch);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+      }
+      pool_free(device, d_words);
+      if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "missing-mask upload failed: %s", hipGetErrorString(e)));
+    }
+    const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(variants, ((size_t)256 << 20) / m->pitch));
+    uint8_t* d_slab = nullptr;
+    e = pool_malloc(device, (void**)&d_slab, slab_rows * m->pitch);
+    if (e == hipSuccess) e = hipMemset(d_slab, 0, slab_rows * m->pitch);  // padding columns stay zero
+    for (size_t r0 = 0; r0 < variants && e == hipSuccess; r0 += slab_rows) {
+      const size_t rows = std::min(slab_rows, variants - r0);
+      e = hipMemcpy2D(d_slab, m->pitch, h_data + r0 * m->columns, m->columns, m->columns, rows, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = pack_rows(m, d_slab, m->pitch, nullptr, 0, r0, rows, 0);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    pool_free(device, d_slab);
+    if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "matrix upload failed: %s", hipGetErrorString(e)));
+    *out = m;
+    return FMH_OK;
+  }
   FMH_TRY(fmh_matrix_alloc(variants, samples, ploidy, h_missing != nullptr, max_allele, device, out));
   fmh_matrix* m = *out;
   auto bail = [&](int code) { fmh_matrix_destroy(m); *out = nullptr; return code; };
@@ -337,17 +462,19 @@ extern "C" int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_bits, size_t 
   m->nvec = (uint32_t)(round_up(cols, 16) / 16);
   m->max_allele = max_allele;
   m->owns = false;
+  m->has_missing = d_bits != nullptr;
   *out = m;
   return FMH_OK;
 }
 
 extern "C" int fmh_matrix_destroy(fmh_matrix* m) {
   if (!m) return FMH_OK;
+  (void)hipSetDevice(m->device);
   if (m->owns) {
-    (void)hipSetDevice(m->device);
     pool_free(m->device, m->data);
     pool_free(m->device, m->bits);
   }
+  free_planes(m);
   delete m;
   return FMH_OK;
 }
@@ -360,7 +487,7 @@ extern "C" int fmh_matrix_info(const fmh_matrix* m, size_t* variants, size_t* sa
   if (ploidy) *ploidy = m->ploidy;
   if (pitch) *pitch = m->pitch;
   if (bits_pitch) *bits_pitch = m->bits_pitch;
-  if (has_missing) *has_missing = m->bits != nullptr;
+  if (has_missing) *has_missing = m->has_missing;
   if (max_allele) *max_allele = m->max_allele;
   if (device) *device = m->device;
   return FMH_OK;
@@ -378,15 +505,29 @@ extern "C" int fmh_matrix_download(const fmh_matrix* m, uint8_t* h_data, uint64_
   if (!h_data) return fail(FMH_ERR_INVALID, "h_data is NULL");
   FMH_TRY(use_device(m->device));
   if (m->variants == 0) return FMH_OK;
-  HIP_TRY(hipMemcpy2D(h_data, m->columns, m->data, m->pitch, m->columns, m->variants, hipMemcpyDeviceToHost));
-  if (m->bits) {
+  if (m->data) {
+    HIP_TRY(hipMemcpy2D(h_data, m->columns, m->data, m->pitch, m->columns, m->variants, hipMemcpyDeviceToHost));
+  } else {  // packed image only: unpack through a staging slab
+    const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(m->variants, ((size_t)256 << 20) / m->pitch));
+    uint8_t* d_slab = nullptr;
+    HIP_TRY(pool_malloc(m->device, (void**)&d_slab, slab_rows * m->pitch));
+    hipError_t e = hipSuccess;
+    for (size_t r0 = 0; r0 < m->variants && e == hipSuccess; r0 += slab_rows) {
+      const size_t rows = std::min(slab_rows, m->variants - r0);
+      e = unpack_rows(m, r0, rows, d_slab, m->pitch, 0);
+      if (e == hipSuccess) e = hipMemcpy2D(h_data + r0 * m->columns, m->columns, d_slab, m->pitch, m->columns, rows, hipMemcpyDeviceToHost);
+    }
+    pool_free(m->device, d_slab);
+    if (e != hipSuccess) return fail(FMH_ERR_HIP, "matrix download failed: %s", hipGetErrorString(e));
+  }
+  if (m->has_missing) {
     if (!h_missing) return fail(FMH_ERR_INVALID, "matrix has a missing mask but h_missing is NULL");
     const size_t words = (m->variants * (size_t)m->columns + 63) / 64;
     unsigned long long* d_words = nullptr;
     HIP_TRY(hipMalloc((void**)&d_words, words * 8));
     const int blocks = (int)std::min<size_t>((words + 255) / 256, 65535);
-    hipLaunchKernelGGL(called_rows_to_missing, dim3(blocks), dim3(256), 0, 0, m->bits, m->bits_pitch, m->variants,
-                       m->columns, d_words, words);
+    hipLaunchKernelGGL(called_rows_to_missing, dim3(blocks), dim3(256), 0, 0, m->bits ? m->bits : m->pc, m->bits ? m->bits_pitch : m->plane_pitch,
+                       m->variants, m->columns, d_words, words);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(h_missing, d_words, words * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d_words);
@@ -403,11 +544,16 @@ extern "C" int fmh_matrix_scan_max_allele(const fmh_matrix* m, uint8_t* h_max, v
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(d_out, 0, 4, st);
   unsigned int host = 0;
-  if (e == hipSuccess && m->variants) {
+  if (e == hipSuccess && m->variants && m->data) {
     const size_t total = m->variants * (size_t)m->columns;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(max_allele_kernel, dim3(blocks), dim3(256), 0, st, m->data, m->pitch, m->bits, m->bits_pitch,
                        m->variants, m->columns, d_out);
+    e = hipGetLastError();
+  } else if (e == hipSuccess && m->variants) {
+    const size_t total = m->variants * (m->plane_pitch / 4);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(packed_max_allele_kernel, dim3(blocks), dim3(256), 0, st, m->p0, m->p1, m->pc, m->plane_pitch, m->variants, d_out);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&host, d_out, 4, hipMemcpyDeviceToHost, st);
@@ -424,6 +570,7 @@ extern "C" int fmh_matrix_generate(fmh_matrix* m, uint64_t seed, uint64_t first_
   if (n_pops < 1 || n_pops > 255) return fail(FMH_ERR_INVALID, "n_pops out of range");
   for (uint32_t h = 0; h < m->columns; ++h)
     if (h_pop_of_column[h] >= n_pops) return fail(FMH_ERR_INVALID, "pop_of_column[%u] = %u >= n_pops", h, h_pop_of_column[h]);
+  if (!m->data) return fail(FMH_ERR_INVALID, "the generator writes the byte image, which this matrix has released");
   if (missing_thr && !m->bits) return fail(FMH_ERR_INVALID, "missing_threshold set but the matrix has no mask");
   FMH_TRY(use_device(m->device));
   if (m->variants == 0) return FMH_OK;
@@ -447,6 +594,7 @@ extern "C" int fmh_matrix_generate(fmh_matrix* m, uint64_t seed, uint64_t first_
   if (d_pop) (void)hipFree(d_pop);
   if (e != hipSuccess) return fail(FMH_ERR_HIP, "generate failed: %s", hipGetErrorString(e));
   if (m->max_allele < 1) m->max_allele = 1;
+  if (m->p0) FMH_TRY(fmh_matrix_pack(m, 0));  // keep an existing packed image in step
   return FMH_OK;
 }
 
@@ -652,12 +800,25 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   FMH_TRY(workspace(m->device, &w));
   std::lock_guard<std::mutex> busy(w->in_use);
   hipStream_t st = (hipStream_t)stream;
-  a.mv.data = m->data;
-  a.mv.bits = m->bits;
-  a.mv.pitch = m->pitch;
-  a.mv.bits_pitch = m->bits_pitch;
+  // the packed image when there is one (FMH_LAYOUT=bytes keeps the byte kernels on matrices that still hold their bytes)
+  const bool packed = m->p0 && !(m->data && layout_bytes_forced());
+  if (packed) {
+    a.mv.data = m->p0;
+    a.mv.data1 = m->p1;
+    a.mv.bits = m->pc;
+    a.mv.pitch = m->plane_pitch;
+    a.mv.bits_pitch = m->plane_pitch;
+    a.mv.nvec = m->pvec;
+  } else {
+    if (!m->data) return fail(FMH_ERR_INVALID, "matrix holds neither a byte nor a packed image");
+    a.mv.data = m->data;
+    a.mv.data1 = nullptr;
+    a.mv.bits = m->bits;
+    a.mv.pitch = m->pitch;
+    a.mv.bits_pitch = m->bits_pitch;
+    a.mv.nvec = m->nvec;
+  }
   a.mv.columns = m->columns;
-  a.mv.nvec = m->nvec;
   a.masks = g->masks;
   a.mask_pitch = g->mask_pitch;
   a.mask_bits = g->mask_bits;
@@ -687,7 +848,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   }
   memset(res, 0, sizeof *res);
   if (a.row_count == 0) return FMH_OK;
-  const bool missing = m->bits != nullptr;
+  const bool missing = m->has_missing;
   const bool general = m->max_allele > 1;
   const int P = g->padded;
   static const int env_unroll = getenv("FMH_UNROLL") ? atoi(getenv("FMH_UNROLL")) : 0;
@@ -695,12 +856,30 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
   size_t smem = (size_t)P * a.nvec_pad * 16;
   int mask_mode = kMaskLdsBytes;
-  if (smem > kSweepLdsLimit) {  // byte masks do not fit LDS: bits in LDS if those fit, else bytes in global memory (L2)
+  if (packed) {
+    // 128 columns per vector; 1..4 vectors per lane in flight per trip
+    static const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;
+    int best_u = 1;
+    if (m->pvec > 16) {  // fewest padded vector slots per row; ties go to the deeper batch
+      size_t best = SIZE_MAX;
+      for (int u = 2; u <= 4; ++u) {
+        const size_t slots = round_up(m->pvec, 16 * u);
+        if (slots <= best) { best = slots; best_u = u; }
+      }
+    }
+    a.unroll = env_punroll >= 1 && env_punroll <= 4 ? env_punroll : best_u;
+    a.nvec_pad = (uint32_t)round_up(m->pvec, 16 * a.unroll);
+    smem = (size_t)P * a.nvec_pad * 16;
+    mask_mode = kMaskPacked;
+    if (smem > kSweepLdsLimit)
+      return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep fewer groups at a time on rows this wide", P, m->columns);
+  } else if (smem > kSweepLdsLimit) {  // byte masks do not fit LDS: bits in LDS if those fit, else bytes in global memory (L2)
     smem = (size_t)P * a.nvec_pad * 2;
     mask_mode = kMaskLdsBits;
     if (smem > kSweepLdsLimit) { smem = 0; mask_mode = kMaskGlobalBytes; }
   }
-  if (const char* force = getenv("FMH_MASK_MODE")) {  // tests and measurements: take a slower mask route than needed
+  const char* force = packed ? nullptr : getenv("FMH_MASK_MODE");
+  if (force) {  // tests and measurements: take a slower mask route than needed
     const int want = atoi(force);
     const bool global_ok = P <= 2 && mode != kModeWc;
     if (want == kMaskLdsBits && mask_mode == kMaskLdsBytes) { smem = (size_t)P * a.nvec_pad * 2; mask_mode = kMaskLdsBits; }
@@ -711,7 +890,23 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
 #define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
 #define BITS(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskLdsBits>(w, a, smem, st, missing, general, &grid)
 #define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskGlobalBytes>(w, a, smem, st, missing, general, &grid)
-  if (mask_mode == kMaskGlobalBytes) {
+#define PACKED(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskPacked>(w, a, smem, st, missing, general, &grid)
+  if (mask_mode == kMaskPacked) {
+    if (mode == kModeSummary) {
+      if (P == 1) PACKED(1, kModeSummary); else if (P == 2) PACKED(2, kModeSummary); else if (P == 4) PACKED(4, kModeSummary); else PACKED(8, kModeSummary);
+    } else if (mode == (kModeSummary | kModeHudson)) {
+      if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
+      PACKED(2, kModeSummary | kModeHudson);
+    } else if (mode == (kModeSummary | kModeDiversity)) {
+      if (P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
+      PACKED(1, kModeSummary | kModeDiversity);
+    } else if (mode == kModeWc) {
+      if (P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
+      if (P == 2) PACKED(2, kModeWc); else if (P == 4) PACKED(4, kModeWc); else PACKED(8, kModeWc);
+    } else {
+      return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
+    }
+  } else if (mask_mode == kMaskGlobalBytes) {
     // one or two groups per sweep on this route (summaries and W&C re-batch their groups accordingly)
     if (mode == kModeSummary && P == 1) WIDE(1, kModeSummary);
     else if (mode == kModeSummary && P == 2) WIDE(2, kModeSummary);
@@ -748,6 +943,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
     return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
   }
 #undef BITS
+#undef PACKED
 #undef WIDE
 #undef CASE
   FMH_TRY(rc);
@@ -1068,7 +1264,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   if (n_samples < 2 || m->variants == 0) return FMH_OK;
   hipStream_t st = (hipStream_t)stream;
   const int n_alleles = (int)m->max_allele + 1;
-  const bool missing = m->bits != nullptr;
+  const bool missing = m->has_missing;
   // biallelic and nothing missing: one plane (allele 1) and an all-ones row after the last sample (pairwise_kernels.hpp)
   static const bool env_two_planes = getenv("FMH_PD_TWO_PLANES") != nullptr;  // measurements / tests: the general route
   const bool single = !missing && n_alleles == 2 && !env_two_planes;
@@ -1084,6 +1280,9 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
   size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK) / kPdStageK * ksites;
   slab = std::min(round_up(m->variants, ksites), slab);
+  // a matrix that kept only its packed image is unpacked slab by slab into a byte staging buffer of at most 2 GiB
+  const bool staged = m->data == nullptr;
+  if (staged) slab = std::max<size_t>(ksites, std::min(slab, ((size_t)2 << 30) / m->pitch / ksites * ksites));
   Workspace* w = nullptr;
   FMH_TRY(workspace(m->device, &w));
   std::lock_guard<std::mutex> busy(w->in_use);
@@ -1107,13 +1306,28 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     HIP_TRY(hipMemsetAsync(d_gram, 0, gram_bytes, st));
     HIP_TRY(hipMemsetAsync(d_totals, 0, totals_bytes, st));
   }
+  uint8_t* d_stage = nullptr;
   const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
   static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
   for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
     const size_t rows = std::min(slab, m->variants - row0);
     const size_t s_pad = round_up(rows, ksites);  // sites
     const size_t k_bytes = s_pad / spb;           // K bytes per sample in this slab
-    MatrixView mv{m->data + row0 * m->pitch, m->bits ? m->bits + row0 * m->bits_pitch : nullptr, m->pitch, m->bits_pitch, m->columns, m->nvec};
+    MatrixView mv{};
+    mv.pitch = m->pitch;
+    mv.columns = m->columns;
+    mv.nvec = m->nvec;
+    if (staged) {
+      if (!d_stage && (e = hipMalloc((void**)&d_stage, std::min(slab, round_up(m->variants, ksites)) * m->pitch)) != hipSuccess) break;
+      if ((e = unpack_rows(m, row0, rows, d_stage, m->pitch, st)) != hipSuccess) break;
+      mv.data = d_stage;
+      mv.bits = m->pc ? m->pc + row0 * m->plane_pitch : nullptr;
+      mv.bits_pitch = m->plane_pitch;
+    } else {
+      mv.data = m->data + row0 * m->pitch;
+      mv.bits = m->bits ? m->bits + row0 * m->bits_pitch : nullptr;
+      mv.bits_pitch = m->bits_pitch;
+    }
     // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
     // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
     // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
@@ -1188,6 +1402,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (d_stage) { (void)hipStreamSynchronize(st); (void)hipFree(d_stage); }
   if (e != hipSuccess) return fail(FMH_ERR_HIP, "pairwise differences failed: %s", hipGetErrorString(e));
   return FMH_OK;
 }

@@ -36,12 +36,13 @@ enum Mode : int { kModeSummary = 1, kModeHudson = 2, kModeDiversity = 4, kModeWc
 enum Formula : int { kFormulaSparse = 0, kFormulaDense = 1, kFormulaSummary = 2 };
 
 struct MatrixView {
-  const uint8_t* data;
+  const uint8_t* data;   // byte layout: genotype bytes; packed layout: bit plane 0 (allele & 1), one bit per column
+  const uint8_t* data1;  // packed layout with alleles 2..3: bit plane 1 (allele >> 1); else null
   const uint8_t* bits;  // called bits, may be null
   size_t pitch;
   size_t bits_pitch;
   uint32_t columns;  // H = samples * ploidy
-  uint32_t nvec;     // 16-byte vectors per row = ceil(H/16) (<= pitch/16)
+  uint32_t nvec;     // 16-byte vectors per row = ceil(H/16) (<= pitch/16); packed layout: ceil(H/128)
 };
 
 // The allele-independent part of calculate_variance_components (stats.rs:2034-2127) for one W&C slot
@@ -384,6 +385,9 @@ __device__ __forceinline__ uint4 called_bytes(uint32_t bits16) {
 // expanded to 0/1 bytes in registers: 8x the width for ~16 VALU ops per vector and group); beyond that, bytes in
 // global memory (L2), for one or two groups.
 constexpr int kMaskLdsBytes = 0, kMaskGlobalBytes = 1, kMaskLdsBits = 2;
+// kMaskPacked: the MATRIX is bit-packed (one bit per column per plane, 128 columns per 16-byte vector) and so are the
+// masks in LDS (the same bit image as kMaskLdsBits, read as 16-byte vectors); counting is AND + v_bcnt.
+constexpr int kMaskPacked = 3;
 template <int MM>
 __device__ __forceinline__ uint4 mask_vec(const void* base, uint32_t idx) {
   if constexpr (MM == kMaskLdsBits) return called_bytes(reinterpret_cast<const uint16_t*>(base)[idx]);
@@ -445,6 +449,70 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
     if (MISSING) n[p] = row16_sum(n[p]);
   }
   if (MISSING && NEED_ALL) n_all = row16_sum(n_all);
+}
+
+// Bit-packed row (fmh_matrix_pack): plane 0 holds allele & 1, plane 1 (NPL == 2, alleles up to 3) allele >> 1, the called
+// plane one bit per column; masks are bit vectors too.  s0[p] = members with bit 0 set (the alt count when NPL == 1),
+// s1 / s01 as in count_row_planes, n[p] = called members, allele_or = OR of the called allele values.  Same batching as
+// the byte cores: U 16-byte vectors (128 columns each) per lane in flight, clamped addresses, zero-padded masks.
+__device__ __forceinline__ uint32_t popc128(const uint4& v, uint32_t acc) {
+  acc += __builtin_popcount(v.x); acc += __builtin_popcount(v.y); acc += __builtin_popcount(v.z); acc += __builtin_popcount(v.w);
+  return acc;
+}
+__device__ __forceinline__ uint4 and128(const uint4& a, const uint4& b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
+
+template <int P, bool MISSING, bool NEED_ALL, int NPL, int U>
+__device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uint4* __restrict__ lds_mask, uint32_t nvec_pad,
+                                                 const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1,
+                                                 const uint8_t* __restrict__ called_ptr, int gl, uint32_t (&n)[P], uint32_t& n_all,
+                                                 uint32_t& allele_or, uint32_t (&s0)[P], uint32_t (&s1)[P], uint32_t (&s01)[P]) {
+#pragma unroll
+  for (int p = 0; p < P; ++p) { n[p] = 0; s0[p] = 0; s1[p] = 0; s01[p] = 0; }
+  n_all = 0;
+  allele_or = 0;
+  const uint32_t last = mv.nvec - 1;
+  for (uint32_t v0 = gl; v0 < nvec_pad; v0 += 16 * U) {
+    uint4 x0[U], x1[U], cb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = v0 + 16 * u;
+      const uint32_t vc = v < last ? v : last;
+      x0[u] = load_stream(row0 + (size_t)vc * 16);
+      if (NPL == 2) x1[u] = load_stream(row1 + (size_t)vc * 16);
+      if (MISSING) cb[u] = load_stream(called_ptr + (size_t)vc * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = v0 + 16 * u;
+      const bool inside = v <= last;
+      uint4 a0 = x0[u], a1 = NPL == 2 ? x1[u] : make_uint4(0, 0, 0, 0);
+      if (MISSING) {
+        a0 = and128(a0, cb[u]);
+        if (NPL == 2) a1 = and128(a1, cb[u]);
+        if (NEED_ALL) n_all = inside ? popc128(cb[u], n_all) : n_all;
+      }
+      if (NPL == 2) {
+        const uint32_t any0 = a0.x | a0.y | a0.z | a0.w, any1 = a1.x | a1.y | a1.z | a1.w;
+        allele_or |= inside ? ((any0 ? 1u : 0u) | (any1 ? 2u : 0u)) : 0u;
+      }
+      const uint4 a01 = NPL == 2 ? and128(a0, a1) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
+        if (MISSING) { m = and128(m, cb[u]); n[p] = popc128(m, n[p]); }
+        s0[p] = popc128(and128(a0, m), s0[p]);
+        if (NPL == 2) { s1[p] = popc128(and128(a1, m), s1[p]); s01[p] = popc128(and128(a01, m), s01[p]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (MISSING) n[p] = row16_sum(n[p]);
+    s0[p] = row16_sum(s0[p]);
+    if (NPL == 2) { s1[p] = row16_sum(s1[p]); s01[p] = row16_sum(s01[p]); }
+  }
+  if (MISSING && NEED_ALL) n_all = row16_sum(n_all);
+  if (NPL == 2) allele_or = row16_or(allele_or);
 }
 
 // General row, single pass for alleles 0..3 by bit planes: with s0 = #(bit0 set), s1 = #(bit1 set),
@@ -771,6 +839,16 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   if constexpr (MM == kMaskGlobalBytes) {
     lds_mask = A.masks;
     nvec_pad = (uint32_t)(A.mask_pitch / 16);  // the stride between the masks of two groups, in vectors
+  } else if constexpr (MM == kMaskPacked) {
+    // the groups' bit masks as 16-byte vectors (128 columns each), zero beyond the row
+    uint4* staged = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec_pad; i += kBlock) {
+      const uint32_t p = i / nvec_pad, v = i - p * nvec_pad;
+      staged[i] = v < nvec ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(A.mask_bits) + (size_t)p * (A.mask_pitch / 8) + (size_t)v * 16)
+                           : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    lds_mask = staged;
   } else if constexpr (MM == kMaskLdsBits) {
     // one 16-bit word per vector and group, zero beyond the row (the host lays them out with the same padded stride)
     uint16_t* staged = reinterpret_cast<uint16_t*>(smem);
@@ -827,7 +905,14 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       if constexpr (!GENERAL) {
         uint32_t alt[P], n[P], n_all;
         // rows past the end are clamped to the last row (their results are discarded by row_ok)
-        if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+        if constexpr (MM == kMaskPacked) {
+          uint32_t aor, s1[P], s01[P];
+          const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
+          if (A.unroll == 4) count_row_packed<P, MISSING, NEED_ALL, 1, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          else if (A.unroll == 2) count_row_packed<P, MISSING, NEED_ALL, 1, 2>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          else count_row_packed<P, MISSING, NEED_ALL, 1, 1>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+        } else if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
         else count_row_biallelic<P, MISSING, NEED_ALL, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
         if (own) {
 #pragma unroll
@@ -839,7 +924,16 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         }
       } else {
         uint32_t n[P], n_all, aor, s0[P], s1[P], s01[P];
-        count_row_planes<P, MISSING, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+        if constexpr (MM == kMaskPacked) {
+          const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
+          const uint8_t* row_ptr1 = mv.data1 + row * mv.pitch;
+          if (A.unroll == 4) count_row_packed<P, MISSING, true, 2, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          else if (A.unroll == 2) count_row_packed<P, MISSING, true, 2, 2>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          else count_row_packed<P, MISSING, true, 2, 1>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+        } else {
+          count_row_planes<P, MISSING, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+        }
         if (!MISSING) {
 #pragma unroll
           for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
@@ -899,7 +993,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
               consume(a, c);
             }
           }
-        } else {
+        } else if constexpr (MM != kMaskPacked) {  // a packed matrix holds alleles 0..3 only
           for (uint32_t a = 0; a <= bound; ++a) {
             uint32_t c[P];
             count_row_allele<P, MISSING, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
@@ -1083,6 +1177,88 @@ __global__ void generate_kernel(uint8_t* __restrict__ data, size_t pitch, uint8_
     *reinterpret_cast<uint4*>(data + s * pitch + (size_t)v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     if (bits && (size_t)v * 2 + 1 < bits_pitch) *reinterpret_cast<uint16_t*>(bits + s * bits_pitch + (size_t)v * 2) = (uint16_t)called;
   }
+}
+
+// ---- bit-packed image (fmh_matrix_pack) ---------------------------------------------------------------------------
+// bytes -> planes: one thread per (row, 32 columns).  Bit c of a plane word = column 32 w + c; bits past the last column
+// are zero whatever the padding bytes hold.  p1 / pc may be null (biallelic / nothing missing).
+__device__ __forceinline__ uint32_t pack_nibble(uint32_t w, int shift) {  // bit `shift` of each of 4 bytes -> 4 bits, LSB = byte 0
+  return ((((w >> shift) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+__global__ void pack_rows_kernel(const uint8_t* __restrict__ data, size_t pitch, const uint8_t* __restrict__ bits, size_t bits_pitch,
+                                 size_t rows, uint32_t columns, uint8_t* __restrict__ p0, uint8_t* __restrict__ p1,
+                                 uint8_t* __restrict__ pc, size_t plane_pitch) {
+  const size_t words = plane_pitch / 4, total = rows * words;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = idx / words;
+    const uint32_t w = (uint32_t)(idx - row * words), col0 = w * 32;
+    uint32_t b0 = 0, b1 = 0, bc = 0;
+    if (col0 < columns) {
+      const uint32_t valid = columns - col0 >= 32 ? 0xFFFFFFFFu : ((1u << (columns - col0)) - 1u);
+      const uint8_t* src = data + row * pitch + col0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (col0 + 16 * q < columns) {  // pitch is a multiple of 16 and >= columns: the 16-byte piece is inside the row
+          const uint4 g = *reinterpret_cast<const uint4*>(src + 16 * q);
+          const uint32_t d[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            b0 |= pack_nibble(d[k], 0) << (16 * q + 4 * k);
+            b1 |= pack_nibble(d[k], 1) << (16 * q + 4 * k);
+          }
+        }
+      }
+      b0 &= valid;
+      b1 &= valid;
+      if (bits) {
+        const uint8_t* cb = bits + row * bits_pitch + (size_t)w * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((size_t)w * 4 + k < bits_pitch) bc |= (uint32_t)cb[k] << (8 * k);
+        bc &= valid;
+      }
+    }
+    *reinterpret_cast<uint32_t*>(p0 + row * plane_pitch + (size_t)w * 4) = b0;
+    if (p1) *reinterpret_cast<uint32_t*>(p1 + row * plane_pitch + (size_t)w * 4) = b1;
+    if (pc && bits) *reinterpret_cast<uint32_t*>(pc + row * plane_pitch + (size_t)w * 4) = bc;
+  }
+}
+
+// planes -> bytes: one thread per (row, 16 columns); padding columns come out zero
+__global__ void unpack_rows_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, size_t plane_pitch, size_t rows,
+                                   uint8_t* __restrict__ data, size_t pitch) {
+  const size_t vecs = pitch / 16, total = rows * vecs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = idx / vecs;
+    const uint32_t v = (uint32_t)(idx - row * vecs);
+    uint32_t lo = 0, hi = 0;
+    if ((size_t)v * 2 + 2 <= plane_pitch) {
+      lo = *reinterpret_cast<const uint16_t*>(p0 + row * plane_pitch + (size_t)v * 2);
+      if (p1) hi = *reinterpret_cast<const uint16_t*>(p1 + row * plane_pitch + (size_t)v * 2);
+    }
+    uint4 a = called_bytes(lo);
+    if (p1) {
+      const uint4 b = called_bytes(hi);
+      a.x |= b.x << 1; a.y |= b.y << 1; a.z |= b.z << 1; a.w |= b.w << 1;
+    }
+    *reinterpret_cast<uint4*>(data + row * pitch + (size_t)v * 16) = a;
+  }
+}
+
+// largest called allele of a packed image: 3 if some column has both plane bits, else 2 / 1 / 0
+__global__ void packed_max_allele_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ pc,
+                                         size_t plane_pitch, size_t rows, unsigned int* __restrict__ out) {
+  const size_t words = plane_pitch / 4, total = rows * words;
+  unsigned int best = 0;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    uint32_t a = reinterpret_cast<const uint32_t*>(p0)[idx];
+    uint32_t b = p1 ? reinterpret_cast<const uint32_t*>(p1)[idx] : 0u;
+    if (pc) { const uint32_t c = reinterpret_cast<const uint32_t*>(pc)[idx]; a &= c; b &= c; }
+    const unsigned int v = (a & b) ? 3u : (b ? 2u : (a ? 1u : 0u));
+    best = v > best ? v : best;
+  }
+  for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, best);
 }
 
 // max over called entries

@@ -102,6 +102,10 @@ class DeviceMatrix:
                                                    thr.shape[0], missing_threshold24, None))
         self.max_allele = max(self.max_allele, 1)
 
+    def pack(self, release_bytes: bool = False) -> None:
+        """fmh_matrix_pack: build the bit-packed image the sweeps prefer (alleles 0..3); optionally drop the u8 rows."""
+        _abi.check(_abi.load().fmh_matrix_pack(self._h, 1 if release_bytes else 0))
+
     def download(self):
         data = np.empty(self.variants * self.columns, dtype=np.uint8)
         words = None

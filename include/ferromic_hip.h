@@ -81,8 +81,12 @@ int fmh_device_release_scratch(int device);
 /*
  * Upload a site-major matrix in the reference's host layout: data[site*stride + sample*ploidy + side],
  * stride = samples*ploidy (stats.rs:293); optional missing bitset, one bit per linear entry,
- * LSB-first in u64 words (stats.rs:1298-1302; lib.rs:1188-1189).  On the device rows are padded to
- * a 16-byte pitch and the missing bitset is re-laid as one "called" bit-row per site.
+ * LSB-first in u64 words (stats.rs:1298-1302; lib.rs:1188-1189).
+ * Resident layout: with max_allele <= 3 (every biallelic and every SNP cohort) the matrix is kept BIT-PACKED - one bit
+ * plane per allele bit plus one "called" plane, 128 columns per 16-byte vector - and the sweeps read 1/8 (1/4 with
+ * alleles 2..3) of the bytes the u8 layout would cost; the bytes only pass through a staging slab.  Other matrices
+ * (max_allele > 3, rows beyond 600 000 columns, FMH_LAYOUT=bytes) keep the u8 rows, padded to a 16-byte pitch, with the
+ * missing bitset re-laid as one "called" bit-row per site.  Values above max_allele are a caller error.
  */
 int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing_or_null, size_t variants,
                       size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out);
@@ -95,10 +99,16 @@ int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, int with_mi
 int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_called_bits_or_null, size_t bits_pitch,
                     size_t variants, size_t samples, size_t ploidy, uint8_t max_allele, int device,
                     fmh_matrix** out);
+/* Build the bit-packed image of a matrix that holds u8 rows (fmh_matrix_alloc + fmh_matrix_generate, fmh_matrix_wrap);
+ * the sweeps use it from then on.  release_bytes != 0 frees the u8 rows of a matrix the library owns (a wrapped matrix
+ * keeps the caller's memory).  FMH_ERR_UNSUPPORTED when max_allele > 3 or the rows are too wide; a no-op when the
+ * matrix is already packed and holds no bytes. */
+int fmh_matrix_pack(fmh_matrix* m, int release_bytes);
 int fmh_matrix_destroy(fmh_matrix* m);
 /* geometry: any pointer may be NULL */
 int fmh_matrix_info(const fmh_matrix* m, size_t* variants, size_t* samples, size_t* ploidy, size_t* pitch,
                     size_t* bits_pitch, int* has_missing, uint8_t* max_allele, int* device);
+/* the u8 rows and called bit-rows; NULL for a matrix that holds only its packed image */
 int fmh_matrix_device_ptrs(const fmh_matrix* m, void** d_data, void** d_called_bits);
 /* Copy back in the reference host layout (tests / oracle). h_missing_or_null must hold
  * ceil(variants*stride/64) words when the matrix has a mask. */

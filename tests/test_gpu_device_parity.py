@@ -401,3 +401,59 @@ def test_eight_groups_on_rows_beyond_the_bit_mask_budget(dev):
         exp = R.build_dense_population_summary(m, lists[g])
         assert np.array_equal(got.alt[g], np.array(exp.alt_counts, dtype=np.uint32))
         assert np.array_equal(got.called[g], np.array(exp.called_counts, dtype=np.uint32))
+
+
+def test_packed_and_byte_layouts_agree(dev, monkeypatch):
+    """A generated cohort is swept from its u8 rows (FMH_LAYOUT=bytes), from the bit-packed image next to them, and from
+    the packed image alone (bytes released); every output must be the same bits.  Then the packed-only matrix is
+    downloaded (unpack), scanned for its max allele and sent through the pairwise Gram (unpack staging)."""
+    rng = np.random.default_rng(31)
+    for (S, N, max_allele, p_missing) in ((300, 700, 1, 0.0), (257, 333, 1, 0.04), (130, 1100, 3, 0.0), (90, 260, 2, 0.1), (70, 40, 3, 0.02)):
+        m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
+        monkeypatch.setenv("FMH_LAYOUT", "bytes")
+        dm = upload(dev, m)                       # u8 rows only
+        monkeypatch.delenv("FMH_LAYOUT")
+        cut = N // 3
+        lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, N - 3))]
+        thirds = [H.haps_for_samples(range(i, N, 3)) for i in range(3)]
+        g2, g1, g3 = (dev.Groups.from_haplotype_lists(dm, x) for x in (lists, lists[:1], thirds))
+
+        def run():
+            return (dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE), dev.diversity_sites(dm, g1), dev.wc_sweep(dm, g3),
+                    dev.population_summaries(dm, g3, dev.FORMULA_SUMMARY), dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE))
+
+        base = run()
+        host_before = dm.download()
+        pd_before = dev.pairwise_differences(dm, N)
+
+        def same(got):
+            for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+                H.assert_bits_equal(got[0].sites[k], base[0].sites[k], k)
+                H.assert_bits_equal(got[4].sites[k], base[4].sites[k], k + " sparse")
+            assert np.array_equal(got[0].sites["alt"], base[0].sites["alt"]) and np.array_equal(got[0].sites["called"], base[0].sites["called"])
+            assert got[0].totals == base[0].totals and got[0].pop == base[0].pop
+            H.assert_bits_equal(got[1].pi, base[1].pi, "site pi")
+            H.assert_bits_equal(got[1].theta, base[1].theta, "site theta")
+            assert np.array_equal(got[1].distinct, base[1].distinct)
+            assert np.array_equal(got[2].a, base[2].a, equal_nan=True) and np.array_equal(got[2].b, base[2].b, equal_nan=True)
+            assert np.array_equal(got[2].state, base[2].state) and np.array_equal(got[2].group_called, base[2].group_called)
+            assert np.array_equal(got[3].alt, base[3].alt) and np.array_equal(got[3].called, base[3].called)
+            assert got[3].totals == base[3].totals
+
+        dm.pack()                                  # packed image next to the bytes: the sweeps switch to it
+        same(run())
+        monkeypatch.setenv("FMH_LAYOUT", "bytes")  # ... unless told otherwise
+        same(run())
+        monkeypatch.delenv("FMH_LAYOUT")
+        dm.pack(release_bytes=True)                # packed image alone
+        same(run())
+        host_after = dm.download()
+        assert np.array_equal(host_after[0], host_before[0])
+        if host_before[1] is not None:
+            assert np.array_equal(host_after[1], host_before[1])
+        exp_max = int(np.asarray(host_before[0]).max()) if p_missing == 0.0 else None
+        if exp_max is not None:
+            assert dm.scan_max_allele() == exp_max
+        pd_after = dev.pairwise_differences(dm, N)
+        iu = np.triu_indices(N, k=1)
+        assert np.array_equal(pd_after[0][iu], pd_before[0][iu]) and np.array_equal(pd_after[1][iu], pd_before[1][iu])

@@ -26,6 +26,8 @@ CONFIGS = {
     "C5": (2_000_000, 10_000, 2, "hudson", 0.0),
     "C3h": (5_000_000, 2_500, 4, "summaries", 0.0),
     "C2x10": (10_000_000, 1_000, 2, "hudson", 0.0),  # C2 rows, 10x the sites: separates fixed launch cost from per-row efficiency
+    "NARROW": (10_000_000, 640, 2, "hudson", 0.0),  # 40 vectors per row: the per-row instruction stream a bit-packed C4 row would have
+    "NARROWm": (10_000_000, 640, 2, "hudson", 0.01),
     "WIDE": (100_000, 200_000, 2, "hudson", 0.0),  # byte masks beyond the LDS budget: bit masks in LDS (FMH_MASK_MODE=1: global)
 }
 
@@ -43,6 +45,9 @@ def main():
         thr = np.stack([base[p % 2] for p in range(P)])
         dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=miss > 0, max_allele=1)
         dm.generate(seed, 0, thr, poc, int(miss * (1 << 24)))
+        layout = os.environ.get("MEASURE_LAYOUT", "packed")
+        if layout == "packed":
+            dm.pack(release_bytes=True)
         masks = np.stack([(poc == p) for p in range(P)]).astype(np.uint8)
         g = device.Groups(dm, masks)
         bufs = []
@@ -108,12 +113,14 @@ def main():
         ms, n = C.c_double(), C.c_uint64()
         lib.fmh_timing_read(C.byref(ms), C.byref(n))
         lib.fmh_timing_enable(0)
-        b_site = H + (((H + 7) // 8) if miss > 0 else 0) + w_out
+        row_b = (H + 7) // 8 if layout == "packed" else H   # resident genotype bytes per site
+        b_site = row_b + (((H + 7) // 8) if miss > 0 else 0) + w_out
+        b_site_u8 = H + (((H + 7) // 8) if miss > 0 else 0) + w_out
         k_s = ms.value / 1e3 / n.value
-        print(json.dumps({"config": name, "sites": S, "haplotypes": H, "populations": P, "kind": kind, "missing": miss,
+        print(json.dumps({"config": name, "layout": layout, "sites": S, "haplotypes": H, "populations": P, "kind": kind, "missing": miss,
                           "sites_per_s": S * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": k_s * 1e3,
                           "bytes_per_site": b_site, "achieved_GBs": b_site * S / k_s / 1e9,
-                          "frac_of_8TBs": b_site * S / k_s / 8e12}), flush=True)
+                          "frac_of_8TBs": b_site * S / k_s / 8e12, "u8_layout_equivalent_GBs": b_site_u8 * S / k_s / 1e9}), flush=True)
         del bufs, g, dm
 
 
