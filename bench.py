@@ -101,6 +101,8 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--layout", choices=["packed", "bytes"], default="packed",
                     help="resident layout of the cohort: bit-packed planes (what fmh_matrix_create keeps for alleles 0..3) or the u8 rows")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the all-reduce path even with one rank (measures the software cost of the collective step on a one-GPU box)")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
                     help="all ranks share cuda:0 (with --backend gloo): exercises the sharded code path on a one-GPU box")
     args = ap.parse_args()
@@ -124,10 +126,14 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -165,13 +171,23 @@ def main() -> int:
     from ferromic_amd import sharding
 
     state = {"totals": _abi.HudsonTotals()}
+    # N > 1: the 20 regional accumulators of a step are summed over the ranks by one RCCL all-reduce that overlaps the
+    # next step's sweep (its own stream); fence() collects the last one, so every step's reduce ends inside the timed region
+    pipeline = sharding.HudsonTotalsPipeline(dist, "cuda") if dist is not None else None
 
     def step():
         local = _abi.HudsonTotals()
         _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
-        state["totals"] = sharding.allreduce_hudson_totals(local, dist, "cuda") if dist is not None else local
+        if pipeline is not None:
+            pipeline.submit(local)
+        else:
+            state["totals"] = local
 
     def fence():
+        if pipeline is not None:
+            merged = pipeline.flush()
+            if merged is not None:
+                state["totals"] = merged
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -236,7 +252,7 @@ def main() -> int:
             "sites_per_gpu": S,
             "haplotypes": H,
             "populations": 2,
-            "parallelism": f"region-sharded x{world} (one slab per GPU, one {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of 20 accumulators per step)",
+            "parallelism": f"region-sharded x{world} (one slab per GPU, one {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of 20 accumulators per step, overlapped with the next step's sweep)",
             "seed": seed,
             "generate_s": gen_s,
             "pack_s": pack_s,

@@ -41,7 +41,23 @@ def main():
         return t
 
     begin, end = sharding.slab_for_rank(S, rank, world)
-    merged = sharding.allreduce_hudson_totals(totals_of(begin, end), dist, "cpu")
+    mine = totals_of(begin, end)
+    merged = sharding.allreduce_hudson_totals(mine, dist, "cpu")
+    # the pipelined form bench.py uses: step k's reduce is collected when step k + 1 submits, the last one by flush()
+    pipe = sharding.HudsonTotalsPipeline(dist, "cpu")
+    half = totals_of(begin, begin + (end - begin) // 2)
+    pipe.submit(half)
+    assert pipe.latest is None
+    pipe.submit(mine)
+    first = pipe.latest
+    piped = pipe.flush()
+    assert pipe.flush() is piped
+    assert first.sites_with_components < piped.sites_with_components or S < 4
+    for k, _ in _abi.HudsonTotals._fields_:
+        if k != "pop":
+            assert getattr(piped, k) == getattr(merged, k), k
+    for p in range(2):
+        assert piped.pop[p].segregating_sites == merged.pop[p].segregating_sites and piped.pop[p].pi_sum == merged.pop[p].pi_sum
     if rank == 0:
         whole = totals_of(0, S)
         for k, _ in _abi.HudsonTotals._fields_:
