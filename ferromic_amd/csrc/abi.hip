@@ -1280,9 +1280,8 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
   size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK) / kPdStageK * ksites;
   slab = std::min(round_up(m->variants, ksites), slab);
-  // a matrix that kept only its packed image is unpacked slab by slab into a byte staging buffer of at most 2 GiB
-  const bool staged = m->data == nullptr;
-  if (staged) slab = std::max<size_t>(ksites, std::min(slab, ((size_t)2 << 30) / m->pitch / ksites * ksites));
+  // a matrix with a packed image feeds the planes kernel its bit rows (1/8 of the bytes); FMH_LAYOUT=bytes keeps the u8 route
+  const bool from_packed = m->p0 && !(m->data && layout_bytes_forced());
   Workspace* w = nullptr;
   FMH_TRY(workspace(m->device, &w));
   std::lock_guard<std::mutex> busy(w->in_use);
@@ -1306,44 +1305,55 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     HIP_TRY(hipMemsetAsync(d_gram, 0, gram_bytes, st));
     HIP_TRY(hipMemsetAsync(d_totals, 0, totals_bytes, st));
   }
-  uint8_t* d_stage = nullptr;
   const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
   static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
   for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
     const size_t rows = std::min(slab, m->variants - row0);
     const size_t s_pad = round_up(rows, ksites);  // sites
     const size_t k_bytes = s_pad / spb;           // K bytes per sample in this slab
-    MatrixView mv{};
-    mv.pitch = m->pitch;
-    mv.columns = m->columns;
-    mv.nvec = m->nvec;
-    if (staged) {
-      if (!d_stage && (e = hipMalloc((void**)&d_stage, std::min(slab, round_up(m->variants, ksites)) * m->pitch)) != hipSuccess) break;
-      if ((e = unpack_rows(m, row0, rows, d_stage, m->pitch, st)) != hipSuccess) break;
-      mv.data = d_stage;
-      mv.bits = m->pc ? m->pc + row0 * m->plane_pitch : nullptr;
-      mv.bits_pitch = m->plane_pitch;
+    if (from_packed) {
+      // bit rows are tiny in LDS: 256 samples per workgroup (64-byte row pieces for diploid samples)
+      const uint32_t sbp = 256;
+      const size_t bitb = ((size_t)sbp * m->ploidy + 7) / 8 + 1;
+      const size_t smem_p = 3 * ksites * bitb;
+      const dim3 grid_p((unsigned)(s_pad / ksites), (unsigned)(n_pad / sbp));
+      const uint8_t* q0 = m->p0 + row0 * m->plane_pitch;
+      const uint8_t* q1 = m->p1 ? m->p1 + row0 * m->plane_pitch : nullptr;
+      const uint8_t* qc = m->pc ? m->pc + row0 * m->plane_pitch : nullptr;
+      const void* fn = fp4 ? (const void*)pd_planes_packed_kernel<true> : (const void*)pd_planes_packed_kernel<false>;
+      if (smem_p > 64 * 1024 && (e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p)) != hipSuccess) break;
+      if (fp4)
+        hipLaunchKernelGGL(pd_planes_packed_kernel<true>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
+                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
+      else
+        hipLaunchKernelGGL(pd_planes_packed_kernel<false>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
+                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
     } else {
+      if (!m->data) { e = hipErrorInvalidValue; break; }
+      MatrixView mv{};
+      mv.pitch = m->pitch;
+      mv.columns = m->columns;
+      mv.nvec = m->nvec;
       mv.data = m->data + row0 * m->pitch;
       mv.bits = m->bits ? m->bits + row0 * m->bits_pitch : nullptr;
       mv.bits_pitch = m->bits_pitch;
+      // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
+      // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
+      // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
+      static const uint32_t env_sb = getenv("FMH_PD_SB") ? (uint32_t)atoi(getenv("FMH_PD_SB")) : 0;  // measurements
+      uint32_t sb = env_sb ? env_sb : kPdBlock;
+      while ((size_t)sb * m->ploidy * ksites > 32 * 1024 && sb > 4) sb /= 2;
+      const size_t planes_smem = ksites * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
+      const void* planes_fn = fp4 ? (const void*)pd_planes_kernel<true> : (const void*)pd_planes_kernel<false>;
+      if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute(planes_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
+      const dim3 planes_grid((unsigned)(s_pad / ksites), (unsigned)(n_pad / sb));
+      if (fp4)
+        hipLaunchKernelGGL(pd_planes_kernel<true>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
+                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
+      else
+        hipLaunchKernelGGL(pd_planes_kernel<false>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
+                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
     }
-    // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
-    // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
-    // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
-    static const uint32_t env_sb = getenv("FMH_PD_SB") ? (uint32_t)atoi(getenv("FMH_PD_SB")) : 0;  // measurements
-    uint32_t sb = env_sb ? env_sb : kPdBlock;
-    while ((size_t)sb * m->ploidy * ksites > 32 * 1024 && sb > 4) sb /= 2;
-    const size_t planes_smem = ksites * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
-    const void* planes_fn = fp4 ? (const void*)pd_planes_kernel<true> : (const void*)pd_planes_kernel<false>;
-    if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute(planes_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
-    const dim3 planes_grid((unsigned)(s_pad / ksites), (unsigned)(n_pad / sb));
-    if (fp4)
-      hipLaunchKernelGGL(pd_planes_kernel<true>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
-                         n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
-    else
-      hipLaunchKernelGGL(pd_planes_kernel<false>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
-                         n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
     if ((e = hipGetLastError()) != hipSuccess) break;
     // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
     // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
@@ -1402,7 +1412,6 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (d_stage) { (void)hipStreamSynchronize(st); (void)hipFree(d_stage); }
   if (e != hipSuccess) return fail(FMH_ERR_HIP, "pairwise differences failed: %s", hipGetErrorString(e));
   return FMH_OK;
 }

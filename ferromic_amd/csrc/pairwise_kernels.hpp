@@ -148,6 +148,163 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
   }
 }
 
+// The same planes from a BIT-PACKED matrix (fmh_matrix_pack): p0 = allele & 1, p1 = allele >> 1 (null when biallelic),
+// pc = called bits (null when nothing is missing), rows of plane_pitch bytes.  A workgroup stages the bit rows of its
+// K block x SB samples in LDS (a few KiB) and emits the same 16-byte chunks as pd_planes_kernel; the matrix read is
+// 1/8 of the u8 route's.
+template <bool FP4>
+__global__ __launch_bounds__(256) void pd_planes_packed_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
+                                                               const uint8_t* __restrict__ pc, size_t plane_pitch, size_t row_count,
+                                                               uint32_t samples, uint32_t ploidy, int n_alleles, int n_planes, int allele_base,
+                                                               int ones_row, uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
+  extern __shared__ __align__(16) unsigned char pd_smem[];
+  constexpr uint32_t KS = FP4 ? 2 * kPdStageK : kPdStageK;  // sites per K block
+  constexpr uint32_t PER = KS / 8;                          // sites per 16-byte chunk of the output row
+  const uint32_t bitb = (sb * ploidy + 7) / 8 + 1;          // bytes per site per plane in the tile (+1: unaligned start)
+  uint8_t* l0 = pd_smem;                                    // [KS][bitb] each
+  uint8_t* l1 = l0 + (size_t)KS * bitb;
+  uint8_t* lc = l1 + (size_t)KS * bitb;
+  const size_t kb = blockIdx.x, site0 = kb * KS;
+  const uint32_t samp0 = blockIdx.y * sb;
+  const size_t col0 = (size_t)samp0 * ploidy;
+  const uint32_t bit0 = (uint32_t)(col0 & 7);
+  const uint32_t body = bitb - 1;  // the tile's own bytes; the extra one only matters for an unaligned start
+  if ((body & 3) == 0 && ((col0 >> 3) & 3) == 0 && bit0 == 0) {
+    // dword pieces (diploid samples in blocks of 256: 64-byte row pieces); the spare byte of each LDS row is never read
+    const uint32_t words = body / 4;
+    for (uint32_t w = threadIdx.x; w < KS * words; w += 256) {
+      const uint32_t r = w / words, c = (w - r * words) * 4;
+      const bool ok = site0 + r < row_count && (col0 >> 3) + c + 4 <= plane_pitch;
+      const size_t off = (site0 + r) * plane_pitch + (col0 >> 3) + c;
+      const uint32_t v0 = ok ? *reinterpret_cast<const uint32_t*>(p0 + off) : 0u;
+      const uint32_t v1 = ok && p1 ? *reinterpret_cast<const uint32_t*>(p1 + off) : 0u;
+      const uint32_t vc = ok ? (pc ? *reinterpret_cast<const uint32_t*>(pc + off) : 0xFFFFFFFFu) : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        l0[(size_t)r * bitb + c + k] = (uint8_t)(v0 >> (8 * k));
+        l1[(size_t)r * bitb + c + k] = (uint8_t)(v1 >> (8 * k));
+        lc[(size_t)r * bitb + c + k] = (uint8_t)(vc >> (8 * k));
+      }
+    }
+  } else {
+    for (uint32_t w = threadIdx.x; w < KS * bitb; w += 256) {
+      const uint32_t r = w / bitb, c = w - r * bitb;
+      const bool ok = site0 + r < row_count && (col0 >> 3) + c < plane_pitch;
+      const size_t off = (site0 + r) * plane_pitch + (col0 >> 3) + c;
+      l0[w] = ok ? p0[off] : (uint8_t)0;
+      l1[w] = ok && p1 ? p1[off] : (uint8_t)0;
+      lc[w] = ok ? (pc ? pc[off] : (uint8_t)0xFF) : (uint8_t)0;
+    }
+  }
+  __syncthreads();
+  const bool diploid_complete = ploidy == 2 && !pc;  // the common case: two bits per genotype from one LDS byte, no loops
+  const size_t k_blocks = s_pad / KS;
+  auto put = [](uint32_t (&out)[4], int i, uint32_t val) {
+    if constexpr (FP4) out[i >> 3] |= pd_fp4_code(val) << (4 * (i & 7));
+    else out[i >> 2] |= val << (8 * (i & 3));
+  };
+  auto bit_at = [&](const uint8_t* plane, uint32_t r, uint32_t h) { return (uint32_t)(plane[(size_t)r * bitb + (h >> 3)] >> (h & 7)) & 1u; };
+  for (int p = 0; p < n_planes; ++p) {
+    const uint32_t pa = (uint32_t)(p + allele_base);
+    if (diploid_complete && bit0 == 0 && (sb & 3) == 0) {
+      // one LDS byte = the genotypes of four neighbouring diploid samples at one site: a thread turns a column of PER such
+      // bytes into the four samples' 16-byte chunks (a quarter of the LDS reads of the one-sample-per-thread form)
+      for (uint32_t v = threadIdx.x; v < (sb / 4) * 8; v += 256) {
+        const uint32_t q = v % (sb / 4), chunk = v / (sb / 4);
+        uint32_t out4[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {  // one output dword per sample at a time; the barrier keeps the live set small
+#pragma unroll
+          for (int j = 0; j < (int)PER / 4; ++j) {
+            const int i = d * ((int)PER / 4) + j;
+            const uint32_t r = chunk * PER + i;
+            const uint32_t y0 = l0[(size_t)r * bitb + q];
+            const uint32_t y1 = p1 ? (uint32_t)l1[(size_t)r * bitb + q] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t x0 = (y0 >> (2 * k)) & 3u, x1 = (y1 >> (2 * k)) & 3u;
+              const uint32_t lo = (x0 & 1u) | ((x1 & 1u) << 1), hi = (x0 >> 1) | ((x1 >> 1) << 1);
+              put(out4[k], i, (lo == pa ? 1u : 0u) + (hi == pa ? 1u : 0u));  // rows past the end were staged as zeros: count 0 unless pa == 0
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t smp = samp0 + q * 4 + k;
+          uint32_t o[4] = {out4[k][0], out4[k][1], out4[k][2], out4[k][3]};
+          if (smp >= samples || pa == 0) {
+            // padding samples are zero rows; allele 0 must not count the zero-staged sites past the end of the matrix
+            o[0] = o[1] = o[2] = o[3] = 0;
+            if (smp < samples) {
+#pragma unroll
+              for (int i = 0; i < (int)PER; ++i) {
+                const uint32_t r = chunk * PER + i;
+                if (site0 + r < row_count) {
+                  const uint32_t x0 = ((uint32_t)l0[(size_t)r * bitb + q] >> (2 * k)) & 3u;
+                  const uint32_t x1 = p1 ? ((uint32_t)l1[(size_t)r * bitb + q] >> (2 * k)) & 3u : 0u;
+                  const uint32_t lo = (x0 & 1u) | ((x1 & 1u) << 1), hi = (x0 >> 1) | ((x1 >> 1) << 1);
+                  put(o, i, (lo == 0 ? 1u : 0u) + (hi == 0 ? 1u : 0u));
+                }
+              }
+            }
+            if (ones_row && smp == samples) {
+#pragma unroll
+              for (int i = 0; i < (int)PER; ++i)
+                if (site0 + chunk * PER + i < row_count) put(o, i, 1u);
+            }
+          }
+          *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      continue;
+    }
+    for (uint32_t v = threadIdx.x; v < sb * 8; v += 256) {
+      const uint32_t s = v % sb, chunk = v / sb;
+      const uint32_t smp = samp0 + s;
+      uint32_t out[4] = {0, 0, 0, 0};
+      if (ones_row && smp == samples) {
+#pragma unroll
+        for (int i = 0; i < (int)PER; ++i)
+          if (site0 + chunk * PER + i < row_count) put(out, i, 1u);
+      } else if (diploid_complete) {
+        if (smp < samples) {
+          const uint32_t h = bit0 + s * 2, bi = h >> 3, sh = h & 7;  // h is even: both bits sit in one byte
+#pragma unroll
+          for (int i = 0; i < (int)PER; ++i) {
+            const uint32_t r = chunk * PER + i;
+            const uint32_t x0 = ((uint32_t)l0[(size_t)r * bitb + bi] >> sh) & 3u;
+            const uint32_t x1 = ((uint32_t)l1[(size_t)r * bitb + bi] >> sh) & 3u;
+            const uint32_t lo = (x0 & 1u) | ((x1 & 1u) << 1), hi = (x0 >> 1) | ((x1 >> 1) << 1);
+            uint32_t val = (lo == pa ? 1u : 0u) + (hi == pa ? 1u : 0u);
+            if (site0 + r >= row_count) val = 0;
+            put(out, i, val);
+          }
+        }
+      } else if (smp < samples) {
+#pragma unroll 8
+        for (int i = 0; i < (int)PER; ++i) {
+          const uint32_t r = chunk * PER + i;
+          uint32_t val = 0;
+          if (site0 + r < row_count) {
+            // genotype length: CompressedGenotypes::get stops at the first missing allele (process.rs:479-496)
+            uint32_t len = 0, cnt = 0;
+            for (uint32_t k = 0; k < ploidy; ++k) {
+              const uint32_t h = bit0 + s * ploidy + k;
+              if (!bit_at(lc, r, h)) break;
+              ++len;
+              cnt += (bit_at(l0, r, h) | (bit_at(l1, r, h) << 1)) == pa ? 1u : 0u;
+            }
+            val = pa < (uint32_t)n_alleles ? cnt : (pa == (uint32_t)n_alleles ? len : (len > 0 ? 1u : 0u));
+          }
+          put(out, i, val);
+        }
+      }
+      *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+  }
+}
+
 // Gram product of sample-major int8 planes on the matrix cores:
 //   out(i, j) += sign * sum_{p in [plane_begin, plane_begin + plane_count)} sum_{k in chunk} planes[p][i][k] * planes[p][j][k]
 // v_mfma_i32_16x16x64_i8: each lane feeds 16 consecutive K bytes of one row of A and of one row of B (row = lane & 15,
