@@ -746,9 +746,9 @@ extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes>
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16>
 static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStream_t st, int* grid_out) {
-  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL, MM>;
+  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL, MM, LPR>;
   static thread_local int cached_occ[64];
   static thread_local size_t cached_smem[64];
   int dev = 0;
@@ -778,10 +778,10 @@ static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStrea
   return FMH_OK;
 }
 
-template <int P, int MODE, int MM = kMaskLdsBytes>
+template <int P, int MODE, int MM = kMaskLdsBytes, int LPR = 16>
 static int launch_pm(Workspace* w, const SweepArgs& a, size_t smem, hipStream_t st, bool missing, bool general, int* grid) {
-  if (missing) return general ? launch_one<P, MODE, true, true, MM>(w, a, smem, st, grid) : launch_one<P, MODE, true, false, MM>(w, a, smem, st, grid);
-  return general ? launch_one<P, MODE, false, true, MM>(w, a, smem, st, grid) : launch_one<P, MODE, false, false, MM>(w, a, smem, st, grid);
+  if (missing) return general ? launch_one<P, MODE, true, true, MM, LPR>(w, a, smem, st, grid) : launch_one<P, MODE, true, false, MM, LPR>(w, a, smem, st, grid);
+  return general ? launch_one<P, MODE, false, true, MM, LPR>(w, a, smem, st, grid) : launch_one<P, MODE, false, false, MM, LPR>(w, a, smem, st, grid);
 }
 
 struct SweepResult {
@@ -856,19 +856,27 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
   size_t smem = (size_t)P * a.nvec_pad * 16;
   int mask_mode = kMaskLdsBytes;
+  int lpr = 16;
   if (packed) {
-    // 128 columns per vector; 1..4 vectors per lane in flight per trip
-    static const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;
-    int best_u = 1;
-    if (m->pvec > 16) {  // fewest padded vector slots per row; ties go to the deeper batch
-      size_t best = SIZE_MAX;
-      for (int u = 2; u <= 4; ++u) {
-        const size_t slots = round_up(m->pvec, 16 * u);
-        if (slots <= best) { best = slots; best_u = u; }
-      }
+    // 128 columns per vector.  Rows of up to 32 vectors (4 096 columns) are shared by FOUR lanes (no idle vector slots
+    // on short rows, a two-step reduction: C2 0.081 -> 0.042 ms, C3 0.94 -> 0.63 ms), wider ones by the sixteen lanes of a
+    // DPP row (C4's 40 vectors: 1.32 vs 1.34 ms, 200 000 columns: 0.46 vs 0.66 ms); the batch depth U (vectors per lane in
+    // flight per trip) is the one with the fewest padded slots, ties to the deeper batch.
+    const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;  // read per call: tests flip them
+    const int env_lpr = getenv("FMH_PACKED_LPR") ? atoi(getenv("FMH_PACKED_LPR")) : 0;
+    lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
+    const int us4[4] = {1, 2, 3, 5}, us16[3] = {2, 3, 4};
+    const int* us = lpr == 4 ? us4 : us16;
+    const int nus = lpr == 4 ? 4 : 3;
+    int best_u = us[0];
+    size_t best = SIZE_MAX;
+    for (int k = 0; k < nus; ++k) {
+      const size_t slots = round_up(m->pvec, (size_t)lpr * us[k]);
+      if (slots <= best) { best = slots; best_u = us[k]; }
     }
-    a.unroll = env_punroll >= 1 && env_punroll <= 4 ? env_punroll : best_u;
-    a.nvec_pad = (uint32_t)round_up(m->pvec, 16 * a.unroll);
+    a.unroll = best_u;
+    for (int k = 0; k < nus; ++k) if (env_punroll == us[k]) a.unroll = env_punroll;
+    a.nvec_pad = (uint32_t)round_up(m->pvec, (size_t)lpr * a.unroll);
     smem = (size_t)P * a.nvec_pad * 16;
     mask_mode = kMaskPacked;
     if (smem > kSweepLdsLimit)
@@ -890,7 +898,8 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
 #define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
 #define BITS(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskLdsBits>(w, a, smem, st, missing, general, &grid)
 #define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskGlobalBytes>(w, a, smem, st, missing, general, &grid)
-#define PACKED(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskPacked>(w, a, smem, st, missing, general, &grid)
+#define PACKED(PV, MODEV) rc = lpr == 4 ? launch_pm<PV, MODEV, kMaskPacked, 4>(w, a, smem, st, missing, general, &grid) \
+                                          : launch_pm<PV, MODEV, kMaskPacked, 16>(w, a, smem, st, missing, general, &grid)
   if (mask_mode == kMaskPacked) {
     if (mode == kModeSummary) {
       if (P == 1) PACKED(1, kModeSummary); else if (P == 2) PACKED(2, kModeSummary); else if (P == 4) PACKED(4, kModeSummary); else PACKED(8, kModeSummary);

@@ -129,6 +129,28 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t x) {
   x += dpp<0x140>(x);  // row_mirror
   return x;
 }
+// all-reduce over groups of LPR consecutive lanes (LPR = 16: one DPP row, LPR = 4: one quad); values that are NOT dot4
+// results (the packed cores' popcounts), so no wait states are needed
+template <int LPR>
+__device__ __forceinline__ uint32_t group_sum(uint32_t x) {
+  x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  if constexpr (LPR == 16) {
+    x += dpp<0x141>(x);  // row_half_mirror
+    x += dpp<0x140>(x);  // row_mirror
+  }
+  return x;
+}
+template <int LPR>
+__device__ __forceinline__ uint32_t group_or(uint32_t x) {
+  x |= dpp<0xB1>(x);
+  x |= dpp<0x4E>(x);
+  if constexpr (LPR == 16) {
+    x |= dpp<0x141>(x);
+    x |= dpp<0x140>(x);
+  }
+  return x;
+}
 __device__ __forceinline__ uint32_t row16_or(uint32_t x) {
   x |= dpp<0xB1>(x);
   x |= dpp<0x4E>(x);
@@ -455,13 +477,15 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
 // plane one bit per column; masks are bit vectors too.  s0[p] = members with bit 0 set (the alt count when NPL == 1),
 // s1 / s01 as in count_row_planes, n[p] = called members, allele_or = OR of the called allele values.  Same batching as
 // the byte cores: U 16-byte vectors (128 columns each) per lane in flight, clamped addresses, zero-padded masks.
+// LPR lanes share a row: 16 (one DPP row, 256 B contiguous per load instruction) or 4 (one quad, 64 B per instruction and
+// a two-step reduction: packed rows are short - C4 is 40 vectors - and four lanes cover them with no idle slots).
 __device__ __forceinline__ uint32_t popc128(const uint4& v, uint32_t acc) {
   acc += __builtin_popcount(v.x); acc += __builtin_popcount(v.y); acc += __builtin_popcount(v.z); acc += __builtin_popcount(v.w);
   return acc;
 }
 __device__ __forceinline__ uint4 and128(const uint4& a, const uint4& b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
 
-template <int P, bool MISSING, bool NEED_ALL, int NPL, int U>
+template <int P, bool MISSING, bool NEED_ALL, int NPL, int U, int LPR>
 __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uint4* __restrict__ lds_mask, uint32_t nvec_pad,
                                                  const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1,
                                                  const uint8_t* __restrict__ called_ptr, int gl, uint32_t (&n)[P], uint32_t& n_all,
@@ -471,11 +495,11 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
   n_all = 0;
   allele_or = 0;
   const uint32_t last = mv.nvec - 1;
-  for (uint32_t v0 = gl; v0 < nvec_pad; v0 += 16 * U) {
+  for (uint32_t v0 = gl; v0 < nvec_pad; v0 += LPR * U) {
     uint4 x0[U], x1[U], cb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t v = v0 + 16 * u;
+      const uint32_t v = v0 + LPR * u;
       const uint32_t vc = v < last ? v : last;
       x0[u] = load_stream(row0 + (size_t)vc * 16);
       if (NPL == 2) x1[u] = load_stream(row1 + (size_t)vc * 16);
@@ -483,7 +507,7 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t v = v0 + 16 * u;
+      const uint32_t v = v0 + LPR * u;
       const bool inside = v <= last;
       uint4 a0 = x0[u], a1 = NPL == 2 ? x1[u] : make_uint4(0, 0, 0, 0);
       if (MISSING) {
@@ -507,12 +531,12 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
   }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    if (MISSING) n[p] = row16_sum(n[p]);
-    s0[p] = row16_sum(s0[p]);
-    if (NPL == 2) { s1[p] = row16_sum(s1[p]); s01[p] = row16_sum(s01[p]); }
+    if (MISSING) n[p] = group_sum<LPR>(n[p]);
+    s0[p] = group_sum<LPR>(s0[p]);
+    if (NPL == 2) { s1[p] = group_sum<LPR>(s1[p]); s01[p] = group_sum<LPR>(s01[p]); }
   }
-  if (MISSING && NEED_ALL) n_all = row16_sum(n_all);
-  if (NPL == 2) allele_or = row16_or(allele_or);
+  if (MISSING && NEED_ALL) n_all = group_sum<LPR>(n_all);
+  if (NPL == 2) allele_or = group_or<LPR>(allele_or);
 }
 
 // General row, single pass for alleles 0..3 by bit planes: with s0 = #(bit0 set), s1 = #(bit1 set),
@@ -829,8 +853,9 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
 // the sweep kernel
 // ------------------------------------------------------------------------------------------------
 // MM = where the membership masks live (kMaskLdsBytes / kMaskGlobalBytes / kMaskLdsBits, see mask_vec).
-template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes>
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
+  static_assert(LPR == 16 || (LPR == 4 && MM == kMaskPacked), "four lanes per row exist for the packed cores only");
   extern __shared__ __align__(16) unsigned char smem[];
   const MatrixView mv = A.mv;
   const uint32_t nvec = mv.nvec;
@@ -871,8 +896,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int grp = lane >> 4;
-  const int gl = lane & 15;
+  const int grp = lane / LPR;   // the wave's 64 / LPR groups take LPR rows of the tile each, one row per step
+  const int gl = lane % LPR;
   constexpr bool NEED_ALL = (MODE & kModeWc) != 0;
 
   LaneTotals<P, MODE> T;
@@ -894,8 +919,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       for (int k = 0; k < NW; ++k) { wc.a[k] = 0.0; wc.b[k] = 0.0; }
     }
 
-    for (int s = 0; s < 16; ++s) {
-      const size_t rel = tile_row0 + (size_t)grp * 16 + s;
+    for (int s = 0; s < LPR; ++s) {
+      const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;
       const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);
       const uint8_t* row_ptr = mv.data + row * mv.pitch;
@@ -908,10 +933,16 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         if constexpr (MM == kMaskPacked) {
           uint32_t aor, s1[P], s01[P];
           const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-          if (A.unroll == 4) count_row_packed<P, MISSING, NEED_ALL, 1, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-          else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-          else if (A.unroll == 2) count_row_packed<P, MISSING, NEED_ALL, 1, 2>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-          else count_row_packed<P, MISSING, NEED_ALL, 1, 1>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          if constexpr (LPR == 4) {
+            if (A.unroll == 5) count_row_packed<P, MISSING, NEED_ALL, 1, 5, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else if (A.unroll == 2) count_row_packed<P, MISSING, NEED_ALL, 1, 2, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else count_row_packed<P, MISSING, NEED_ALL, 1, 1, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          } else {
+            if (A.unroll == 4) count_row_packed<P, MISSING, NEED_ALL, 1, 4, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else count_row_packed<P, MISSING, NEED_ALL, 1, 2, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          }
         } else if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
         else count_row_biallelic<P, MISSING, NEED_ALL, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
         if (own) {
@@ -927,10 +958,16 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         if constexpr (MM == kMaskPacked) {
           const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
           const uint8_t* row_ptr1 = mv.data1 + row * mv.pitch;
-          if (A.unroll == 4) count_row_packed<P, MISSING, true, 2, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-          else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-          else if (A.unroll == 2) count_row_packed<P, MISSING, true, 2, 2>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-          else count_row_packed<P, MISSING, true, 2, 1>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          if constexpr (LPR == 4) {
+            if (A.unroll == 5) count_row_packed<P, MISSING, true, 2, 5, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else if (A.unroll == 2) count_row_packed<P, MISSING, true, 2, 2, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else count_row_packed<P, MISSING, true, 2, 1, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          } else {
+            if (A.unroll == 4) count_row_packed<P, MISSING, true, 2, 4, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else count_row_packed<P, MISSING, true, 2, 2, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          }
         } else {
           count_row_planes<P, MISSING, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
         }
@@ -946,8 +983,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         }
         // wave-uniform bound: OR of the called allele values over the four rows of this step
         uint32_t bound = aor;
-        bound |= __shfl_xor(bound, 16, 64);
-        bound |= __shfl_xor(bound, 32, 64);
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) bound |= __shfl_xor(bound, off, 64);
         bound = __builtin_amdgcn_readfirstlane(bound);
         if (bound > (uint32_t)A.max_allele) bound = (uint32_t)A.max_allele;
         double inv1 = 0.0, inv2 = 0.0;

@@ -442,6 +442,12 @@ def test_packed_and_byte_layouts_agree(dev, monkeypatch):
 
         dm.pack()                                  # packed image next to the bytes: the sweeps switch to it
         same(run())
+        for lpr, unroll in (("4", "1"), ("4", "5"), ("16", "2"), ("16", "4")):   # both lane layouts of the packed cores, odd batch depths
+            monkeypatch.setenv("FMH_PACKED_LPR", lpr)
+            monkeypatch.setenv("FMH_PACKED_UNROLL", unroll)
+            same(run())
+        monkeypatch.delenv("FMH_PACKED_LPR")
+        monkeypatch.delenv("FMH_PACKED_UNROLL")
         monkeypatch.setenv("FMH_LAYOUT", "bytes")  # ... unless told otherwise
         same(run())
         monkeypatch.delenv("FMH_LAYOUT")
