@@ -861,13 +861,14 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
     // 128 columns per vector.  Rows of up to 32 vectors (4 096 columns) are shared by FOUR lanes (no idle vector slots
     // on short rows, a two-step reduction: C2 0.081 -> 0.042 ms, C3 0.94 -> 0.63 ms), wider ones by the sixteen lanes of a
     // DPP row (C4's 40 vectors: 1.32 vs 1.34 ms, 200 000 columns: 0.46 vs 0.66 ms); the batch depth U (vectors per lane in
-    // flight per trip) is the one with the fewest padded slots, ties to the deeper batch.
+    // flight per trip) is the one with the fewest padded slots, ties to the deeper batch.  (Eight lanes per row measured between
+    // the two everywhere - C4 1.37 ms - and is not built.)
     const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;  // read per call: tests flip them
     const int env_lpr = getenv("FMH_PACKED_LPR") ? atoi(getenv("FMH_PACKED_LPR")) : 0;
     lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
     const int us4[4] = {1, 2, 3, 5}, us16[3] = {2, 3, 4};
-    const int* us = lpr == 4 ? us4 : us16;
-    const int nus = lpr == 4 ? 4 : 3;
+    const int* us = lpr != 16 ? us4 : us16;
+    const int nus = lpr != 16 ? 4 : 3;
     int best_u = us[0];
     size_t best = SIZE_MAX;
     for (int k = 0; k < nus; ++k) {
@@ -899,7 +900,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
 #define BITS(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskLdsBits>(w, a, smem, st, missing, general, &grid)
 #define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskGlobalBytes>(w, a, smem, st, missing, general, &grid)
 #define PACKED(PV, MODEV) rc = lpr == 4 ? launch_pm<PV, MODEV, kMaskPacked, 4>(w, a, smem, st, missing, general, &grid) \
-                                          : launch_pm<PV, MODEV, kMaskPacked, 16>(w, a, smem, st, missing, general, &grid)
+                                         : launch_pm<PV, MODEV, kMaskPacked, 16>(w, a, smem, st, missing, general, &grid)
   if (mask_mode == kMaskPacked) {
     if (mode == kModeSummary) {
       if (P == 1) PACKED(1, kModeSummary); else if (P == 2) PACKED(2, kModeSummary); else if (P == 4) PACKED(4, kModeSummary); else PACKED(8, kModeSummary);

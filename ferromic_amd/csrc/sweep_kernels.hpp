@@ -135,20 +135,16 @@ template <int LPR>
 __device__ __forceinline__ uint32_t group_sum(uint32_t x) {
   x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
   x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
-  if constexpr (LPR == 16) {
-    x += dpp<0x141>(x);  // row_half_mirror
-    x += dpp<0x140>(x);  // row_mirror
-  }
+  if constexpr (LPR >= 8) x += dpp<0x141>(x);   // row_half_mirror
+  if constexpr (LPR == 16) x += dpp<0x140>(x);  // row_mirror
   return x;
 }
 template <int LPR>
 __device__ __forceinline__ uint32_t group_or(uint32_t x) {
   x |= dpp<0xB1>(x);
   x |= dpp<0x4E>(x);
-  if constexpr (LPR == 16) {
-    x |= dpp<0x141>(x);
-    x |= dpp<0x140>(x);
-  }
+  if constexpr (LPR >= 8) x |= dpp<0x141>(x);
+  if constexpr (LPR == 16) x |= dpp<0x140>(x);
   return x;
 }
 __device__ __forceinline__ uint32_t row16_or(uint32_t x) {
@@ -855,7 +851,7 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
 // MM = where the membership masks live (kMaskLdsBytes / kMaskGlobalBytes / kMaskLdsBits, see mask_vec).
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
-  static_assert(LPR == 16 || (LPR == 4 && MM == kMaskPacked), "four lanes per row exist for the packed cores only");
+  static_assert(LPR == 16 || ((LPR == 4 || LPR == 8) && MM == kMaskPacked), "four / eight lanes per row exist for the packed cores only");
   extern __shared__ __align__(16) unsigned char smem[];
   const MatrixView mv = A.mv;
   const uint32_t nvec = mv.nvec;
@@ -933,11 +929,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         if constexpr (MM == kMaskPacked) {
           uint32_t aor, s1[P], s01[P];
           const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-          if constexpr (LPR == 4) {
-            if (A.unroll == 5) count_row_packed<P, MISSING, NEED_ALL, 1, 5, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else if (A.unroll == 2) count_row_packed<P, MISSING, NEED_ALL, 1, 2, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else count_row_packed<P, MISSING, NEED_ALL, 1, 1, 4>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+          if constexpr (LPR != 16) {
+            if (A.unroll == 5) count_row_packed<P, MISSING, NEED_ALL, 1, 5, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else if (A.unroll == 2) count_row_packed<P, MISSING, NEED_ALL, 1, 2, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
+            else count_row_packed<P, MISSING, NEED_ALL, 1, 1, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
           } else {
             if (A.unroll == 4) count_row_packed<P, MISSING, NEED_ALL, 1, 4, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
             else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
@@ -958,11 +954,11 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         if constexpr (MM == kMaskPacked) {
           const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
           const uint8_t* row_ptr1 = mv.data1 + row * mv.pitch;
-          if constexpr (LPR == 4) {
-            if (A.unroll == 5) count_row_packed<P, MISSING, true, 2, 5, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else if (A.unroll == 2) count_row_packed<P, MISSING, true, 2, 2, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else count_row_packed<P, MISSING, true, 2, 1, 4>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          if constexpr (LPR != 16) {
+            if (A.unroll == 5) count_row_packed<P, MISSING, true, 2, 5, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else if (A.unroll == 2) count_row_packed<P, MISSING, true, 2, 2, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+            else count_row_packed<P, MISSING, true, 2, 1, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
           } else {
             if (A.unroll == 4) count_row_packed<P, MISSING, true, 2, 4, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
             else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
