@@ -26,6 +26,8 @@ def main():
         thr = np.stack([base[p % 2] for p in range(G)])
         dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=False, max_allele=1)
         dm.generate(7, 0, thr, poc, 0)
+        if os.environ.get("MEASURE_LAYOUT", "packed") == "packed":
+            dm.pack(release_bytes=True)
         masks = np.ascontiguousarray(np.stack([(poc == p) for p in range(G)]).astype(np.uint8))
         nw = 1 + G * (G - 1) // 2
         bufs = [device.DeviceBuffer(0, 8 * nw * S), device.DeviceBuffer(0, 8 * nw * S), device.DeviceBuffer(0, nw * S), device.DeviceBuffer(0, 4 * G * S)]
