@@ -17,7 +17,6 @@ namespace fmh {
 // so diff(i, j) = ploidy*(T_i + T_j) - 2*G(i, j) with G the Gram product of plane 1 and T_i = sum over sites of cnt_i(1),
 // which the same product delivers as G(i, ones) against an all-ones row appended after the last sample.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPdTile = 64;
 constexpr int kPdBlock = 128;   // samples per planes-kernel workgroup
 constexpr int kPdStageK = 128;  // K BYTES per sample per Gram stage: 128 sites as int8, 256 sites as FP4 (two per byte)
 
@@ -319,7 +318,6 @@ __global__ __launch_bounds__(256) void pd_planes_packed_kernel(const uint8_t* __
 // they are walking the same K range over different tile pairs and every stage tile fetched from HBM by one of them
 // is an L2 hit for the others that need it.
 typedef int pd_v4i __attribute__((ext_vector_type(4)));
-typedef int pd_v16i __attribute__((ext_vector_type(16)));
 typedef int pd_v8i __attribute__((ext_vector_type(8)));
 typedef float pd_v4f __attribute__((ext_vector_type(4)));
 
