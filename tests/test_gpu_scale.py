@@ -35,8 +35,18 @@ def two_pops(N):
     return poc, np.stack([poc == 0, poc == 1]).astype(np.uint8)
 
 
+LAYOUTS = ["packed", "bytes"]  # the bit-packed resident image (what fmh_matrix_create keeps) and the u8 rows
+
+
+def settle(dm, layout):
+    """A generated cohort holds u8 rows; `packed` turns it into what fmh_matrix_create would have left: planes only."""
+    if layout == "packed":
+        dm.pack(release_bytes=True)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("missing", [0.0, 0.01])
-def test_c2_full_against_c_oracle(dev, missing):
+def test_c2_full_against_c_oracle(dev, missing, layout):
     S, N = 1_000_000, 500
     seed = S + N
     thr = thresholds(S, seed)
@@ -44,6 +54,7 @@ def test_c2_full_against_c_oracle(dev, missing):
     dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=missing > 0)
     mt = int(missing * (1 << 24))
     dm.generate(seed, 0, thr, poc, mt)
+    settle(dm, layout)
     g = dev.Groups(dm, masks)
     got = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
     data, words = dm.download()
@@ -73,13 +84,15 @@ def test_c2_full_against_c_oracle(dev, missing):
         assert H.rel_close(s.totals[p]["pi_sum"], exp.pop[p]["pi_sum"])
 
 
-def test_c4_width_properties(dev):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_c4_width_properties(dev, layout):
     S, N = 2_000_000, 2500
     seed = 10_002_500
     thr = thresholds(S, seed)
     poc, masks = two_pops(N)
     dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
     dm.generate(seed, 0, thr, poc, 0)
+    settle(dm, layout)
     g = dev.Groups(dm, masks)
     full = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
     t = full.totals
@@ -120,7 +133,8 @@ def test_c4_width_properties(dev):
         H.assert_bits_equal(full.sites[name][b:e], getattr(exp, name), name)
 
 
-def test_c3_wc_four_populations_properties(dev):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_c3_wc_four_populations_properties(dev, layout):
     """W&C at C3 width (2 500 haplotypes, 4 populations): pair (i, j) of the 4-group sweep equals a
     2-group sweep of just those groups; regional sums equal the track sums."""
     S, N, P = 300_000, 1250, 4
@@ -131,6 +145,7 @@ def test_c3_wc_four_populations_properties(dev):
     poc = np.repeat(pop_of_sample, 2)
     dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=True)
     dm.generate(seed, 0, thr, poc, int(0.02 * (1 << 24)))
+    settle(dm, layout)
     masks = np.stack([poc == p for p in range(P)]).astype(np.uint8)
     w4 = dev.wc_sweep(dm, dev.Groups(dm, masks))
     pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
@@ -148,7 +163,8 @@ def test_c3_wc_four_populations_properties(dev):
         assert H.rel_close(float(w4.b[slot][ok].sum()), float(w4.sum_b[slot]))
 
 
-def test_c3_wc_sampled_sites_against_oracle(dev):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_c3_wc_sampled_sites_against_oracle(dev, layout):
     """SURVEY 8(d) parity gate for C3: a fixed subsample of sites of a C3-width cohort (2 500 haplotypes, 4 populations)
     against the oracle's literal per-site W&C (calculate_fst_wc_at_site_with_membership), a and b bit for bit; the
     regional sums against the oracle's sums over the SAME subsample read back from the GPU tracks."""
@@ -160,6 +176,7 @@ def test_c3_wc_sampled_sites_against_oracle(dev):
     poc = np.repeat(pop_of_sample, 2)
     dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
     dm.generate(seed, 0, thr, poc, 0)
+    settle(dm, layout)
     masks = np.stack([poc == p for p in range(P)]).astype(np.uint8)
     w = dev.wc_sweep(dm, dev.Groups(dm, masks))
     membership = R.SubpopulationMembership.from_map(N, {(s, side): str(pop_of_sample[s]) for s in range(N) for side in (0, 1)})
