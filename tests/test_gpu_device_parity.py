@@ -463,3 +463,38 @@ def test_packed_and_byte_layouts_agree(dev, monkeypatch):
         pd_after = dev.pairwise_differences(dm, N)
         iu = np.triu_indices(N, k=1)
         assert np.array_equal(pd_after[0][iu], pd_before[0][iu]) and np.array_equal(pd_after[1][iu], pd_before[1][iu])
+
+
+def test_pack_api_contract(dev):
+    """fmh_matrix_pack: refuses what the planes cannot hold, is idempotent, and a matrix that released its bytes says so
+    (no byte pointers, no generator) while every read path keeps working."""
+    from ferromic_amd import _abi
+    import ctypes as C
+
+    rng = np.random.default_rng(8)
+    wide_alleles = H.random_dense_matrix(rng, 20, 30, 2, 5, 0.0)
+    dm = upload(dev, wide_alleles)                 # max_allele 5: stays on u8 rows
+    with pytest.raises(_abi.FerromicHipError):
+        dm.pack()
+    ok = dev.DeviceMatrix.alloc(40, 25, 2, with_missing=True)
+    thr = (rng.random((1, 40)) * (1 << 24)).astype(np.uint32)
+    ok.generate(3, 0, thr, np.zeros(50, dtype=np.uint8), missing_threshold24=int(0.1 * (1 << 24)))
+    before = ok.download()
+    ok.pack()
+    ok.pack()                                      # again: same planes
+    ok.generate(3, 0, thr, np.zeros(50, dtype=np.uint8), missing_threshold24=int(0.1 * (1 << 24)))  # bytes present: re-packed
+    ok.pack(release_bytes=True)
+    ok.pack(release_bytes=True)                    # nothing left to pack: a no-op
+    d, b = C.c_void_p(1), C.c_void_p(1)
+    _abi.check(_abi.load().fmh_matrix_device_ptrs(ok._h, C.byref(d), C.byref(b)))
+    assert not d.value and not b.value
+    with pytest.raises(_abi.FerromicHipError):
+        ok.generate(3, 0, thr, np.zeros(50, dtype=np.uint8), 0)
+    after = ok.download()
+    assert np.array_equal(after[0], before[0]) and np.array_equal(after[1], before[1])
+    g = dev.Groups(ok, np.ones((1, 50), dtype=np.uint8))
+    s = dev.population_summaries(ok, g, dev.FORMULA_DENSE)
+    data = np.asarray(before[0]).reshape(40, 50)
+    miss = np.unpackbits(np.asarray(before[1]).view(np.uint8), bitorder="little")[:40 * 50].reshape(40, 50).astype(bool)
+    assert np.array_equal(s.called[0], (~miss).sum(axis=1).astype(np.uint32))
+    assert np.array_equal(s.alt[0], ((data == 1) & ~miss).sum(axis=1).astype(np.uint32))
