@@ -353,13 +353,15 @@ __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t*
 #pragma unroll
   for (int m = 0; m < MT; ++m) { const uint32_t r = wr * (MT * 16) + m * 16 + (lane & 15); offa[m] = r * kPdStageK; swza[m] = (r >> 1) & 7; }
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { const uint32_t r = wc * (NT * 16) + n * 16 + (lane & 15); offb[n] = kImageBytes + r * kPdStageK; swzb[n] = (r >> 1) & 7; }
+  for (int n = 0; n < NT; ++n) { const uint32_t r = wc * (NT * 16) + n * 16 + (lane & 15); offb[n] = r * kPdStageK; swzb[n] = (r >> 1) & 7; }
   for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
     uint32_t t = item % tiles, bi = 0;
     while (t >= nt - bi) { t -= nt - bi; ++bi; }
     const uint32_t bj = bi + t;
     const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
     if (k0 >= s_pad) continue;  // uniform for the workgroup
+    const bool diagonal = bi == bj;
+    const uint32_t b_image = diagonal ? 0u : (uint32_t)kImageBytes;  // where this item's B fragments are read from
     typedef typename std::conditional<FP4, pd_v4f, pd_v4i>::type acc_t;
     acc_t acc[MT][NT];
 #pragma unroll
@@ -386,8 +388,10 @@ __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t*
       unsigned char* lb = la + kImageBytes;
 #pragma unroll
       for (int q = 0; q < kLoadsPerImage; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(pa + q * THREADS * 16), (lptr_t)(la + q * THREADS * 16), 16, 0, 0);
+      if (!diagonal) {  // a diagonal tile pair's B operand IS its A operand: one image, half the fill
 #pragma unroll
-      for (int q = 0; q < kLoadsPerImage; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(pb + q * THREADS * 16), (lptr_t)(lb + q * THREADS * 16), 16, 0, 0);
+        for (int q = 0; q < kLoadsPerImage; ++q) __builtin_amdgcn_global_load_lds((gptr_t)(pb + q * THREADS * 16), (lptr_t)(lb + q * THREADS * 16), 16, 0, 0);
+      }
       pa += tile_stride;
       pb += tile_stride;
     };
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t*
 #pragma unroll
         for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&img[offa[m] + ((cl ^ swza[m]) << 4)]);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[offb[n] + ((cl ^ swzb[n]) << 4)]);
+        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&img[b_image + offb[n] + ((cl ^ swzb[n]) << 4)]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
