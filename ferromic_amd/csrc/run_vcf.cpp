@@ -654,7 +654,7 @@ bool colon_part(sv cell, size_t k, sv* out) {
 
 // per-thread scratch reused across lines
 struct VariantScratch {
-  vector<sv> fields;
+  vector<sv> cells;       // the kept sample columns of the line
   vector<uint32_t> off;   // start of sample s in vals
   vector<uint16_t> len;   // parsed alleles of sample s
   vector<uint8_t> none;   // 1 = genotype is None
@@ -665,24 +665,30 @@ struct VariantScratch {
 // trailing newline exactly as the reference's read_line buffer does.
 bool process_variant(sv line, const string& chr, const vector<Interval>& regions, const vector<size_t>& kept,
                      unsigned min_gq, const RegionMap* allow, const RegionMap* mask, VariantScratch& scr, Variant* out, uint8_t* out_flags) {
-  vector<sv>& fields = scr.fields;
-  fields.clear();
-  {
-    const char* p = line.data();
-    const size_t L = line.size();
-    size_t b = 0;
-    for (size_t i = 0; i < L; ++i)
-      if (p[i] == '\t') { fields.push_back(sv(p + b, i - b)); b = i + 1; }
-    fields.push_back(sv(p + b, L - b));
+  // The nine fixed fields are cut first; the sample columns are then walked in place, one pass: a typical line is
+  // thousands of 7-byte cells, and tokenising it into a vector before looking at any cell cost more than parsing it.
+  // Every failure below makes the reference skip the line (an Err is printed and dropped, None is dropped), so only the
+  // set of conditions matters, not the order they are found in.
+  const char* const lbeg = line.data();
+  const char* const lend = lbeg + line.size();
+  sv fields[9];
+  const char* cur = lbeg;
+  bool more = true;  // a tab followed the last field cut so far
+  for (int f = 0; f < 9; ++f) {
+    if (!more) throw Error("Invalid VCF line format");
+    const char* t = (const char*)memchr(cur, '\t', (size_t)(lend - cur));
+    fields[f] = sv(cur, (size_t)((t ? t : lend) - cur));
+    more = t != nullptr;
+    cur = t ? t + 1 : lend;
   }
-  if (fields.size() < 9) throw Error("Invalid VCF line format");
-  size_t max_idx = 0;
-  for (size_t k : kept) max_idx = std::max(max_idx, k);
-  if (!kept.empty() && fields.size() <= max_idx) throw Error("Invalid VCF line format: missing genotype column");
   const string vcf_chr = normalize_chr_prefix(string(trim_sv(fields[0])));
-  if (vcf_chr != normalize_chr_prefix(trim(chr))) return false;
-  int64_t pos1;
-  if (!parse_i64(string(fields[1]), &pos1)) throw Error("Invalid position");
+  const bool chr_ok = vcf_chr == normalize_chr_prefix(trim(chr));
+  int64_t pos1 = 0;
+  const bool pos_ok = parse_i64(string(fields[1]), &pos1);
+  // the reference checks the column count before anything else; a short line is an error even on another chromosome,
+  // which is the same outcome (skipped) as the None of a foreign chromosome - so the cheap exits come first
+  if (!chr_ok) return false;
+  if (!pos_ok) throw Error("Invalid position");
   if (pos1 < 1) throw Error("Invalid 1-based pos");
   const int64_t pos0 = pos1 - 1;
   bool in_regions = false;
@@ -721,33 +727,53 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
       b = e + 1;
     }
   }
-  if (gq_index == SIZE_MAX) throw Error("GQ field not found in FORMAT");
   const size_t n = kept.size();
-  scr.off.resize(n); scr.len.resize(n); scr.none.resize(n);
+  scr.off.resize(n); scr.len.resize(n); scr.none.resize(n); scr.cells.resize(n);
   scr.vals.clear();
   bool low_gq = false, missing = false;
   size_t max_len = 0;
+  size_t col = 9;  // column index of the field that starts at `cur` (valid while `more`)
   for (size_t i = 0; i < n; ++i) {
-    const sv cell = fields[kept[i]];
+    // skip to column kept[i] (ascending: the header is read left to right)
+    while (col < kept[i]) {
+      if (!more) throw Error("Invalid VCF line format: missing genotype column");
+      const char* t = (const char*)memchr(cur, '\t', (size_t)(lend - cur));
+      more = t != nullptr;
+      cur = t ? t + 1 : lend;
+      ++col;
+    }
+    if (!more) throw Error("Invalid VCF line format: missing genotype column");
+    const char* c = cur;
+    const size_t room = (size_t)(lend - c);
     scr.off[i] = (uint32_t)scr.vals.size();
-    {  // the overwhelmingly common cell "a|b:GQ..." with one-digit alleles and GQ second: no searching at all
-      const char* c = cell.data();
-      const size_t L = cell.size();
-      if (gq_index == 1 && L >= 5 && c[3] == ':' && (c[1] == '|' || c[1] == '/') && (unsigned)(c[0] - '0') < 10u && (unsigned)(c[2] - '0') < 10u) {
-        size_t j = 4;
-        unsigned v = 0;
-        while (j < L && (unsigned)(c[j] - '0') < 10u && v < 100000u) { v = v * 10 + (unsigned)(c[j] - '0'); ++j; }
-        if (j > 4 && v <= 65535u && (j == L || c[j] == ':' || (c[j] == '\n' && j + 1 == L))) {
-          scr.vals.push_back((uint8_t)(c[0] - '0'));
-          scr.vals.push_back((uint8_t)(c[2] - '0'));
-          scr.len[i] = 2;
-          scr.none[i] = 2;  // called, and its GQ is already judged
-          max_len = std::max<size_t>(max_len, 2);
-          if (v < min_gq) low_gq = true;
-          continue;
-        }
+    const char* cell_end = nullptr;
+    bool fast = false;
+    // the overwhelmingly common cell "a|b:GQ..." with one-digit alleles and GQ second: parsed where it stands
+    if (gq_index == 1 && room >= 5 && c[3] == ':' && (c[1] == '|' || c[1] == '/') && (unsigned)(c[0] - '0') < 10u && (unsigned)(c[2] - '0') < 10u) {
+      size_t j = 4;
+      unsigned v = 0;
+      while (j < room && (unsigned)(c[j] - '0') < 10u && v < 100000u) { v = v * 10 + (unsigned)(c[j] - '0'); ++j; }
+      if (j > 4 && v <= 65535u) {
+        if (j == room || c[j] == '\t') { cell_end = c + j; fast = true; }
+        else if (c[j] == '\n' && j + 1 == room) { cell_end = lend; fast = true; }
+        else if (c[j] == ':') { const char* t = (const char*)memchr(c + j, '\t', room - j); cell_end = t ? t : lend; fast = true; }
+      }
+      if (fast) {
+        scr.vals.push_back((uint8_t)(c[0] - '0'));
+        scr.vals.push_back((uint8_t)(c[2] - '0'));
+        scr.len[i] = 2;
+        scr.none[i] = 2;  // called, and its GQ is already judged
+        max_len = std::max<size_t>(max_len, 2);
+        if (v < min_gq) low_gq = true;
       }
     }
+    if (!cell_end) { const char* t = (const char*)memchr(c, '\t', room); cell_end = t ? t : lend; }
+    const sv cell(c, (size_t)(cell_end - c));
+    scr.cells[i] = cell;
+    more = cell_end != lend;
+    cur = more ? cell_end + 1 : lend;
+    ++col;
+    if (fast) continue;
     const sv alleles = cell.substr(0, cell.find(':'));
     scr.len[i] = 0;
     scr.none[i] = 1;
@@ -768,11 +794,12 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
     scr.len[i] = (uint16_t)std::min<size_t>(cnt, 65535);
     max_len = std::max(max_len, cnt);
   }
+  if (gq_index == SIZE_MAX) throw Error("GQ field not found in FORMAT");
   for (size_t i = 0; i < n; ++i) {
     if (scr.none[i] == 2) continue;
     if (scr.none[i]) { missing = true; continue; }
     sv part;
-    if (!colon_part(fields[kept[i]], gq_index, &part)) throw Error("GQ value missing in sample genotype field");
+    if (!colon_part(scr.cells[i], gq_index, &part)) throw Error("GQ value missing in sample genotype field");
     const sv gq_str = trim_sv(part);
     unsigned gq = 0;
     if (!(gq_str == "." || gq_str.empty())) { if (!parse_unsigned_sv(gq_str, 65535, &gq)) gq = 0; }
