@@ -101,6 +101,9 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--layout", choices=["packed", "bytes"], default="packed",
                     help="resident layout of the cohort: bit-packed planes (what fmh_matrix_create keeps for alleles 0..3) or the u8 rows")
+    ap.add_argument("--u8-reference-steps", type=int, default=5,
+                    help="with --layout packed: before the u8 rows are released, time this many sweeps over them (the layout "
+                         "north_star names) and report their HBM fraction next to the headline; 0 skips it")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-reduce path even with one rank (measures the software cost of the collective step on a one-GPU box)")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
@@ -157,7 +160,7 @@ def main() -> int:
     gen_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     if args.layout == "packed":
-        dm.pack(release_bytes=True)  # the resident image fmh_matrix_create keeps: one bit per haplotype, u8 rows freed
+        dm.pack(release_bytes=False)  # the resident image fmh_matrix_create keeps: one bit per haplotype
     pack_s = time.perf_counter() - t0
     masks = np.stack([(poc == 0), (poc == 1)]).astype(np.uint8)
     groups = device.Groups(dm, masks)
@@ -192,6 +195,30 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
         _abi.check(lib.fmh_stream_synchronize(local_rank, None))
+
+    # the same sweep over the u8 rows (one byte per haplotype, the layout the reference and north_star name), timed while the
+    # matrix still holds them: its HBM fraction is reported next to the headline; then the rows are released
+    u8_reference = None
+    if args.layout == "packed":
+        if args.u8_reference_steps > 0:
+            os.environ["FMH_LAYOUT"] = "bytes"  # read per call by the library: sweeps take the u8 kernels while the rows exist
+            local = _abi.HudsonTotals()
+            _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
+            lib.fmh_timing_enable(1)
+            lib.fmh_timing_reset()
+            for _ in range(args.u8_reference_steps):
+                _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
+            ms8, n8 = C.c_double(), C.c_uint64()
+            lib.fmh_timing_read(C.byref(ms8), C.byref(n8))
+            lib.fmh_timing_enable(0)
+            del os.environ["FMH_LAYOUT"]
+            k8 = ms8.value / 1e3 / max(n8.value, 1)
+            u8_reference = {"kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, u8>", "kernel_ms_avg": k8 * 1e3,
+                            "algorithmic_bytes_per_site": H + W_OUT_HUDSON, "achieved": (H + W_OUT_HUDSON) * S / k8 / 1e9,
+                            "frac": (H + W_OUT_HUDSON) * S / k8 / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "sites_per_s_kernel": S / k8,
+                            "steps": args.u8_reference_steps,
+                            "hudson_fst": local.numerator_sum / local.denominator_sum if local.denominator_sum > 1e-12 else None}
+        dm.pack(release_bytes=True)  # from here on the matrix is what fmh_matrix_create leaves: planes only
 
     for _ in range(args.warmup):
         step()
@@ -272,6 +299,8 @@ def main() -> int:
             # have to move per second to keep up - above the HBM peak when the packed layout does its job
             "u8_layout_bytes_per_site": b_site_u8,
             "u8_layout_equivalent_GBs": b_site_u8 * S / avg_kernel_s / 1e9,
+            # measured, same cohort, same process: the sweep over u8 rows (one byte per haplotype) before they were released
+            "u8_layout_measured": u8_reference,
         },
         "results": {
             "hudson_fst": totals.numerator_sum / totals.denominator_sum if totals.denominator_sum > 1e-12 else None,
