@@ -1,9 +1,13 @@
 // sweep_kernels.hpp — hand-written gfx950 (CDNA4, wave64) kernels for the per-site allele-count
 // sweep and its fused statistics epilogues.  Included by abi.hip only.
 //
-// Geometry (DESIGN.md §3)
-//   * genotype matrix: site-major u8, row pitch a multiple of 16 B, padding bytes zero;
-//     optional "called" bit-row per site (bit h set = entry h is called).
+// Geometry (DESIGN.md §2, §3)
+//   * genotype matrix, default resident form: BIT PLANES (fmh_matrix_pack) - plane 0 = allele & 1, plane 1 = allele >> 1
+//     (alleles 2..3), a "called" plane when calls can be missing; 128 columns per 16-byte vector.  Counting is AND +
+//     v_bcnt against bit masks (count_row_packed); rows of up to 32 vectors are shared by 4 lanes, wider ones by 16.
+//   * genotype matrix, u8 form (alleles >= 4, wrapped memory, FMH_LAYOUT=bytes): site-major u8, row pitch a multiple
+//     of 16 B, padding bytes zero; optional "called" bit-row per site (bit h set = entry h is called).  The points
+//     below describe this form; the packed cores keep the same tile / epilogue / reduction structure.
 //   * one workgroup = 4 waves; one wave owns a tile of 64 consecutive sites.  A wave is split in
 //     four 16-lane groups (one DPP row each).  Group g sweeps rows 16g .. 16g+15 of the tile, one
 //     row per step; its 16 lanes read the row as consecutive 16-byte vectors (256 B contiguous per
