@@ -36,3 +36,19 @@ def test_two_ranks_equal_one_rank():
     for a, b in zip(one["results"]["pi_sum"], two["results"]["pi_sum"]):
         assert a == pytest.approx(b, rel=1e-9)
     assert one["results"]["hudson_fst"] == pytest.approx(two["results"]["hudson_fst"], rel=1e-9)
+
+
+def test_rccl_collective_path_with_one_rank():
+    """The collective step through RCCL itself (backend nccl, a one-rank group): async all-reduce on RCCL's stream, collected
+    one step later, flushed by the fence - same totals as the run without it, and both layouts' roofline blocks present."""
+    common = ["--steps", "4", "--warmup", "1", "--sites", "250000", "--haplotypes", "1000", "--no-cpu-baseline"]
+    plain = run([sys.executable, "bench.py"] + common)
+    coll = run([sys.executable, "bench.py", "--force-collective"] + common)
+    assert coll["results"] == plain["results"]
+    for d in (plain, coll):
+        r = d["roofline"]
+        assert r["algorithmic_bytes_per_site"] == 125 + 56 and r["u8_layout_bytes_per_site"] == 1000 + 56
+        assert r["u8_layout_measured"]["hudson_fst"] == d["results"]["hudson_fst"]   # u8 rows and bit planes: the same regional FST
+        assert 0 < r["frac"] and 0 < r["u8_layout_measured"]["frac"]
+    u8 = run([sys.executable, "bench.py", "--layout", "bytes"] + common)
+    assert u8["results"] == plain["results"] and u8["roofline"]["algorithmic_bytes_per_site"] == 1056 and u8["dtype"] == "u8"
