@@ -19,10 +19,12 @@ python3 - "$O" <<'PY'
 import csv, json, sys
 o = sys.argv[1]
 def sweep_mean(path):
-    for row in csv.DictReader(open(path)):
-        if "sweep_kernel" in row["kernel"]:
-            return float(row["mean"])
-    raise SystemExit("no sweep kernel in " + path)
+    # the packed sweep (mask mode 3) - the run also holds the five u8-row reference sweeps (mask mode 0) of bench.py
+    rows = [r for r in csv.DictReader(open(path)) if "sweep_kernel" in r["kernel"]]
+    packed = [r for r in rows if r["kernel"].rstrip('"').rstrip().endswith(", 3, 16>")]
+    if not packed:
+        raise SystemExit("no packed sweep kernel in " + path)
+    return float(packed[0]["mean"])
 fetch, write = sweep_mean(o + "/c4_pmc_fetch_summary.csv"), sweep_mean(o + "/c4_pmc_write_summary.csv")
 json.dump({"10000000x5000:packed": {
     "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_size_kb": fetch, "write_size_kb": write,
