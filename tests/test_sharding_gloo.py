@@ -28,3 +28,27 @@ def test_region_sharded_allreduce_gloo(world):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert f"GLOO_SHARDING_OK world={world}" in out.stdout
+
+
+def test_totals_ride_exactly_in_one_f64_vector():
+    """One all-reduce carries the f64 sums and the u64 counts: counts below 2^53 survive the f64 round trip exactly, larger
+    ones are refused rather than rounded."""
+    from ferromic_amd import _abi, sharding
+
+    t = _abi.HudsonTotals()
+    t.numerator_sum, t.denominator_sum, t.pi1_sum = 0.1 + 0.2, 1e-300, 3.0e15 + 0.5
+    t.dxy_uncallable_sites = (1 << 53) - 1
+    t.sites_with_components = 10_000_000 * 8
+    t.pop[0].segregating_sites = 123_456_789_012
+    t.pop[1].uncallable_sites = 7
+    v = sharding._pack(t)
+    assert len(v) == _abi.HUDSON_PACK_F64 + _abi.HUDSON_PACK_U64 and all(isinstance(x, float) for x in v)
+    back = sharding._unpack(v)
+    assert back.numerator_sum == t.numerator_sum and back.denominator_sum == t.denominator_sum and back.pi1_sum == t.pi1_sum
+    assert back.dxy_uncallable_sites == (1 << 53) - 1 and back.sites_with_components == 80_000_000
+    assert back.pop[0].segregating_sites == 123_456_789_012 and back.pop[1].uncallable_sites == 7
+    doubled = sharding._unpack([2 * x for x in v[:_abi.HUDSON_PACK_F64]] + [x + x for x in v[_abi.HUDSON_PACK_F64:]])  # what a 2-rank sum does
+    assert doubled.sites_with_components == 160_000_000 and doubled.pop[0].segregating_sites == 246_913_578_024
+    t.sites_with_components = 1 << 53
+    with pytest.raises(OverflowError):
+        sharding._pack(t)
