@@ -78,6 +78,7 @@ def test_population_rejects_non_positive_sequence_length():
 def test_inversion_allele_frequency_counts_haplotypes():
     sample_map = {"sampleA": (0, 1), "sampleB": (1, 1), "sampleC": (2, 255)}
     assert fm.inversion_allele_frequency(sample_map) == pytest.approx(0.75)
+    assert fm.inversion_allele_frequency({"Sample1": (0, 1), "Sample2": (0, 1), "Sample3": (0, 0)}) == pytest.approx(2.0 / 6.0, abs=1e-6)  # stats_tests.rs:1770-1826
     assert fm.inversion_allele_frequency({"x": (2, 3)}) is None
     with pytest.raises(ValueError, match="sample_to_group must be a dict"):
         fm.inversion_allele_frequency([("a", (0, 1))])

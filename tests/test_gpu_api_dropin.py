@@ -424,3 +424,14 @@ def test_hudson_reference_property_cases_through_api(kats):
             assert len(sites) == c["n_sites"]
             s = sites[0]
             assert None not in (s.d_xy, s.pi_pop1, s.pi_pop2, s.fst) and c["site_fst_min"] <= s.fst <= c["site_fst_max"]
+
+
+def test_pairwise_differences_reference_cases_literal(kats):
+    """The four pairwise tests of src/tests/stats_tests.rs:368-470 through the drop-in module (FP4 / int8 MFMA Gram)."""
+    for case in kats["pairwise_differences"]["cases"]:
+        variants = [build_variant(pos, genos) for pos, genos in case["variants"]]
+        res = fm.pairwise_differences(variants, case["sample_count"], case["sequence_length"])
+        assert len(res) == case["result_len"]
+        got = {f"{p.sample_i},{p.sample_j}": [p.differences, p.comparable_sites] for p in res}
+        for key, exp in case["expected"].items():
+            assert got[key] == exp, (case["name"], key)

@@ -323,3 +323,14 @@ def test_hudson_reference_property_cases(kats):
             s = sites[0]
             assert s.d_xy is not None and s.pi_pop1 is not None and s.pi_pop2 is not None and s.fst is not None
             assert c["site_fst_min"] <= s.fst <= c["site_fst_max"]
+
+
+def test_pairwise_differences_reference_cases(kats):
+    """src/tests/stats_tests.rs:368-470, literally: per-haplotype mismatch counts and comparable sites of sample pairs."""
+    for case in kats["pairwise_differences"]["cases"]:
+        variants = [R.make_variant(pos, genos) for pos, genos in case["variants"]]
+        res = R.calculate_pairwise_differences(variants, case["sample_count"], case["sequence_length"])
+        assert len(res) == case["result_len"]
+        got = {f"{i},{j}": [d, c] for (i, j), d, c in res}
+        for key, exp in case["expected"].items():
+            assert got[key] == exp, (case["name"], key)
