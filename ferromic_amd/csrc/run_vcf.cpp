@@ -815,6 +815,14 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
   out->num_samples = n;
   out->stride = max_ploidy;
   out->max_len = max_len;
+  if (scr.vals.size() == n * max_ploidy && max_ploidy == 2 && !missing) {
+    // nothing is None, no genotype is longer than two alleles and there are 2 n alleles in all: every genotype is a called
+    // diploid one (the usual line) and the parsed alleles already ARE the packed row
+    out->data.swap(scr.vals);
+    scr.vals.clear();
+    *out_flags = flags;
+    return true;
+  }
   out->data.assign(n * max_ploidy, 0xFF);
   for (size_t s2 = 0; s2 < n; ++s2)
     if (scr.none[s2] != 1) {
