@@ -881,27 +881,44 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
   // (the reference runs the same stage as a reader thread + rayon consumers, process.rs:4274-4392).
   vector<std::pair<Variant, uint8_t>> items;
   const unsigned T = worker_threads();
-  string block, carry, ahead;
-  const size_t kBlock = (size_t)64 << 20;
+  string cur, next, carry, spill;
+  // (FERROMIC_INGEST_BLOCK / FERROMIC_INGEST_HEAD shrink the two sizes so that tests cross block borders on small files)
+  const size_t kBlock = getenv("FERROMIC_INGEST_BLOCK") ? std::max<size_t>(16, (size_t)atoll(getenv("FERROMIC_INGEST_BLOCK"))) : ((size_t)64 << 20);
+  const size_t kHead = getenv("FERROMIC_INGEST_HEAD") ? (size_t)atoll(getenv("FERROMIC_INGEST_HEAD")) : ((size_t)4 << 20);  // room in front of every block for the unfinished line of the previous one
   bool eof = false;
-  // the next block is read (and inflated) by a helper thread while this one is parsed
-  auto fetch = [&r, kBlock](string* dst) -> size_t { dst->resize(kBlock); const size_t got = r.read(&(*dst)[0], kBlock); dst->resize(got); return got; };
-  size_t ahead_got = fetch(&ahead);
+  // the next block is read (and inflated) by a helper thread while this one is parsed; the two buffers are allocated
+  // once and a block is never copied: the carried-over partial line is written into the headroom in front of it
+  auto fetch = [&r, kBlock, kHead](string* dst) -> size_t { if (dst->size() != kHead + kBlock) dst->resize(kHead + kBlock); return r.read(&(*dst)[kHead], kBlock); };
+  size_t next_got = fetch(&next);
   while (!eof) {
-    block = std::move(carry);
-    carry.clear();
-    block += ahead;
-    if (ahead_got < kBlock) eof = true;
-    std::thread reader;
-    if (!eof) reader = std::thread([&] { ahead_got = fetch(&ahead); });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) { StageTimer w("    ingest:wait_for_reader"); t.join(); } } } joiner{reader};
-    size_t usable = block.size();
-    if (!eof) {
-      const size_t nl = block.rfind('\n');
-      if (nl == string::npos) { carry.swap(block); continue; }
-      usable = nl + 1;
-      carry.assign(block, usable, string::npos);
+    cur.swap(next);
+    const size_t got = next_got;
+    if (got < kBlock) eof = true;
+    const char* bdata;
+    size_t bsize;
+    if (carry.size() <= kHead) {
+      memcpy(&cur[kHead - carry.size()], carry.data(), carry.size());
+      bdata = cur.data() + (kHead - carry.size());
+      bsize = carry.size() + got;
+    } else {  // a line longer than the headroom: the slow way, once
+      spill.assign(carry);
+      spill.append(cur.data() + kHead, got);
+      bdata = spill.data();
+      bsize = spill.size();
     }
+    std::thread reader;
+    if (!eof) reader = std::thread([&] { next_got = fetch(&next); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) { StageTimer w("    ingest:wait_for_reader"); t.join(); } } } joiner{reader};
+    size_t usable = bsize;
+    if (!eof) {
+      const void* nlp = memrchr(bdata, '\n', bsize);
+      if (!nlp) { carry.assign(bdata, bsize); continue; }
+      usable = (size_t)((const char*)nlp - bdata) + 1;
+      carry.assign(bdata + usable, bsize - usable);
+    } else {
+      carry.clear();
+    }
+    struct { const char* d; const char* data() const { return d; } } block{bdata};
     if (usable == 0) continue;
     // line-aligned cut points
     vector<size_t> cut(T + 1, usable);
