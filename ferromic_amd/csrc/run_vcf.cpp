@@ -4,6 +4,8 @@
 // hudson_fst_results.tsv.gz).  Host C++ does text ingest (config TSV, BED/TSV regions, FASTA index,
 // VCF) and the writers; every statistic over genotype data is computed on the GPU through the
 // C-ABI of libferromic_hip.so.  PHYLIP / CDS export and PCA are outside the path.
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -510,7 +512,7 @@ struct LineReader {
     if (!f) throw Error("cannot open " + path);
     gzbuffer(f, 1 << 20);
   }
-  ~LineReader() { if (f) gzclose(f); if (raw_fd >= 0) close(raw_fd); }
+  ~LineReader() { if (f) gzclose(f); if (raw_fd >= 0) close(raw_fd); if (map_base) munmap((void*)map_base, map_len); }
   int raw_fd = -1;
   int64_t raw_off = 0;
   string path_;
@@ -537,6 +539,27 @@ struct LineReader {
       total += (size_t)got;
     }
     return total;
+  }
+  // Plain text only: the rest of the file (whatever follows the lines next() consumed) as one read-only mapping, so the
+  // body is parsed where the page cache holds it - no read() copy, no reader thread.  False for gzip / BGZF input.
+  const char* map_base = nullptr;
+  size_t map_len = 0;
+  bool map_rest(const char** base, size_t* len) {
+    if (bgzf || !gzdirect(f)) return false;
+    const int64_t off = (int64_t)gztell(f);
+    const int fd = open(path_.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0 || off > st.st_size) { close(fd); return false; }
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    map_base = (const char*)m;
+    map_len = (size_t)st.st_size;
+    *base = map_base + off;
+    *len = map_len - (size_t)off;
+    return true;
   }
   bool next(string& out) {
     if (bgzf) return bgzf->next_line(out);
@@ -881,45 +904,9 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
   // (the reference runs the same stage as a reader thread + rayon consumers, process.rs:4274-4392).
   vector<std::pair<Variant, uint8_t>> items;
   const unsigned T = worker_threads();
-  string cur, next, carry, spill;
-  // (FERROMIC_INGEST_BLOCK / FERROMIC_INGEST_HEAD shrink the two sizes so that tests cross block borders on small files)
-  const size_t kBlock = getenv("FERROMIC_INGEST_BLOCK") ? std::max<size_t>(16, (size_t)atoll(getenv("FERROMIC_INGEST_BLOCK"))) : ((size_t)64 << 20);
-  const size_t kHead = getenv("FERROMIC_INGEST_HEAD") ? (size_t)atoll(getenv("FERROMIC_INGEST_HEAD")) : ((size_t)4 << 20);  // room in front of every block for the unfinished line of the previous one
-  bool eof = false;
-  // the next block is read (and inflated) by a helper thread while this one is parsed; the two buffers are allocated
-  // once and a block is never copied: the carried-over partial line is written into the headroom in front of it
-  auto fetch = [&r, kBlock, kHead](string* dst) -> size_t { if (dst->size() != kHead + kBlock) dst->resize(kHead + kBlock); return r.read(&(*dst)[kHead], kBlock); };
-  size_t next_got = fetch(&next);
-  while (!eof) {
-    cur.swap(next);
-    const size_t got = next_got;
-    if (got < kBlock) eof = true;
-    const char* bdata;
-    size_t bsize;
-    if (carry.size() <= kHead) {
-      memcpy(&cur[kHead - carry.size()], carry.data(), carry.size());
-      bdata = cur.data() + (kHead - carry.size());
-      bsize = carry.size() + got;
-    } else {  // a line longer than the headroom: the slow way, once
-      spill.assign(carry);
-      spill.append(cur.data() + kHead, got);
-      bdata = spill.data();
-      bsize = spill.size();
-    }
-    std::thread reader;
-    if (!eof) reader = std::thread([&] { next_got = fetch(&next); });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) { StageTimer w("    ingest:wait_for_reader"); t.join(); } } } joiner{reader};
-    size_t usable = bsize;
-    if (!eof) {
-      const void* nlp = memrchr(bdata, '\n', bsize);
-      if (!nlp) { carry.assign(bdata, bsize); continue; }
-      usable = (size_t)((const char*)nlp - bdata) + 1;
-      carry.assign(bdata + usable, bsize - usable);
-    } else {
-      carry.clear();
-    }
+  // one block of whole lines: cut into T line-aligned runs, each parsed by one pool thread; results keep the file order
+  auto parse_block = [&](const char* bdata, size_t usable) {
     struct { const char* d; const char* data() const { return d; } } block{bdata};
-    if (usable == 0) continue;
     // line-aligned cut points
     vector<size_t> cut(T + 1, usable);
     cut[0] = 0;
@@ -951,6 +938,68 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
     for (unsigned t = 0; t < T; ++t) {
       if (!complaints[t].empty()) fputs(complaints[t].c_str(), stderr);
       for (auto& it : parts[t]) items.push_back(std::move(it));
+    }
+  };
+  const char* mapped = nullptr;
+  size_t mapped_len = 0;
+  static const bool env_no_mmap = getenv("FERROMIC_NO_MMAP") != nullptr;
+  if (!env_no_mmap && r.map_rest(&mapped, &mapped_len)) {
+    // plain text: blocks are windows of the mapping, each ending at a line end (a line longer than a block is one block)
+    const size_t kWindow = getenv("FERROMIC_INGEST_BLOCK") ? std::max<size_t>(16, (size_t)atoll(getenv("FERROMIC_INGEST_BLOCK"))) : ((size_t)64 << 20);
+    size_t off = 0;
+    while (off < mapped_len) {
+      size_t bsize = std::min(kWindow, mapped_len - off);
+      if (off + bsize < mapped_len) {
+        const void* nl = memrchr(mapped + off, '\n', bsize);
+        if (nl) {
+          bsize = (size_t)((const char*)nl - (mapped + off)) + 1;
+        } else {
+          const void* nl2 = memchr(mapped + off + bsize, '\n', mapped_len - off - bsize);
+          bsize = nl2 ? (size_t)((const char*)nl2 - (mapped + off)) + 1 : mapped_len - off;
+        }
+      }
+      parse_block(mapped + off, bsize);
+      off += bsize;
+    }
+  } else {
+    string cur, next, carry, spill;
+    // (FERROMIC_INGEST_BLOCK / FERROMIC_INGEST_HEAD shrink the two sizes so that tests cross block borders on small files)
+    const size_t kBlock = getenv("FERROMIC_INGEST_BLOCK") ? std::max<size_t>(16, (size_t)atoll(getenv("FERROMIC_INGEST_BLOCK"))) : ((size_t)64 << 20);
+    const size_t kHead = getenv("FERROMIC_INGEST_HEAD") ? (size_t)atoll(getenv("FERROMIC_INGEST_HEAD")) : ((size_t)4 << 20);  // room in front of every block for the unfinished line of the previous one
+    bool eof = false;
+    // the next block is read (and inflated) by a helper thread while this one is parsed; the two buffers are allocated
+    // once and a block is never copied: the carried-over partial line is written into the headroom in front of it
+    auto fetch = [&r, kBlock, kHead](string* dst) -> size_t { if (dst->size() != kHead + kBlock) dst->resize(kHead + kBlock); return r.read(&(*dst)[kHead], kBlock); };
+    size_t next_got = fetch(&next);
+    while (!eof) {
+      cur.swap(next);
+      const size_t got = next_got;
+      if (got < kBlock) eof = true;
+      const char* bdata;
+      size_t bsize;
+      if (carry.size() <= kHead) {
+        memcpy(&cur[kHead - carry.size()], carry.data(), carry.size());
+        bdata = cur.data() + (kHead - carry.size());
+        bsize = carry.size() + got;
+      } else {  // a line longer than the headroom: the slow way, once
+        spill.assign(carry);
+        spill.append(cur.data() + kHead, got);
+        bdata = spill.data();
+        bsize = spill.size();
+      }
+      std::thread reader;
+      if (!eof) reader = std::thread([&] { next_got = fetch(&next); });
+      struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) { StageTimer w("    ingest:wait_for_reader"); t.join(); } } } joiner{reader};
+      size_t usable = bsize;
+      if (!eof) {
+        const void* nlp = memrchr(bdata, '\n', bsize);
+        if (!nlp) { carry.assign(bdata, bsize); continue; }
+        usable = (size_t)((const char*)nlp - bdata) + 1;
+        carry.assign(bdata + usable, bsize - usable);
+      } else {
+        carry.clear();
+      }
+      if (usable) parse_block(bdata, usable);
     }
   }
   StageTimer tsort("    ingest:sort_and_store");

@@ -38,17 +38,21 @@ def oracle_digests(kw, min_gq=30, mask_file=None, allow_file=None, exclude=()):
     return out
 
 
+@pytest.mark.parametrize("route", ["mmap", "stream", "gzip"])
 @pytest.mark.parametrize("block,head", [("1000", "4096"), ("333", "40"), ("64", "0"), ("5000", "100")])
-def test_ingest_across_block_borders(tmp_path, block, head):
-    """The body is read in blocks; the unfinished line of a block is carried into the headroom in front of the next one
-    (or, when it is longer than the headroom, through a spill buffer).  Tiny blocks put every line across a border."""
+def test_ingest_across_block_borders(tmp_path, block, head, route):
+    """A plain-text body is parsed in line-aligned windows of a mapping of the file; a compressed one (and a plain one
+    under FERROMIC_NO_MMAP) is streamed in blocks whose unfinished last line is carried into the headroom in front of the
+    next block (or, when it is longer than the headroom, through a spill buffer).  Tiny blocks put every line across a
+    border on every route."""
     if not os.path.exists(BIN):
         pytest.skip("run_vcf binary not built")
-    kw, names = make_cohort(tmp_path, seed=93, n_samples=11, gz=False)
+    kw, names = make_cohort(tmp_path, seed=93, n_samples=11, gz=route == "gzip")
     cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--config_file", kw["config_file"],
            "--output_file", str(tmp_path / "out" / "o.csv"), "--ingest_only"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_THREADS="3", FERROMIC_INGEST_BLOCK=block, FERROMIC_INGEST_HEAD=head))
+                         env=dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_THREADS="3", FERROMIC_INGEST_BLOCK=block, FERROMIC_INGEST_HEAD=head,
+                                  **({"FERROMIC_NO_MMAP": "1"} if route == "stream" else {})))
     assert res.returncode == 0, res.stderr[-2000:]
     got = {m.group(1): (int(m.group(2)), int(m.group(3)), m.group(4))
            for m in re.finditer(r"\[INGEST\] chr (\S+): (\d+) variants x (\d+) samples digest ([0-9a-f]{16})", res.stdout)}
