@@ -878,6 +878,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
     a.unroll = best_u;
     for (int k = 0; k < nus; ++k) if (env_punroll == us[k]) a.unroll = env_punroll;
     a.nvec_pad = (uint32_t)round_up(m->pvec, (size_t)lpr * a.unroll);
+    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH");
     smem = (size_t)P * a.nvec_pad * 16;
     mask_mode = kMaskPacked;
     if (smem > kSweepLdsLimit)

@@ -72,6 +72,7 @@ struct SweepArgs {
   uint32_t group_size[8]; // mask popcounts
   uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
   int unroll;             // vectors per lane issued back to back (4 or 8)
+  int single_trip;        // packed cores: nvec_pad == lanes-per-row * unroll, i.e. one batch of loads covers a row
   int n_groups;           // caller's group count (<= kernel P; padded groups are never reported)
   size_t row_begin;
   size_t row_count;
@@ -539,6 +540,53 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
   if (NPL == 2) allele_or = group_or<LPR>(allele_or);
 }
 
+// The LPR rows a group owns in one tile, for the commonest packed shape: biallelic, nothing missing, and a row that one
+// batch of U loads per lane covers (C4: 40 vectors, 16 lanes x 3).  Then (1) a lane's mask vectors are the same for every
+// row, so they are read from LDS once per tile into registers, and (2) the loads of row s + 1 are issued before the
+// popcounts and the reduction of row s, so a wave always has two rows of loads in flight instead of one.
+template <int P, int U, int LPR>
+__device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, const MatrixView& mv, const uint4* __restrict__ lds_mask,
+                                                          uint32_t nvec_pad, size_t tile_row0, int grp, int gl, uint32_t (&alt_mine)[P]) {
+  const uint32_t last = mv.nvec - 1;
+  uint4 m[P][U];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int u = 0; u < U; ++u) m[p][u] = lds_mask[(uint32_t)p * nvec_pad + (uint32_t)gl + LPR * u];  // zero beyond the row
+  auto load_row = [&](uint4 (&dst)[U], int s) {
+    const size_t rel = tile_row0 + (size_t)grp * LPR + s;
+    const size_t row = A.row_begin + (rel < A.row_count ? rel : A.row_count - 1);  // rows past the end re-read the last one
+    const uint8_t* rp = mv.data + row * mv.pitch;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t v = (uint32_t)gl + LPR * u;
+      dst[u] = load_stream(rp + (size_t)(v < last ? v : last) * 16);
+    }
+  };
+  auto count_row = [&](const uint4 (&x)[U], int s) {
+    uint32_t alt[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      alt[p] = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) alt[p] = popc128(and128(x[u], m[p][u]), alt[p]);
+      alt[p] = group_sum<LPR>(alt[p]);
+    }
+    if (gl == s) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) alt_mine[p] = alt[p];
+    }
+  };
+  uint4 a[U], b[U];
+  load_row(a, 0);
+  for (int s = 0; s < LPR; s += 2) {  // LPR is even
+    load_row(b, s + 1);
+    count_row(a, s);
+    if (s + 2 < LPR) load_row(a, s + 2);
+    count_row(b, s + 1);
+  }
+}
+
 // General row, single pass for alleles 0..3 by bit planes: with s0 = #(bit0 set), s1 = #(bit1 set),
 // s01 = #(both) over the called members, and every called allele < 4 (checked through allele_or),
 //   c3 = s01, c1 = s0 - s01, c2 = s1 - s01, c0 = n - c1 - c2 - c3.
@@ -919,7 +967,30 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       for (int k = 0; k < NW; ++k) { wc.a[k] = 0.0; wc.b[k] = 0.0; }
     }
 
-    for (int s = 0; s < LPR; ++s) {
+    bool rows_done = false;
+    if constexpr (MM == kMaskPacked && !GENERAL && !MISSING) {
+      if (A.single_trip) {
+        const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
+        uint32_t alt_mine[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) alt_mine[p] = 0;
+        if constexpr (LPR != 16) {
+          if (A.unroll == 5) tile_rows_packed_prefetch<P, 5, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+          else if (A.unroll == 3) tile_rows_packed_prefetch<P, 3, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+          else if (A.unroll == 2) tile_rows_packed_prefetch<P, 2, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+          else tile_rows_packed_prefetch<P, 1, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+        } else {
+          if (A.unroll == 4) tile_rows_packed_prefetch<P, 4, 16>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+          else if (A.unroll == 3) tile_rows_packed_prefetch<P, 3, 16>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+          else tile_rows_packed_prefetch<P, 2, 16>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) { mine.alt[p] = alt_mine[p]; mine.n[p] = A.group_size[p]; }
+        mine.n_all = mv.columns;
+        rows_done = true;
+      }
+    }
+    for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;
       const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);
