@@ -57,3 +57,20 @@ def test_rccl_collective_path_with_one_rank():
     for a, b in zip(u8["results"]["pi_sum"], plain["results"]["pi_sum"]):
         assert a == pytest.approx(b, rel=1e-12)
     assert u8["roofline"]["algorithmic_bytes_per_site"] == 1056 and u8["dtype"] == "u8"
+
+
+def test_bench_line_contract():
+    """The one JSON line the driver parses: every field of the contract, with the roofline and cpu_baseline objects."""
+    d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--sites", "200000", "--haplotypes", "400", "--cpu-sample-sites", "50000"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "sites/s" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(200000 * 3 / (d["ms_per_step"] * 3 / 1e3), rel=1e-6)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert "traffic" in r and r["algorithmic_bytes_per_site"] == 50 + 56
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "sites/s" and "sample" in c
+    assert c["parity_vs_gpu"]["alt_counts_bit_exact"] is True and c["parity_vs_gpu"]["per_site_f64_max_rel_err"] <= 1e-9
