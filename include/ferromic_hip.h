@@ -134,9 +134,10 @@ int fmh_matrix_generate(fmh_matrix* m, uint64_t seed, uint64_t first_global_site
  * DenseMembership::build (stats.rs:1252-1284) / HapMembership::build (1212-1238) reduce a
  * (sample, side) list to: duplicates collapse, out-of-range samples are dropped, the Right side is
  * dropped when ploidy <= 1.  Populations may overlap.  1 <= P <= FMH_MAX_GROUPS.
- * Row width: the masks of one sweep sit in LDS as bytes while P_padded * round_up(H, 1024) <= 150 KiB (P_padded = 1, 2,
- * 4, 8), as bits up to 8x that width, and in global memory beyond (one or two groups at a time) — fmh_population_summaries
- * and fmh_wc_sweep re-batch their groups by themselves, fmh_hudson_sweep / fmh_diversity_sites need no batching.
+ * Row width: a packed matrix is swept with bit masks in LDS (P_padded * H / 8 bytes <= 150 KiB, P_padded = 1, 2, 4, 8);
+ * on u8 rows the masks sit in LDS as bytes while P_padded * round_up(H, 1024) <= 150 KiB, as bits up to 8x that width,
+ * and in global memory beyond (one or two groups at a time) — fmh_population_summaries and fmh_wc_sweep re-batch their
+ * groups by themselves, fmh_hudson_sweep / fmh_diversity_sites need no batching.
  */
 int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_column_mask, int n_groups, fmh_groups** out);
 int fmh_groups_destroy(fmh_groups* g);
