@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py — variant-sites/sec of the fused "pi + Hudson FST" sweep (BASELINE.json metric).
 
-A step = one pass of the hot path (fmh_hudson_sweep: per-site allele counts for both populations,
-per-site pi1/pi2/Dxy/num/den, regional accumulators back on the host) over the synthetic cohort
-already resident in HBM.  Default workload = BASELINE config C4 on ONE GPU: 10 M sites x 5 000
-haplotypes, 2 populations (50 GB of uint8 genotypes).  With --gpus N every rank owns its own
-genomic slab of the same size (region sharding, weak scaling) and the regional accumulators are
-combined with one RCCL all-reduce per step (torch.distributed, backend nccl == RCCL).
+A step = one pass of the hot path (per-site allele counts for both populations, per-site pi1/pi2/Dxy/num/den tracks,
+regional accumulators summed over all ranks and back on the host) over the synthetic cohort already resident in HBM.
+Workload = BASELINE config C4: 10 M sites x 5 000 haplotypes, 2 populations.
+
+  N = 1   the whole cohort on one GPU, fmh_hudson_sweep.
+  N > 1   region sharding: rank r owns one contiguous slab and only that slab; the regional accumulators are
+          summed by RCCL inside libferromic_hip.so (fmh_hudson_sweep_sharded_begin/_end: finalise on the device, ncclAllReduce
+          on the communicator's stream, pipelined one step deep so the reduce of step k overlaps the sweep of step k + 1).
+          --scaling strong (default): the 10 M sites are SPLIT over the ranks (the metric's "10M sites, 1 -> 8 GPUs");
+          --scaling weak: every rank owns --sites sites of an N x larger cohort.  The other mode is measured in the same run
+          and reported under "secondary".
 
 Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                  --master-port P bench.py --gpus N --steps K --warmup W
+or simply `python bench.py --gpus N`: the script then starts that launcher itself, before touching the GPU.
 Prints ONE JSON line on rank 0.
 """
 
@@ -17,8 +23,11 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 W_OUT_HUDSON = 56      # bytes of per-site results written: 2*(4+4) counts + 5*8 (pi1, pi2, dxy, num, den); SURVEY.md 8(d)
 
 
-def synthetic_thresholds(sites: int, first_site: int, total_sites: int, seed: int, sigma: float = 0.05) -> np.ndarray:
+def synthetic_thresholds(sites: int, first_site: int, seed: int, sigma: float = 0.05) -> np.ndarray:
     """Per-site population frequencies following the reference's benchmark recipe
     (src/pybenches/test_population_statistics_benchmarks.py:113-158): base ~ Beta(0.8, 0.8),
     divergence ~ N(0, sigma), clip [0.001, 0.999]; rows 0 and 1 of the cohort forced informative.
@@ -60,13 +69,41 @@ def synthetic_thresholds(sites: int, first_site: int, total_sites: int, seed: in
     return thr
 
 
-def cpu_baseline(args, thr_full: np.ndarray, poc: np.ndarray, seed: int, gpu_check):
+def usable_cores() -> dict:
+    """Host cores this process can actually run on: the affinity mask, further capped by the cgroup CPU quota
+    (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  os.cpu_count() is the machine, not the share."""
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = visible
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = int(fq.read()), int(fp.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = affinity
+    if quota is not None:
+        usable = max(1, min(affinity, int(quota + 0.5)))
+    return {"cores_visible": visible, "cores_affinity": affinity, "cgroup_cpu_quota": quota, "cores_usable": usable}
+
+
+def cpu_baseline(args, sample: int, thr_full: np.ndarray, poc: np.ndarray, seed: int, gpu_check):
     """The reference algorithm restated in C (oracle/dense_oracle.c), site ranges over host threads,
     on a bounded sample of the same cohort (rows [0, sample) are bit-identical to the GPU's)."""
     from oracle import dense as D
 
-    cores = os.cpu_count() or 1
-    sample = min(args.cpu_sample_sites, args.sites)
+    host = usable_cores()
+    cores = args.cpu_threads if args.cpu_threads > 0 else host["cores_usable"]
     H = args.haplotypes
     data, _ = D.generate(sample, H, seed, 0, np.ascontiguousarray(thr_full[:, :sample]), poc, 0, cores)
     off1 = np.nonzero(poc == 0)[0].astype(np.uint64)
@@ -81,7 +118,10 @@ def cpu_baseline(args, thr_full: np.ndarray, poc: np.ndarray, seed: int, gpu_che
     return {
         "value": sample / best,
         "unit": "sites/s",
-        "cores": cores,
+        "cores": cores,  # threads the restatement ran on = the cores this process may use (affinity mask capped by the cgroup quota)
+        "cores_visible": host["cores_visible"],
+        "cores_usable": host["cores_usable"],
+        "cgroup_cpu_quota": host["cgroup_cpu_quota"],
         "kind": "port",
         "sample": f"first {sample} sites x {H} haplotypes of the same cohort, best of 3 passes "
                   f"({best:.3f} s each), C restatement of stats.rs:1367-1470 + 1554-1623 + 3179-3278",
@@ -89,38 +129,87 @@ def cpu_baseline(args, thr_full: np.ndarray, poc: np.ndarray, seed: int, gpu_che
     }
 
 
-def main() -> int:
+def kernel_source_sha() -> str:
+    """Identity of the sweep kernel sources: profiles/pmc_traffic.json records the one its counters were collected on."""
+    h = hashlib.sha256()
+    for name in ("sweep_kernels.hpp", "sweep_launch.inc"):
+        with open(os.path.join(ROOT, "ferromic_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(sites: int, haplotypes: int, layout: str):
+    """HBM bytes per launch from the committed rocprofv3 --pmc collection (never measured in this run)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "none: profiles/pmc_traffic.json is absent"
+    try:
+        rec = json.load(open(tpath)).get(f"{sites}x{haplotypes}:{layout}")
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None, "none: no recorded collection for this shape and layout"
+    sha = rec.get("kernel_source_sha")
+    where = f"static profiles/pmc_traffic.json ({rec.get('source', '?')}); separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run"
+    if sha != kernel_source_sha():
+        return None, f"stale: collected on kernel sources {sha}, this build is {kernel_source_sha()} ({where})"
+    return rec["hbm_bytes_per_launch"], where + f", kernel sources {sha}"
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sites", type=int, default=10_000_000, help="sites per GPU")
+    ap.add_argument("--sites", type=int, default=10_000_000,
+                    help="sites of the cohort: the WHOLE cohort with --scaling strong (split over the ranks), per GPU with --scaling weak")
     ap.add_argument("--haplotypes", type=int, default=5000)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the measurement of the other scaling mode")
     ap.add_argument("--cpu-sample-sites", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = the cores this process may use)")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="who sums the accumulators over the ranks: libferromic_hip.so's own RCCL communicator (the product path) or "
+                         "torch.distributed (with --backend gloo: the rehearsal of N > 1 on a one-GPU box)")
+    ap.add_argument("--backend", default="gloo",
+                    help="torch.distributed backend of the control plane (barriers, id exchange, max over ranks) and of --transport torch")
     ap.add_argument("--layout", choices=["packed", "bytes"], default="packed",
                     help="resident layout of the cohort: bit-packed planes (what fmh_matrix_create keeps for alleles 0..3) or the u8 rows")
     ap.add_argument("--u8-reference-steps", type=int, default=5,
-                    help="with --layout packed: before the u8 rows are released, time this many sweeps over them (the layout "
+                    help="N = 1 with --layout packed: before the u8 rows are released, time this many sweeps over them (the layout "
                          "north_star names) and report their HBM fraction next to the headline; 0 skips it")
     ap.add_argument("--force-collective", action="store_true",
-                    help="run the all-reduce path even with one rank (measures the software cost of the collective step on a one-GPU box)")
+                    help="run the sharded path (communicator, device-side reduce, pipelining) even with one rank: measures its "
+                         "software cost on a one-GPU box")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
-                    help="all ranks share cuda:0 (with --backend gloo): exercises the sharded code path on a one-GPU box")
-    args = ap.parse_args()
+                    help="all ranks share cuda:0 (needs --transport torch --backend gloo): exercises the sharded code path on a one-GPU box")
+    return ap.parse_args()
+
+
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: become the launcher (nothing has touched the GPU yet) and hand the job to N ranks
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        return subprocess.run(cmd, env=env).returncode
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.rehearse_on_one_device:
         local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}",
-                  file=sys.stderr)
-            return 2
-        args.gpus = world
+        if args.transport != "torch":
+            raise SystemExit("--rehearse-on-one-device needs --transport torch (RCCL cannot place two ranks on one GPU)")
+    args.gpus = world
 
     import torch
 
@@ -129,12 +218,12 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or args.force_collective:
+    if world > 1 or (args.force_collective and args.transport == "torch"):
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
@@ -142,122 +231,159 @@ def main() -> int:
         else:
             dist.init_process_group(backend=args.backend)
 
-    from ferromic_amd import _abi, device
+    from ferromic_amd import _abi, device, sharding
 
     lib = _abi.load()
-    S, H = args.sites, args.haplotypes
+    H = args.haplotypes
     if H % 2:
         raise SystemExit("haplotypes must be even (diploid samples)")
     N = H // 2
-    seed = (S * world) + N  # reference recipe: seed = variants + samples
-    first_site = rank * S
     poc = np.repeat((np.arange(N) >= N // 2).astype(np.uint8), 2)  # contiguous equal populations
-
-    thr = synthetic_thresholds(S, first_site, S * world, seed)
-    dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=False, max_allele=1, device=local_rank)
-    t0 = time.perf_counter()
-    dm.generate(seed, first_site, thr, poc, 0)
-    gen_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    if args.layout == "packed":
-        dm.pack(release_bytes=False)  # the resident image fmh_matrix_create keeps: one bit per haplotype
-    pack_s = time.perf_counter() - t0
     masks = np.stack([(poc == 0), (poc == 1)]).astype(np.uint8)
-    groups = device.Groups(dm, masks)
+    sharded = world > 1 or args.force_collective
+    comm = None
+    if sharded and args.transport == "rccl":
+        comm = sharding.Comm.from_torch_distributed(dist, local_rank) if world > 1 else sharding.Comm.single(local_rank)
 
-    # per-site tracks stay in HBM (56 B/site): counts + pi1, pi2, dxy, num, den
-    bufs = {n: device.DeviceBuffer(local_rank, 8 * S) for n in ("dxy", "pi1", "pi2", "num", "den")}
-    bufs["alt"] = device.DeviceBuffer(local_rank, 4 * 2 * S)
-    bufs["called"] = device.DeviceBuffer(local_rank, 4 * 2 * S)
-    sites = _abi.HudsonSites(None, bufs["dxy"].ptr, bufs["pi1"].ptr, bufs["pi2"].ptr, bufs["num"].ptr,
-                             bufs["den"].ptr, bufs["alt"].ptr, bufs["called"].ptr)
-    from ferromic_amd import sharding
-
-    state = {"totals": _abi.HudsonTotals()}
-    # N > 1: the 20 regional accumulators of a step are summed over the ranks by one RCCL all-reduce that overlaps the
-    # next step's sweep (its own stream); fence() collects the last one, so every step's reduce ends inside the timed region
-    pipeline = sharding.HudsonTotalsPipeline(dist, "cuda") if dist is not None else None
-
-    def step():
-        local = _abi.HudsonTotals()
-        _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
-        if pipeline is not None:
-            pipeline.submit(local)
-        else:
-            state["totals"] = local
-
-    def fence():
-        if pipeline is not None:
-            merged = pipeline.flush()
-            if merged is not None:
-                state["totals"] = merged
-        if dist is not None:
+    def barrier():
+        if dist is not None and world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        _abi.check(lib.fmh_stream_synchronize(local_rank, None))
 
-    # the same sweep over the u8 rows (one byte per haplotype, the layout the reference and north_star name), timed while the
-    # matrix still holds them: its HBM fraction is reported next to the headline; then the rows are released
-    u8_reference = None
-    if args.layout == "packed":
-        if args.u8_reference_steps > 0:
-            os.environ["FMH_LAYOUT"] = "bytes"  # read per call by the library: sweeps take the u8 kernels while the rows exist
+    def max_over_ranks(x: float) -> float:
+        if dist is None or world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run_mode(scaling: str, primary: bool):
+        """Builds this rank's slab for one scaling mode, times K steps, returns the measurements."""
+        if scaling == "strong":
+            total = args.sites
+            begin, end = sharding.slab_for_rank(total, rank, world)
+        else:
+            total = args.sites * world
+            begin, end = rank * args.sites, (rank + 1) * args.sites
+        S = end - begin
+        seed = total + N  # reference recipe: seed = variants + samples
+        thr = synthetic_thresholds(S, begin, seed)
+        dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=False, max_allele=1, device=local_rank)
+        t0 = time.perf_counter()
+        dm.generate(seed, begin, thr, poc, 0)
+        gen_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if args.layout == "packed":
+            dm.pack(release_bytes=False)  # the resident image fmh_matrix_create keeps: one bit per haplotype
+        pack_s = time.perf_counter() - t0
+        groups = device.Groups(dm, masks)
+        # per-site tracks stay in HBM (56 B/site): counts + pi1, pi2, dxy, num, den
+        bufs = {n: device.DeviceBuffer(local_rank, 8 * max(S, 1)) for n in ("dxy", "pi1", "pi2", "num", "den")}
+        bufs["alt"] = device.DeviceBuffer(local_rank, 4 * 2 * max(S, 1))
+        bufs["called"] = device.DeviceBuffer(local_rank, 4 * 2 * max(S, 1))
+        sites = _abi.HudsonSites(None, bufs["dxy"].ptr, bufs["pi1"].ptr, bufs["pi2"].ptr, bufs["num"].ptr,
+                                 bufs["den"].ptr, bufs["alt"].ptr, bufs["called"].ptr)
+        state = {"totals": _abi.HudsonTotals(), "in_flight": 0}
+        pipeline = sharding.HudsonTotalsPipeline(dist, "cuda" if args.backend == "nccl" else "cpu") if sharded and comm is None else None
+
+        def sweep_local():
             local = _abi.HudsonTotals()
             _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
-            lib.fmh_timing_enable(1)
-            lib.fmh_timing_reset()
-            for _ in range(args.u8_reference_steps):
-                _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(local), None))
-            ms8, n8 = C.c_double(), C.c_uint64()
-            lib.fmh_timing_read(C.byref(ms8), C.byref(n8))
-            lib.fmh_timing_enable(0)
-            del os.environ["FMH_LAYOUT"]
-            k8 = ms8.value / 1e3 / max(n8.value, 1)
-            u8_reference = {"kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, u8>", "kernel_ms_avg": k8 * 1e3,
-                            "algorithmic_bytes_per_site": H + W_OUT_HUDSON, "achieved": (H + W_OUT_HUDSON) * S / k8 / 1e9,
-                            "frac": (H + W_OUT_HUDSON) * S / k8 / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "sites_per_s_kernel": S / k8,
-                            "steps": args.u8_reference_steps,
-                            "hudson_fst": local.numerator_sum / local.denominator_sum if local.denominator_sum > 1e-12 else None}
-        dm.pack(release_bytes=True)  # from here on the matrix is what fmh_matrix_create leaves: planes only
+            return local
 
-    for _ in range(args.warmup):
-        step()
-    lib.fmh_timing_enable(1)
-    lib.fmh_timing_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = C.c_double(), C.c_uint64()
-    lib.fmh_timing_read(C.byref(kernel_ms), C.byref(launches))
-    lib.fmh_timing_enable(0)
+        def step():
+            if comm is not None:
+                # enqueue this step's sweep + device-side reduce, then collect the previous step's region-wide totals
+                _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), None))
+                state["in_flight"] += 1
+                if state["in_flight"] > 1:
+                    _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(state["totals"])))
+                    state["in_flight"] -= 1
+            elif pipeline is not None:
+                pipeline.submit(sweep_local())
+            else:
+                state["totals"] = sweep_local()
 
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        def fence():
+            while comm is not None and state["in_flight"] > 0:
+                _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(state["totals"])))
+                state["in_flight"] -= 1
+            if pipeline is not None:
+                merged = pipeline.flush()
+                if merged is not None:
+                    state["totals"] = merged
+            barrier()
+            torch.cuda.synchronize()
+            _abi.check(lib.fmh_stream_synchronize(local_rank, None))
 
-    totals = state["totals"]
-    total_sites = S * world
-    value = total_sites * args.steps / elapsed
+        # the same sweep over the u8 rows (one byte per haplotype, the layout the reference and north_star name), timed while the
+        # matrix still holds them: its HBM fraction is reported next to the headline; then the rows are released
+        u8_reference = None
+        if args.layout == "packed":
+            if primary and world == 1 and args.u8_reference_steps > 0 and S > 0:
+                os.environ["FMH_LAYOUT"] = "bytes"  # read per call by the library: sweeps take the u8 kernels while the rows exist
+                local = sweep_local()
+                lib.fmh_timing_enable(1)
+                lib.fmh_timing_reset()
+                for _ in range(args.u8_reference_steps):
+                    local = sweep_local()
+                ms8, n8 = C.c_double(), C.c_uint64()
+                lib.fmh_timing_read(C.byref(ms8), C.byref(n8))
+                lib.fmh_timing_enable(0)
+                del os.environ["FMH_LAYOUT"]
+                k8 = ms8.value / 1e3 / max(n8.value, 1)
+                u8_reference = {"kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, u8>", "kernel_ms_avg": k8 * 1e3,
+                                "algorithmic_bytes_per_site": H + W_OUT_HUDSON, "achieved": (H + W_OUT_HUDSON) * S / k8 / 1e9,
+                                "frac": (H + W_OUT_HUDSON) * S / k8 / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "sites_per_s_kernel": S / k8,
+                                "steps": args.u8_reference_steps,
+                                "hudson_fst": local.numerator_sum / local.denominator_sum if local.denominator_sum > 1e-12 else None}
+            dm.pack(release_bytes=True)  # from here on the matrix is what fmh_matrix_create leaves: planes only
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        lib.fmh_timing_enable(1)
+        lib.fmh_timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        kernel_ms, launches = C.c_double(), C.c_uint64()
+        lib.fmh_timing_read(C.byref(kernel_ms), C.byref(launches))
+        lib.fmh_timing_enable(0)
+        elapsed = max_over_ranks(elapsed)
+        avg_kernel_s = (kernel_ms.value / 1e3) / max(launches.value, 1)
+        return {"scaling": scaling, "total_sites": total, "slab": (begin, end), "S": S, "seed": seed, "gen_s": gen_s, "pack_s": pack_s,
+                "elapsed": elapsed, "avg_kernel_s": avg_kernel_s, "totals": state["totals"], "u8_reference": u8_reference,
+                "bufs": bufs, "thr": thr, "dm": dm, "groups": groups}
+
+    first = run_mode(args.scaling, True)
+    totals = first["totals"]
+    S = first["S"]
+    value = first["total_sites"] * args.steps / first["elapsed"]
+    secondary = None
+    if world > 1 and not args.no_secondary:
+        # release the primary cohort, then the other mode on the same ranks
+        keep = {k: first[k] for k in ("scaling", "total_sites", "elapsed", "avg_kernel_s", "S", "seed", "gen_s", "pack_s", "slab")}
+        first.clear()
+        first.update(keep)
+        other = run_mode("weak" if args.scaling == "strong" else "strong", False)
+        ot = other["totals"]
+        secondary = {"scaling": other["scaling"], "value": other["total_sites"] * args.steps / other["elapsed"], "unit": "sites/s",
+                     "ms_per_step": other["elapsed"] / args.steps * 1e3, "total_sites": other["total_sites"], "sites_per_gpu": other["S"],
+                     "kernel_ms_avg": other["avg_kernel_s"] * 1e3,
+                     "hudson_fst": ot.numerator_sum / ot.denominator_sum if ot.denominator_sum > 1e-12 else None}
+        other.clear()
+
     # algorithmic bytes per site of the kernel that runs: the genotype row as it is resident in HBM (one bit per
     # haplotype when packed, one byte in the u8 layout) + the 56 B of per-site tracks it writes (DESIGN.md section 6)
     packed = args.layout == "packed"
     b_site_u8 = H + W_OUT_HUDSON
     b_site = ((H + 7) // 8 if packed else H) + W_OUT_HUDSON
-    avg_kernel_s = (kernel_ms.value / 1e3) / max(launches.value, 1)
-    achieved = b_site * S / avg_kernel_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get(f"{S}x{H}:{args.layout}")
-            if rec:
-                traffic = rec["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    avg_kernel_s = first["avg_kernel_s"]
+    achieved = b_site * S / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    traffic, traffic_source = recorded_traffic(S, H, args.layout)
+    reduce_name = {"rccl": "RCCL (ncclAllReduce issued by libferromic_hip.so on its own stream)", "torch": f"torch.distributed ({args.backend})"}[args.transport]
 
     result = {
         "metric": "variant-sites/sec (pi + Hudson FST)",
@@ -266,23 +392,26 @@ def main() -> int:
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": first["elapsed"] / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": first["scaling"],
         "vs_baseline": None,
         "dtype": "u1" if packed else "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"C4 fused per-site pi + Hudson FST sweep: {S} sites x {H} haplotypes per GPU, 2 populations, "
-                        "biallelic, no missing data, matrix resident in HBM "
+            "workload": f"C4 fused per-site pi + Hudson FST sweep: {first['total_sites']} sites x {H} haplotypes"
+                        + (f", {S} sites on each of {world} GPUs" if world > 1 else "")
+                        + ", 2 populations, biallelic, no missing data, matrix resident in HBM "
                         + ("bit-packed (1 bit per haplotype, the layout fmh_matrix_create keeps)" if packed else "as u8 rows"),
+            "total_sites": first["total_sites"],
             "sites_per_gpu": S,
             "haplotypes": H,
             "populations": 2,
-            "parallelism": f"region-sharded x{world} (one slab per GPU, one {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of 20 accumulators per step, overlapped with the next step's sweep)",
-            "seed": seed,
-            "generate_s": gen_s,
-            "pack_s": pack_s,
+            "parallelism": (f"region-sharded x{world}: one contiguous slab per GPU, per-site tracks stay on the owning GPU, the 128 regional "
+                            f"accumulators summed by {reduce_name}, pipelined one step deep") if sharded else "one GPU, no collective",
+            "seed": first["seed"],
+            "generate_s": first["gen_s"],
+            "pack_s": first["pack_s"],
             "layout": args.layout,
         },
         "roofline": {
@@ -292,15 +421,17 @@ def main() -> int:
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, " + ("packed>" if packed else "u8>"),
             "kernel_ms_avg": avg_kernel_s * 1e3,
+            "kernel_sites_per_launch": S,
             "algorithmic_bytes_per_site": b_site,
             # the same sites/s priced at SURVEY 8(d)'s u8-layout figure (H + 56 B/site): what a sweep over u8 rows would
             # have to move per second to keep up - above the HBM peak when the packed layout does its job
             "u8_layout_bytes_per_site": b_site_u8,
-            "u8_layout_equivalent_GBs": b_site_u8 * S / avg_kernel_s / 1e9,
+            "u8_layout_equivalent_GBs": b_site_u8 * S / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0,
             # measured, same cohort, same process: the sweep over u8 rows (one byte per haplotype) before they were released
-            "u8_layout_measured": u8_reference,
+            "u8_layout_measured": first.get("u8_reference"),
         },
         "results": {
             "hudson_fst": totals.numerator_sum / totals.denominator_sum if totals.denominator_sum > 1e-12 else None,
@@ -308,8 +439,12 @@ def main() -> int:
             "pi_sum": [totals.pop[0].pi_sum, totals.pop[1].pi_sum],
         },
     }
+    if secondary is not None:
+        result["secondary"] = secondary
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        bufs = first["bufs"]
+
         def gpu_check(sample, cpu):
             got_alt = bufs["alt"].to_numpy(np.uint32, 2 * S).reshape(2, S)[:, :sample]
             ok_int = bool(np.array_equal(got_alt, cpu.alt))
@@ -323,12 +458,14 @@ def main() -> int:
                 worst = max(worst, float(rel) if same_nan else float("inf"))
             return {"alt_counts_bit_exact": ok_int, "per_site_f64_max_rel_err": worst}
 
-        result["cpu_baseline"] = cpu_baseline(args, thr, poc, seed, gpu_check)
+        result["cpu_baseline"] = cpu_baseline(args, min(args.cpu_sample_sites, S), first["thr"], poc, first["seed"], gpu_check)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     return 0
 

@@ -36,9 +36,11 @@ from ._core import (  # noqa: E402,F401
     watterson_theta,
     wc_fst,
     wc_fst_components,
+    get_device,
+    set_device,
 )
 
-__version__ = "0.1.0"
+__version__ = "0.1.4"  # the reference crate's version (Cargo.toml:3), which lib.rs:2229 exports
 # lib.rs:2229-2239 build attributes; the native layer is HIP/C++, not Rust, but tooling reads these
 __rust_profile__ = "release"
 __rust_opt_level__ = "3"

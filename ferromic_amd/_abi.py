@@ -28,6 +28,7 @@ MAX_GROUPS_MANY = 256
 MAX_PAIRS = 28
 HUDSON_PACK_F64 = 10
 HUDSON_PACK_U64 = 10
+COMM_ID_BYTES = 128
 
 WC_STATES = (
     "calculable",
@@ -131,6 +132,21 @@ SYMBOLS = {
     "fmh_pairwise_differences": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "fmh_hudson_totals_pack": (_i, [_P(HudsonTotals), _P(_d), _P(_u64)]),
     "fmh_hudson_totals_unpack": (_i, [_P(HudsonTotals), _P(_d), _P(_u64)]),
+    "fmh_pop_totals_pack": (_i, [_P(PopTotals), _i, _P(_d), _P(_u64)]),
+    "fmh_pop_totals_unpack": (_i, [_P(PopTotals), _i, _P(_d), _P(_u64)]),
+    "fmh_wc_totals_pack": (_i, [_P(WcTotals), _i, _P(_d), _P(_u64)]),
+    "fmh_wc_totals_unpack": (_i, [_P(WcTotals), _i, _P(_d), _P(_u64)]),
+    "fmh_comm_get_unique_id": (_i, [_vp]),
+    "fmh_comm_init_rank": (_i, [_vp, _i, _i, _i, _P(_vp)]),
+    "fmh_comm_init_all": (_i, [_P(_i), _i, _P(_vp)]),
+    "fmh_comm_destroy": (_i, [_vp]),
+    "fmh_comm_info": (_i, [_vp, _P(_i), _P(_i), _P(_i), _P(_i)]),
+    "fmh_allreduce_totals": (_i, [_vp, _P(_d), _sz, _P(_u64), _sz]),
+    "fmh_allreduce_totals_begin": (_i, [_vp, _P(_d), _sz, _P(_u64), _sz]),
+    "fmh_allreduce_totals_end": (_i, [_vp, _P(_d), _P(_u64)]),
+    "fmh_hudson_sweep_sharded_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _P(HudsonSites), _vp]),
+    "fmh_hudson_sweep_sharded_end": (_i, [_vp, _P(HudsonTotals)]),
+    "fmh_hudson_sweep_sharded": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_timing_enable": (_i, [_i]),
     "fmh_timing_reset": (_i, []),
     "fmh_timing_read": (_i, [_P(_d), _P(_u64)]),

@@ -1,6 +1,7 @@
 // abi.hip — implementation of include/ferromic_hip.h: device memory, layout conversion, kernel
 // dispatch and totals collection.  No CPU compute path exists here: without a GPU every entry
-// point fails with FMH_ERR_NO_DEVICE.
+// point fails with FMH_ERR_NO_DEVICE.  The sweep kernels are instantiated in sweep_*.hip (one object per mask route),
+// the pairwise-differences path lives in pairwise.hip, the RCCL communicator in comm.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -15,19 +16,19 @@
 #include <string>
 #include <vector>
 
-#include "../../include/ferromic_hip.h"
-#include "sweep_kernels.hpp"
-#include "pairwise_kernels.hpp"
+#include "abi_internal.hpp"
+#include "util_kernels.hpp"
 #include "wc_counts_kernels.hpp"
 
 using namespace fmh;
+using namespace fmhi;
 
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char* fmt, ...) {
+int fmhi::fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -36,20 +37,6 @@ static int fail(int code, const char* fmt, ...) {
   g_last_error = buf;
   return code;
 }
-
-#define HIP_TRY(expr)                                                                        \
-  do {                                                                                       \
-    hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess)                                                                    \
-      return fail(_e == hipErrorNoDevice ? FMH_ERR_NO_DEVICE : FMH_ERR_HIP, "%s: %s (%s:%d)", \
-                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                         \
-  } while (0)
-
-#define FMH_TRY(expr)          \
-  do {                         \
-    int _s = (expr);           \
-    if (_s != FMH_OK) return _s; \
-  } while (0)
 
 extern "C" const char* fmh_last_error(void) { return g_last_error.c_str(); }
 extern "C" int fmh_abi_version(void) { return FMH_ABI_VERSION; }
@@ -71,7 +58,7 @@ extern "C" int fmh_device_count(int* h_count) {
   return device_count_checked(h_count);
 }
 
-static int use_device(int device) {
+int fmhi::use_device(int device) {
   int n = 0;
   FMH_TRY(device_count_checked(&n));
   if (device < 0 || device >= n) return fail(FMH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
@@ -104,7 +91,7 @@ static size_t pool_class(size_t bytes) {  // powers of two in quarter steps, >= 
   return p2;
 }
 
-static hipError_t pool_malloc(int device, void** out, size_t bytes) {
+hipError_t fmhi::pool_malloc(int device, void** out, size_t bytes) {
   *out = nullptr;
   if (device < 0 || device >= 64 || bytes > kPoolMaxBlock) return hipMalloc(out, bytes ? bytes : 16);
   DevicePool& pool = g_pool[device];
@@ -136,7 +123,7 @@ static hipError_t pool_malloc(int device, void** out, size_t bytes) {
   return e;
 }
 
-static void pool_free(int device, void* p) {
+void fmhi::pool_free(int device, void* p) {
   if (!p) return;
   if (device >= 0 && device < 64) {
     DevicePool& pool = g_pool[device];
@@ -151,7 +138,7 @@ static void pool_free(int device, void* p) {
   (void)hipFree(p);
 }
 
-static void pool_trim(int device) {
+void fmhi::pool_trim(int device) {
   if (device < 0 || device >= 64) return;
   std::vector<void*> drop;
   {
@@ -209,38 +196,6 @@ extern "C" int fmh_stream_synchronize(int device, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------
-struct fmh_matrix {
-  int device = 0;
-  uint8_t* data = nullptr;
-  uint8_t* bits = nullptr;  // called bit-rows or null
-  size_t pitch = 0, bits_pitch = 0;
-  size_t variants = 0, samples = 0, ploidy = 0;
-  uint32_t columns = 0, nvec = 0;
-  uint8_t max_allele = 0;
-  bool owns = true;
-  bool has_missing = false;  // a called mask exists (bits and / or pc)
-  // bit-packed image (fmh_matrix_pack): p0 = allele & 1, p1 = allele >> 1 (max_allele 2..3), pc = called bits; plane_pitch
-  // bytes per row, pvec = ceil(columns / 128) 16-byte vectors.  data / bits may have been released (nullptr).
-  uint8_t *p0 = nullptr, *p1 = nullptr, *pc = nullptr;
-  size_t plane_pitch = 0;
-  uint32_t pvec = 0;
-};
-
-static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-
-struct fmh_groups {
-  int device = 0;
-  int n_groups = 0;   // caller's P
-  int padded = 0;     // kernel P (1, 2, 4 or 8)
-  uint8_t* masks = nullptr;  // [padded][mask_pitch], zero beyond the row
-  size_t pitch = 0;
-  size_t mask_pitch = 0;     // pitch rounded up to 2048: covers the kernels' zero-padded mask stride
-  uint16_t* mask_bits = nullptr;  // [padded][mask_pitch / 16]: the same masks as one 16-bit word per 16-byte vector
-  uint32_t columns = 0;
-  uint64_t sizes[FMH_MAX_GROUPS] = {0};
-  std::vector<uint8_t> host_mask;  // [n_groups][columns] as handed in (the wide-matrix W&C route re-batches the groups)
-};
-
 // LDS the sweep needs for P (padded) groups of an `nvec`-vector row, masks as bytes (fast) or as bits (8x the width);
 // the kernels take at most 150 KiB.  sweep_lds_bytes() > limit means "does not fit in LDS in either form".
 static const size_t kSweepLdsLimit = 150 * 1024;
@@ -290,10 +245,6 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
 // ---- bit-packed image -------------------------------------------------------------------------------------------
 // Rows wider than this keep the byte layout: their masks would not fit LDS even as bits for two groups.
 static const uint32_t kPackMaxColumns = 600000;
-static bool layout_bytes_forced() {  // read per call: tests flip it
-  const char* v = getenv("FMH_LAYOUT");
-  return v && strcmp(v, "bytes") == 0;
-}
 static bool packable(uint8_t max_allele, uint32_t columns) { return max_allele <= 3 && columns <= kPackMaxColumns; }
 
 static int alloc_planes(fmh_matrix* m) {
@@ -315,14 +266,15 @@ static void free_planes(fmh_matrix* m) {
   m->p0 = m->p1 = m->pc = nullptr;
 }
 // byte rows (and, when `bits` is given, their called rows) -> planes rows [row0, row0 + rows)
+// `d_overflow` (one zeroed device word, may be null) is set when a called entry carries an allele bit the planes do not store
 static hipError_t pack_rows(fmh_matrix* m, const uint8_t* data, size_t pitch, const uint8_t* bits, size_t bits_pitch, size_t row0, size_t rows,
-                            hipStream_t st) {
+                            hipStream_t st, unsigned int* d_overflow = nullptr) {
   if (rows == 0) return hipSuccess;
   const size_t total = rows * (m->plane_pitch / 4);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
   const size_t off = row0 * m->plane_pitch;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, data, pitch, bits, bits_pitch, rows, m->columns, m->p0 + off,
-                     m->p1 ? m->p1 + off : nullptr, m->pc ? m->pc + off : nullptr, m->plane_pitch);
+                     m->p1 ? m->p1 + off : nullptr, m->pc ? m->pc + off : nullptr, m->plane_pitch, d_overflow);
   return hipGetLastError();
 }
 // planes rows [row0, row0 + rows) -> byte rows of `pitch` bytes
@@ -344,9 +296,19 @@ extern "C" int fmh_matrix_pack(fmh_matrix* m, int release_bytes) {
   FMH_TRY(use_device(m->device));
   if (m->p0 && ((m->max_allele >= 2) != (m->p1 != nullptr))) free_planes(m);  // max_allele changed since the last pack
   if (!m->p0) FMH_TRY(alloc_planes(m));
-  hipError_t e = pack_rows(m, m->data, m->pitch, m->bits, m->bits_pitch, 0, m->variants, 0);
+  unsigned int* d_overflow = nullptr;
+  unsigned int overflow = 0;
+  hipError_t e = pool_malloc(m->device, (void**)&d_overflow, 4);
+  if (e == hipSuccess) e = hipMemset(d_overflow, 0, 4);
+  if (e == hipSuccess) e = pack_rows(m, m->data, m->pitch, m->bits, m->bits_pitch, 0, m->variants, 0, d_overflow);
+  if (e == hipSuccess) e = hipMemcpy(&overflow, d_overflow, 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  pool_free(m->device, d_overflow);
   if (e != hipSuccess) return fail(FMH_ERR_HIP, "packing failed: %s", hipGetErrorString(e));
+  if (overflow) {  // the planes would silently count allele 2 as 0 or allele 5 as 1: refuse, the byte rows stay in use
+    free_planes(m);
+    return fail(FMH_ERR_INVALID, "a called entry holds an allele above max_allele = %u: the packed layout cannot represent it", (unsigned)m->max_allele);
+  }
   if (release_bytes && m->owns) {
     pool_free(m->device, m->data);
     pool_free(m->device, m->bits);
@@ -396,16 +358,24 @@ extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missin
     }
     const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(variants, ((size_t)256 << 20) / m->pitch));
     uint8_t* d_slab = nullptr;
+    unsigned int* d_overflow = nullptr;
+    unsigned int overflow = 0;
     e = pool_malloc(device, (void**)&d_slab, slab_rows * m->pitch);
     if (e == hipSuccess) e = hipMemset(d_slab, 0, slab_rows * m->pitch);  // padding columns stay zero
+    if (e == hipSuccess) e = pool_malloc(device, (void**)&d_overflow, 4);
+    if (e == hipSuccess) e = hipMemset(d_overflow, 0, 4);
     for (size_t r0 = 0; r0 < variants && e == hipSuccess; r0 += slab_rows) {
       const size_t rows = std::min(slab_rows, variants - r0);
       e = hipMemcpy2D(d_slab, m->pitch, h_data + r0 * m->columns, m->columns, m->columns, rows, hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = pack_rows(m, d_slab, m->pitch, nullptr, 0, r0, rows, 0);
+      // the called plane (already built from the missing bitset) tells the packer which entries count for the max_allele check
+      if (e == hipSuccess) e = pack_rows(m, d_slab, m->pitch, m->pc ? m->pc + r0 * m->plane_pitch : nullptr, m->plane_pitch, r0, rows, 0, d_overflow);
       if (e == hipSuccess) e = hipDeviceSynchronize();
     }
+    if (e == hipSuccess) e = hipMemcpy(&overflow, d_overflow, 4, hipMemcpyDeviceToHost);
     pool_free(device, d_slab);
+    pool_free(device, d_overflow);
     if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "matrix upload failed: %s", hipGetErrorString(e)));
+    if (overflow) return bail(fail(FMH_ERR_INVALID, "a called entry holds an allele above max_allele = %u: the packed layout cannot represent it", (unsigned)max_allele));
     *out = m;
     return FMH_OK;
   }
@@ -447,8 +417,10 @@ extern "C" int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_bits, size_t 
   if (!d_data) return fail(FMH_ERR_INVALID, "d_data is NULL");
   if (pitch % 16 != 0 || pitch < cols) return fail(FMH_ERR_INVALID, "pitch %zu must be a multiple of 16 and >= %zu", pitch, cols);
   if (((uintptr_t)d_data) % 16 != 0) return fail(FMH_ERR_INVALID, "d_data must be 16-byte aligned");
-  if (d_bits && (bits_pitch % 2 != 0 || bits_pitch * 8 < round_up(cols, 16)))
-    return fail(FMH_ERR_INVALID, "bits_pitch %zu too small or odd", bits_pitch);
+  // the u8 kernels read a called row as 16-bit words, pack_rows_kernel as 4-byte groups: what the header states is enforced
+  if (d_bits && (bits_pitch % 4 != 0 || bits_pitch * 8 < round_up(cols, 16)))
+    return fail(FMH_ERR_INVALID, "bits_pitch %zu must be a multiple of 4 and hold %zu bits", bits_pitch, round_up(cols, 16));
+  if (d_bits && ((uintptr_t)d_bits) % 4 != 0) return fail(FMH_ERR_INVALID, "d_called_bits must be 4-byte aligned");
   fmh_matrix* m = new fmh_matrix();
   m->device = device;
   m->data = (uint8_t*)d_data;
@@ -664,30 +636,13 @@ extern "C" int fmh_groups_sizes(const fmh_groups* g, int* n_groups, uint64_t* h_
 // ------------------------------------------------------------------------------------------------
 // per-device workspace: block partials, totals, harmonic table, timing events
 // ------------------------------------------------------------------------------------------------
-struct Workspace {
-  bool ready = false;
-  int cus = 0;
-  int max_grid = 0;
-  double* part_f64 = nullptr;
-  unsigned long long* part_u64 = nullptr;
-  double* out_f64 = nullptr;
-  unsigned long long* out_u64 = nullptr;
-  double* h_f64 = nullptr;  // pinned
-  unsigned long long* h_u64 = nullptr;
-  double* harmonic = nullptr;
-  size_t harmonic_len = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  uint8_t* pd_planes = nullptr;  // pairwise-differences planes, kept between calls (fmh_device_release_scratch frees them)
-  size_t pd_planes_bytes = 0;
-  std::mutex in_use;  // one sweep at a time per device: concurrent callers share the partials and the pinned staging
-};
 static Workspace g_ws[64];
 static std::mutex g_ws_mutex;
 static std::atomic<bool> g_timing{false};
 static double g_timing_ms = 0.0;
 static uint64_t g_timing_launches = 0;
 
-static int workspace(int device, Workspace** out) {
+int fmhi::workspace(int device, Workspace** out) {
   if (device < 0 || device >= 64) return fail(FMH_ERR_INVALID, "device index %d unsupported", device);
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   Workspace& w = g_ws[device];
@@ -746,60 +701,24 @@ extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
-template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16>
-static int launch_one(Workspace* w, const SweepArgs& args, size_t smem, hipStream_t st, int* grid_out) {
-  auto kern = sweep_kernel<P, MODE, MISSING, GENERAL, MM, LPR>;
-  static thread_local int cached_occ[64];
-  static thread_local size_t cached_smem[64];
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  if (cached_occ[dev] == 0 || cached_smem[dev] != smem) {
-    int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, smem));
-    if (occ < 1) occ = 1;
-    if (occ > 8) occ = 8;
-    static const int env_occ = getenv("FMH_MAX_OCC") ? atoi(getenv("FMH_MAX_OCC")) : 0;
-    if (env_occ > 0 && occ > env_occ) occ = env_occ;
-    cached_occ[dev] = occ;
-    cached_smem[dev] = smem;
-  }
-  const size_t ntiles = (args.row_count + kTileRows - 1) / kTileRows;
-  size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  const size_t cap = (size_t)w->cus * cached_occ[dev];
-  if (blocks > cap) blocks = cap;
-  if (blocks > (size_t)w->max_grid) blocks = w->max_grid;
-  if (blocks < 1) blocks = 1;
-  if (g_timing) HIP_TRY(hipEventRecord(w->ev0, st));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kBlock), smem, st, args);
-  HIP_TRY(hipGetLastError());
-  if (g_timing) HIP_TRY(hipEventRecord(w->ev1, st));
-  *grid_out = (int)blocks;
-  return FMH_OK;
-}
-
-template <int P, int MODE, int MM = kMaskLdsBytes, int LPR = 16>
-static int launch_pm(Workspace* w, const SweepArgs& a, size_t smem, hipStream_t st, bool missing, bool general, int* grid) {
-  if (missing) return general ? launch_one<P, MODE, true, true, MM, LPR>(w, a, smem, st, grid) : launch_one<P, MODE, true, false, MM, LPR>(w, a, smem, st, grid);
-  return general ? launch_one<P, MODE, false, true, MM, LPR>(w, a, smem, st, grid) : launch_one<P, MODE, false, false, MM, LPR>(w, a, smem, st, grid);
-}
-
 struct SweepResult {
   double f64[kMaxF64];
   unsigned long long u64[kMaxU64];
 };
 
-static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, void* stream, SweepResult* res) {
+// Validates, fills the kernel arguments, picks the mask route and enqueues sweep + finalize on `st`: the 128 regional
+// accumulators land in b.out_f64 / b.out_u64 (device).  No synchronisation and no use of the shared workspace buffers, so
+// callers with private buffers (the pipelined sharded sweeps of comm.hip) need no device lock.  `*launched` = false when
+// the row range is empty (nothing was enqueued; the totals are all zero).
+int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, hipStream_t st, const LaunchCtx& ctx,
+                        const SweepBuffers& b, const double* harmonic, bool* launched) {
+  *launched = false;
   if (!m || !g) return fail(FMH_ERR_INVALID, "matrix or groups is NULL");
   if (g->device != m->device || g->pitch != m->pitch || g->columns != m->columns)
     return fail(FMH_ERR_INVALID, "groups were built for a different matrix geometry");
   if (a.row_begin > m->variants || a.row_count > m->variants - a.row_begin)
     return fail(FMH_ERR_INVALID, "row range [%zu, +%zu) exceeds %zu variants", a.row_begin, a.row_count, m->variants);
   FMH_TRY(use_device(m->device));
-  Workspace* w = nullptr;
-  FMH_TRY(workspace(m->device, &w));
-  std::lock_guard<std::mutex> busy(w->in_use);
-  hipStream_t st = (hipStream_t)stream;
   // the packed image when there is one (FMH_LAYOUT=bytes keeps the byte kernels on matrices that still hold their bytes)
   const bool packed = m->p0 && !(m->data && layout_bytes_forced());
   if (packed) {
@@ -840,13 +759,12 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
         a.wc_shape[k] = wc_shape<2>(pn, pu);
       }
   }
-  a.part_f64 = w->part_f64;
-  a.part_u64 = w->part_u64;
+  a.part_f64 = b.part_f64;
+  a.part_u64 = b.part_u64;
   if (mode & kModeDiversity) {
-    FMH_TRY(ensure_harmonic(w, m->columns + 1, st));
-    a.harmonic = w->harmonic;
+    if (!harmonic) return fail(FMH_ERR_INVALID, "diversity sweep without a harmonic table");
+    a.harmonic = harmonic;
   }
-  memset(res, 0, sizeof *res);
   if (a.row_count == 0) return FMH_OK;
   const bool missing = m->has_missing;
   const bool general = m->max_allele > 1;
@@ -896,81 +814,57 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
     if (want == kMaskGlobalBytes && global_ok) { smem = 0; mask_mode = kMaskGlobalBytes; }
   }
   int grid = 0;
-  int rc = FMH_ERR_UNSUPPORTED;
-#define CASE(PV, MODEV) rc = launch_pm<PV, MODEV>(w, a, smem, st, missing, general, &grid)
-#define BITS(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskLdsBits>(w, a, smem, st, missing, general, &grid)
-#define WIDE(PV, MODEV) rc = launch_pm<PV, MODEV, kMaskGlobalBytes>(w, a, smem, st, missing, general, &grid)
-#define PACKED(PV, MODEV) rc = lpr == 4 ? launch_pm<PV, MODEV, kMaskPacked, 4>(w, a, smem, st, missing, general, &grid) \
-                                         : launch_pm<PV, MODEV, kMaskPacked, 16>(w, a, smem, st, missing, general, &grid)
-  if (mask_mode == kMaskPacked) {
-    if (mode == kModeSummary) {
-      if (P == 1) PACKED(1, kModeSummary); else if (P == 2) PACKED(2, kModeSummary); else if (P == 4) PACKED(4, kModeSummary); else PACKED(8, kModeSummary);
-    } else if (mode == (kModeSummary | kModeHudson)) {
-      if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
-      PACKED(2, kModeSummary | kModeHudson);
-    } else if (mode == (kModeSummary | kModeDiversity)) {
-      if (P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
-      PACKED(1, kModeSummary | kModeDiversity);
-    } else if (mode == kModeWc) {
-      if (P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
-      if (P == 2) PACKED(2, kModeWc); else if (P == 4) PACKED(4, kModeWc); else PACKED(8, kModeWc);
-    } else {
-      return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
-    }
-  } else if (mask_mode == kMaskGlobalBytes) {
-    // one or two groups per sweep on this route (summaries and W&C re-batch their groups accordingly)
-    if (mode == kModeSummary && P == 1) WIDE(1, kModeSummary);
-    else if (mode == kModeSummary && P == 2) WIDE(2, kModeSummary);
-    else if (mode == (kModeSummary | kModeHudson) && P == 2) WIDE(2, kModeSummary | kModeHudson);
-    else if (mode == (kModeSummary | kModeDiversity) && P == 1) WIDE(1, kModeSummary | kModeDiversity);
-    else return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
-  } else if (mask_mode == kMaskLdsBits) {
-    if (mode == kModeSummary) {
-      if (P == 1) BITS(1, kModeSummary); else if (P == 2) BITS(2, kModeSummary); else if (P == 4) BITS(4, kModeSummary); else BITS(8, kModeSummary);
-    } else if (mode == (kModeSummary | kModeHudson)) {
-      if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
-      BITS(2, kModeSummary | kModeHudson);
-    } else if (mode == (kModeSummary | kModeDiversity)) {
-      if (P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
-      BITS(1, kModeSummary | kModeDiversity);
-    } else if (mode == kModeWc) {
-      if (P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
-      if (P == 2) BITS(2, kModeWc); else if (P == 4) BITS(4, kModeWc); else BITS(8, kModeWc);
-    } else {
-      return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
-    }
-  } else if (mode == kModeSummary) {
-    if (P == 1) CASE(1, kModeSummary); else if (P == 2) CASE(2, kModeSummary); else if (P == 4) CASE(4, kModeSummary); else CASE(8, kModeSummary);
-  } else if (mode == (kModeSummary | kModeHudson)) {
-    if (P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
-    CASE(2, kModeSummary | kModeHudson);
-  } else if (mode == (kModeSummary | kModeDiversity)) {
-    if (P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
-    CASE(1, kModeSummary | kModeDiversity);
-  } else if (mode == kModeWc) {
-    if (P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
-    if (P == 2) CASE(2, kModeWc); else if (P == 4) CASE(4, kModeWc); else CASE(8, kModeWc);
-  } else {
+  // argument checks shared by every route, then the route's own launcher (sweep_*.hip)
+  if (mode == (kModeSummary | kModeHudson) && P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
+  if (mode == (kModeSummary | kModeDiversity) && P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
+  if (mode == kModeWc && P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
+  if (mode != kModeSummary && mode != (kModeSummary | kModeHudson) && mode != (kModeSummary | kModeDiversity) && mode != kModeWc)
     return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
-  }
-#undef BITS
-#undef PACKED
-#undef WIDE
-#undef CASE
+  if (mask_mode == kMaskGlobalBytes && (P > 2 || mode == kModeWc))
+    return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
+  int rc;
+  if (mask_mode == kMaskPacked) rc = lpr == 4 ? launch_sweep_packed4(P, mode, missing, general, a, smem, st, ctx, &grid) : launch_sweep_packed16(P, mode, missing, general, a, smem, st, ctx, &grid);
+  else if (mask_mode == kMaskGlobalBytes) rc = launch_sweep_global(P, mode, missing, general, a, smem, st, ctx, &grid);
+  else if (mask_mode == kMaskLdsBits) rc = launch_sweep_bits(P, mode, missing, general, a, smem, st, ctx, &grid);
+  else rc = launch_sweep_bytes(P, mode, missing, general, a, smem, st, ctx, &grid);
   FMH_TRY(rc);
-  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, w->part_f64, w->part_u64, grid, w->out_f64, w->out_u64);
+  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, b.part_f64, b.part_u64, grid, b.out_f64, b.out_u64);
   HIP_TRY(hipGetLastError());
+  *launched = true;
+  return FMH_OK;
+}
+
+void fmhi::timing_add(double ms) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  g_timing_ms += ms;
+  g_timing_launches += 1;
+}
+bool fmhi::timing_enabled() { return g_timing.load(); }
+
+static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, void* stream, SweepResult* res) {
+  if (!m || !g) return fail(FMH_ERR_INVALID, "matrix or groups is NULL");
+  FMH_TRY(use_device(m->device));
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(m->device, &w));
+  std::lock_guard<std::mutex> busy(w->in_use);
+  hipStream_t st = (hipStream_t)stream;
+  const bool timing = g_timing.load();  // one snapshot per sweep: another thread may flip the switch while this one runs
+  if (mode & kModeDiversity) FMH_TRY(ensure_harmonic(w, m->columns + 1, st));
+  memset(res, 0, sizeof *res);
+  const LaunchCtx ctx{w->cus, w->max_grid, w->ev0, w->ev1, timing};
+  const SweepBuffers bufs{w->part_f64, w->part_u64, w->out_f64, w->out_u64};
+  bool launched = false;
+  FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, w->harmonic, &launched));
+  if (!launched) return FMH_OK;
   HIP_TRY(hipMemcpyAsync(w->h_f64, w->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(w->h_u64, w->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   memcpy(res->f64, w->h_f64, sizeof res->f64);
   memcpy(res->u64, w->h_u64, sizeof res->u64);
-  if (g_timing) {
+  if (timing) {
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, w->ev0, w->ev1));
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    g_timing_ms += ms;
-    g_timing_launches += 1;
+    if (hipEventElapsedTime(&ms, w->ev0, w->ev1) == hipSuccess) timing_add(ms);  // a timing failure never fails a sweep that has its results
+    else (void)hipGetLastError();
   }
   return FMH_OK;
 }
@@ -1071,20 +965,6 @@ extern "C" int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, siz
   return FMH_OK;
 }
 
-// RAII for the scratch of one call
-struct DeviceScratch {
-  int device = 0;
-  std::vector<void*> ptrs;
-  ~DeviceScratch() { for (void* p : ptrs) pool_free(device, p); }
-  template <class T> int get(T** out, size_t count) {
-    void* p = nullptr;
-    HIP_TRY(pool_malloc(device, &p, std::max<size_t>(count, 1) * sizeof(T)));
-    ptrs.push_back(p);
-    *out = (T*)p;
-    return FMH_OK;
-  }
-};
-
 // regional W&C sums per slot from the per-site tracks (two small launches, deterministic)
 static int wc_slot_sums(DeviceScratch& scratch, hipStream_t st, size_t nslots, size_t rows, const double* d_a, const double* d_b,
                         const uint8_t* d_state, double** sa, double** sb, unsigned long long** si) {
@@ -1155,6 +1035,7 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
     // sums come from the per-site tracks, which therefore must exist
     DeviceScratch scratch;
     scratch.device = m->device;
+    scratch.stream = (hipStream_t)stream;
     const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
     if (!a.wc_a) FMH_TRY(scratch.get(&a.wc_a, nslots * row_count));
     if (!a.wc_b) FMH_TRY(scratch.get(&a.wc_b, nslots * row_count));
@@ -1173,6 +1054,7 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
       HIP_TRY(hipMemcpyAsync(h_totals->informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    scratch.settled = true;
     return FMH_OK;
   }
   SweepResult r;
@@ -1210,6 +1092,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   const int n_alleles = (int)m->max_allele + 1;
   DeviceScratch scratch;
   scratch.device = m->device;
+  scratch.stream = st;
   uint32_t *called = d_group_called, *alt = nullptr, *acounts = nullptr, *n_all = nullptr, *all_alt = nullptr;
   if (!called) FMH_TRY(scratch.get(&called, G * row_count));
   FMH_TRY(scratch.get(&n_all, row_count));
@@ -1263,167 +1146,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   if (h_sum_b) HIP_TRY(hipMemcpyAsync(h_sum_b, sb, nslots * 8, hipMemcpyDeviceToHost, st));
   if (h_informative_sites) HIP_TRY(hipMemcpyAsync(h_informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  return FMH_OK;
-}
-
-extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
-                                        unsigned long long* d_both, void* stream) {
-  if (!m || !d_diff || !d_both) return fail(FMH_ERR_INVALID, "NULL argument");
-  if (n_samples > m->samples) return fail(FMH_ERR_INVALID, "n_samples %zu exceeds the matrix's %zu samples", n_samples, m->samples);
-  if (m->ploidy > 127) return fail(FMH_ERR_UNSUPPORTED, "pairwise differences support ploidy <= 127 (int8 operands), got %zu", m->ploidy);
-  FMH_TRY(use_device(m->device));
-  if (n_samples < 2 || m->variants == 0) return FMH_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const int n_alleles = (int)m->max_allele + 1;
-  const bool missing = m->has_missing;
-  // biallelic and nothing missing: one plane (allele 1) and an all-ones row after the last sample (pairwise_kernels.hpp)
-  static const bool env_two_planes = getenv("FMH_PD_TWO_PLANES") != nullptr;  // measurements / tests: the general route
-  const bool single = !missing && n_alleles == 2 && !env_two_planes;
-  const int n_planes = single ? 1 : (missing ? n_alleles + 2 : n_alleles);  // + genotype length, + valid flag only when calls can be missing
-  const size_t tile_edge = kPdBig;
-  const size_t n_pad = round_up(n_samples + (single ? 1 : 0), kPdBig);
-  // counts 0..4 are exact in FP4 (e2m1): twice the MFMA rate of int8 at half the plane bytes (pairwise_kernels.hpp)
-  static const bool env_int8 = getenv("FMH_PD_INT8") != nullptr;  // measurements / tests: the int8 route
-  const bool fp4 = m->ploidy <= 4 && !env_int8;
-  const size_t spb = fp4 ? 2 : 1;            // sites per byte of a plane row
-  const size_t ksites = kPdStageK * spb;     // sites per K block = per Gram stage
-  // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
-  static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
-  size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK) / kPdStageK * ksites;
-  slab = std::min(round_up(m->variants, ksites), slab);
-  // a matrix with a packed image feeds the planes kernel its bit rows (1/8 of the bytes); FMH_LAYOUT=bytes keeps the u8 route
-  const bool from_packed = m->p0 && !(m->data && layout_bytes_forced());
-  Workspace* w = nullptr;
-  FMH_TRY(workspace(m->device, &w));
-  std::lock_guard<std::mutex> busy(w->in_use);
-  const size_t planes_bytes = (size_t)n_planes * n_pad * slab / spb;
-  if (w->pd_planes_bytes < planes_bytes) {
-    if (w->pd_planes) (void)hipFree(w->pd_planes);
-    w->pd_planes = nullptr;
-    w->pd_planes_bytes = 0;
-    HIP_TRY(hipMalloc((void**)&w->pd_planes, planes_bytes));
-    w->pd_planes_bytes = planes_bytes;
-  }
-  uint8_t* planes = w->pd_planes;
-  hipError_t e = hipSuccess;
-  DeviceScratch scratch;
-  scratch.device = m->device;
-  unsigned long long *d_gram = nullptr, *d_totals = nullptr;
-  if (single) {
-    const size_t gram_bytes = n_samples * n_samples * sizeof(unsigned long long), totals_bytes = n_samples * sizeof(unsigned long long);
-    FMH_TRY(scratch.get(&d_gram, n_samples * n_samples));
-    FMH_TRY(scratch.get(&d_totals, n_samples));
-    HIP_TRY(hipMemsetAsync(d_gram, 0, gram_bytes, st));
-    HIP_TRY(hipMemsetAsync(d_totals, 0, totals_bytes, st));
-  }
-  const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
-  static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
-  for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
-    const size_t rows = std::min(slab, m->variants - row0);
-    const size_t s_pad = round_up(rows, ksites);  // sites
-    const size_t k_bytes = s_pad / spb;           // K bytes per sample in this slab
-    if (from_packed) {
-      // bit rows are tiny in LDS: 256 samples per workgroup (64-byte row pieces for diploid samples)
-      const uint32_t sbp = 256;
-      const size_t bitb = ((size_t)sbp * m->ploidy + 7) / 8 + 1;
-      const size_t smem_p = 3 * ksites * bitb;
-      const dim3 grid_p((unsigned)(s_pad / ksites), (unsigned)(n_pad / sbp));
-      const uint8_t* q0 = m->p0 + row0 * m->plane_pitch;
-      const uint8_t* q1 = m->p1 ? m->p1 + row0 * m->plane_pitch : nullptr;
-      const uint8_t* qc = m->pc ? m->pc + row0 * m->plane_pitch : nullptr;
-      const void* fn = fp4 ? (const void*)pd_planes_packed_kernel<true> : (const void*)pd_planes_packed_kernel<false>;
-      if (smem_p > 64 * 1024 && (e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p)) != hipSuccess) break;
-      if (fp4)
-        hipLaunchKernelGGL(pd_planes_packed_kernel<true>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
-                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
-      else
-        hipLaunchKernelGGL(pd_planes_packed_kernel<false>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
-                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
-    } else {
-      if (!m->data) { e = hipErrorInvalidValue; break; }
-      MatrixView mv{};
-      mv.pitch = m->pitch;
-      mv.columns = m->columns;
-      mv.nvec = m->nvec;
-      mv.data = m->data + row0 * m->pitch;
-      mv.bits = m->bits ? m->bits + row0 * m->bits_pitch : nullptr;
-      mv.bits_pitch = m->bits_pitch;
-      // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
-      // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
-      // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
-      static const uint32_t env_sb = getenv("FMH_PD_SB") ? (uint32_t)atoi(getenv("FMH_PD_SB")) : 0;  // measurements
-      uint32_t sb = env_sb ? env_sb : kPdBlock;
-      while ((size_t)sb * m->ploidy * ksites > 32 * 1024 && sb > 4) sb /= 2;
-      const size_t planes_smem = ksites * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
-      const void* planes_fn = fp4 ? (const void*)pd_planes_kernel<true> : (const void*)pd_planes_kernel<false>;
-      if (planes_smem > 64 * 1024 && (e = hipFuncSetAttribute(planes_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)planes_smem)) != hipSuccess) break;
-      const dim3 planes_grid((unsigned)(s_pad / ksites), (unsigned)(n_pad / sb));
-      if (fp4)
-        hipLaunchKernelGGL(pd_planes_kernel<true>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
-                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
-      else
-        hipLaunchKernelGGL(pd_planes_kernel<false>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
-                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) break;
-    // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
-    // that every XCD has several rounds of (slice, tile pair) items (balance) but a slice still spans many stages
-    static thread_local int gram_occ[64][2];
-    if (gram_occ[m->device][fp4] == 0) {
-      int occ = 0;
-      hipError_t oe = hipFuncSetAttribute(fp4 ? (const void*)pd_gram256_kernel<4, 4, true> : (const void*)pd_gram256_kernel<4, 4, false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kPdBigStageBytes);
-      if (oe == hipSuccess) oe = fp4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4, true>, 1024, 2 * kPdBigStageBytes)
-                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4, false>, 1024, 2 * kPdBigStageBytes);
-      if (oe != hipSuccess || occ < 1) occ = 1;
-      static const int env_occ = getenv("FMH_PD_OCC") ? atoi(getenv("FMH_PD_OCC")) : 0;
-      if (env_occ > 0 && occ > env_occ) occ = env_occ;
-      gram_occ[m->device][fp4] = occ;
-    }
-    const unsigned grid = (unsigned)std::max(8, w->cus * gram_occ[m->device][fp4] / 8 * 8);  // persistent: every workgroup resident
-    const size_t slots = grid / 8;
-    size_t j = env_chunk ? std::max<size_t>(1, (k_bytes + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
-    // an item's accumulators must stay exact: int32 for the int8 route, integers up to 2^24 in f32 for FP4 (counts <= ploidy)
-    const size_t cap_sites = (fp4 ? ((size_t)1 << 24) : (((size_t)1 << 31) - 1)) / (m->ploidy * m->ploidy);
-    const size_t k_cap = std::max<size_t>(cap_sites / spb / kPdStageK, 1) * kPdStageK;
-    size_t k_chunk = round_up((k_bytes + 8 * j - 1) / (8 * j), kPdStageK);
-    const size_t k_floor = std::min<size_t>(k_bytes, 4096);  // at least 32 stages per item unless the slab is shorter
-    if (k_chunk < k_floor) k_chunk = k_floor;
-    if (k_chunk > k_cap) k_chunk = k_cap;
-    j = ((k_bytes + k_chunk - 1) / k_chunk + 7) / 8;
-    auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst, unsigned long long* totals = nullptr) {
-      if (fp4)
-        hipLaunchKernelGGL((pd_gram256_kernel<4, 4, true>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
-                           k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
-      else
-        hipLaunchKernelGGL((pd_gram256_kernel<4, 4, false>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
-                           k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);
-      return hipGetLastError();
-    };
-    if (single) {
-      if ((e = gram(0, 1, 0, d_gram, d_totals)) != hipSuccess) break;
-      continue;
-    }
-    // diff = sum len_i len_j - sum_a cnt_i(a) cnt_j(a)
-    if ((e = gram(0, n_alleles, 1, d_diff)) != hipSuccess) break;
-    if (missing) {
-      if ((e = gram(n_alleles, 1, 0, d_diff)) != hipSuccess) break;
-      if ((e = gram(n_alleles + 1, 1, 0, d_both)) != hipSuccess) break;
-    }
-  }
-  if (e == hipSuccess && single) {
-    const size_t total = n_samples * n_samples;
-    hipLaunchKernelGGL(pd_single_plane_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_diff, d_both, d_gram, d_totals,
-                       (uint32_t)n_samples, (unsigned long long)m->ploidy, (unsigned long long)m->variants);
-    e = hipGetLastError();
-  } else if (e == hipSuccess && !missing) {
-    const size_t total = n_samples * n_samples;
-    hipLaunchKernelGGL(pd_constant_terms_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_diff, d_both, (uint32_t)n_samples,
-                       (unsigned long long)m->variants * m->ploidy * m->ploidy, (unsigned long long)m->variants);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return fail(FMH_ERR_HIP, "pairwise differences failed: %s", hipGetErrorString(e));
+  scratch.settled = true;
   return FMH_OK;
 }
 
@@ -1436,36 +1159,5 @@ extern "C" int fmh_device_release_scratch(int device) {
   w->pd_planes = nullptr;
   w->pd_planes_bytes = 0;
   pool_trim(device);
-  return FMH_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// totals packing for a single all-reduce(sum)
-// ------------------------------------------------------------------------------------------------
-extern "C" int fmh_hudson_totals_pack(const fmh_hudson_totals* t, double* f, uint64_t* u) {
-  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
-  f[0] = t->numerator_sum; f[1] = t->denominator_sum; f[2] = t->pi1_sum; f[3] = t->pi2_sum;
-  f[4] = t->dxy_sum_all; f[5] = t->site_num_sum; f[6] = t->site_den_sum; f[7] = t->site_dxy_sum;
-  f[8] = t->pop[0].pi_sum; f[9] = t->pop[1].pi_sum;
-  u[0] = t->dxy_uncallable_sites; u[1] = t->sites_with_components; u[2] = t->site_dxy_skipped;
-  u[3] = t->pop[0].segregating_sites; u[4] = t->pop[0].uncallable_sites;
-  u[5] = t->pop[1].segregating_sites; u[6] = t->pop[1].uncallable_sites;
-  u[7] = t->pop[0].haplotype_capacity; u[8] = t->pop[1].haplotype_capacity;  // identical on every rank; divide after a sum
-  u[9] = 1;  // ranks summed
-  return FMH_OK;
-}
-
-extern "C" int fmh_hudson_totals_unpack(fmh_hudson_totals* t, const double* f, const uint64_t* u) {
-  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
-  memset(t, 0, sizeof *t);
-  t->numerator_sum = f[0]; t->denominator_sum = f[1]; t->pi1_sum = f[2]; t->pi2_sum = f[3];
-  t->dxy_sum_all = f[4]; t->site_num_sum = f[5]; t->site_den_sum = f[6]; t->site_dxy_sum = f[7];
-  t->pop[0].pi_sum = f[8]; t->pop[1].pi_sum = f[9];
-  t->dxy_uncallable_sites = u[0]; t->sites_with_components = u[1]; t->site_dxy_skipped = u[2];
-  t->pop[0].segregating_sites = u[3]; t->pop[0].uncallable_sites = u[4];
-  t->pop[1].segregating_sites = u[5]; t->pop[1].uncallable_sites = u[6];
-  const uint64_t ranks = u[9] ? u[9] : 1;
-  t->pop[0].haplotype_capacity = u[7] / ranks;
-  t->pop[1].haplotype_capacity = u[8] / ranks;
   return FMH_OK;
 }

@@ -1,0 +1,162 @@
+// abi_internal.hpp — host-side internals shared by the translation units of libferromic_hip.so (abi.hip, pairwise.hip,
+// comm.hip and the sweep_*.hip files that hold the kernel instantiations).  Nothing here is part of the C-ABI: the library
+// is built with -fvisibility=hidden and only include/ferromic_hip.h's functions are exported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#pragma GCC visibility push(default)
+#include "../../include/ferromic_hip.h"
+#pragma GCC visibility pop
+
+#include "sweep_kernels.hpp"
+
+namespace fmhi {
+
+// ---- errors: status code + thread-local message (fmh_last_error) ----------------------------------------------------
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return ::fmhi::fail(_e == hipErrorNoDevice ? FMH_ERR_NO_DEVICE : FMH_ERR_HIP, "%s: %s (%s:%d)", \
+                          #expr, hipGetErrorString(_e), __FILE__, __LINE__);                        \
+  } while (0)
+
+#define FMH_TRY(expr)            \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != FMH_OK) return _s; \
+  } while (0)
+
+int use_device(int device);  // range check + hipSetDevice
+
+// ---- device memory pool (abi.hip) -------------------------------------------------------------------------------------
+hipError_t pool_malloc(int device, void** out, size_t bytes);
+void pool_free(int device, void* p);
+void pool_trim(int device);
+
+inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// FMH_LAYOUT=bytes keeps the u8 kernels on matrices that still hold their byte rows (read per call: tests flip it)
+inline bool layout_bytes_forced() {
+  const char* v = getenv("FMH_LAYOUT");
+  return v && strcmp(v, "bytes") == 0;
+}
+
+// RAII for the scratch of one call
+struct DeviceScratch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool settled = false;  // set once the call has synchronised the stream its kernels ran on
+  std::vector<void*> ptrs;
+  // An early (error) return may leave kernels that write these blocks enqueued: wait for the stream before the blocks go
+  // back to the pool, where another thread's pool_malloc could be handed them at once.
+  ~DeviceScratch() {
+    if (!settled && !ptrs.empty()) { (void)hipStreamSynchronize(stream); (void)hipGetLastError(); }
+    for (void* p : ptrs) pool_free(device, p);
+  }
+  template <class T> int get(T** out, size_t count) {
+    void* p = nullptr;
+    HIP_TRY(pool_malloc(device, &p, (count > 0 ? count : 1) * sizeof(T)));
+    ptrs.push_back(p);
+    *out = (T*)p;
+    return FMH_OK;
+  }
+};
+
+// ---- per-device workspace: block partials, totals, harmonic table, timing events ------------------------------------
+struct Workspace {
+  bool ready = false;
+  int cus = 0;
+  int max_grid = 0;
+  double* part_f64 = nullptr;
+  unsigned long long* part_u64 = nullptr;
+  double* out_f64 = nullptr;
+  unsigned long long* out_u64 = nullptr;
+  double* h_f64 = nullptr;  // pinned
+  unsigned long long* h_u64 = nullptr;
+  double* harmonic = nullptr;
+  size_t harmonic_len = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint8_t* pd_planes = nullptr;  // pairwise-differences planes, kept between calls (fmh_device_release_scratch frees them)
+  size_t pd_planes_bytes = 0;
+  std::mutex in_use;  // one sweep at a time per device: concurrent callers share the partials and the pinned staging
+};
+int workspace(int device, Workspace** out);
+
+// measurement (fmh_timing_*): accumulated HIP-event time of the sweep kernels
+void timing_add(double ms);
+bool timing_enabled();
+
+// ---- kernel launches that live in their own translation units ------------------------------------------------------
+// What a launcher needs from the workspace.
+struct LaunchCtx {
+  int cus;
+  int max_grid;
+  hipEvent_t ev0, ev1;  // recorded around the sweep kernel when `timing`
+  bool timing;
+};
+// Device buffers a sweep reduces into: [grid][64] block partials and the 64 + 64 regional accumulators.
+struct SweepBuffers {
+  double* part_f64;
+  unsigned long long* part_u64;
+  double* out_f64;
+  unsigned long long* out_u64;
+};
+}  // namespace fmhi
+struct fmh_matrix;
+struct fmh_groups;
+namespace fmhi {
+// sweep + finalize enqueued on `st`, no synchronisation (abi.hip)
+int enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, fmh::SweepArgs& a, hipStream_t st, const LaunchCtx& ctx,
+                  const SweepBuffers& b, const double* harmonic, bool* launched);
+
+// One function per (mask route, lanes per row): dispatches on (P, mode, missing, general) to the instantiation, sizes the
+// persistent grid and launches.  FMH_ERR_UNSUPPORTED for a combination the route does not build.
+int launch_sweep_packed4(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+int launch_sweep_packed16(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+int launch_sweep_bytes(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+int launch_sweep_bits(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+int launch_sweep_global(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+
+}  // namespace fmhi
+
+// ---- handles (the opaque types of the C-ABI) ----------------------------------------------------------------------------
+struct fmh_matrix {
+  int device = 0;
+  uint8_t* data = nullptr;
+  uint8_t* bits = nullptr;  // called bit-rows or null
+  size_t pitch = 0, bits_pitch = 0;
+  size_t variants = 0, samples = 0, ploidy = 0;
+  uint32_t columns = 0, nvec = 0;
+  uint8_t max_allele = 0;
+  bool owns = true;
+  bool has_missing = false;  // a called mask exists (bits and / or pc)
+  // bit-packed image (fmh_matrix_pack): p0 = allele & 1, p1 = allele >> 1 (max_allele 2..3), pc = called bits; plane_pitch
+  // bytes per row, pvec = ceil(columns / 128) 16-byte vectors.  data / bits may have been released (nullptr).
+  uint8_t *p0 = nullptr, *p1 = nullptr, *pc = nullptr;
+  size_t plane_pitch = 0;
+  uint32_t pvec = 0;
+};
+
+struct fmh_groups {
+  int device = 0;
+  int n_groups = 0;   // caller's P
+  int padded = 0;     // kernel P (1, 2, 4 or 8)
+  uint8_t* masks = nullptr;  // [padded][mask_pitch], zero beyond the row
+  size_t pitch = 0;
+  size_t mask_pitch = 0;     // pitch rounded up to 2048: covers the kernels' zero-padded mask stride
+  uint16_t* mask_bits = nullptr;  // [padded][mask_pitch / 16]: the same masks as one 16-bit word per 16-byte vector
+  uint32_t columns = 0;
+  uint64_t sizes[FMH_MAX_GROUPS] = {0};
+  std::vector<uint8_t> host_mask;  // [n_groups][columns] as handed in (the wide-matrix W&C route re-batches the groups)
+};

@@ -1,0 +1,507 @@
+// comm.hip — fmh_comm: the sum of the regional accumulators over the ranks of a region-sharded sweep.
+//
+// Transport 0: RCCL (ncclAllReduce over xGMI), bound at run time with dlopen so that a single-GPU host never loads the
+// library and a process that already maps a copy (PyTorch's wheel bundles one) shares it.  Transport 1: an in-process
+// rendezvous that sums in rank order on the host, for one process whose "ranks" alias a device (RCCL refuses two ranks on
+// one GPU) - the rehearsal path of run_vcf --devices 0,0 and of the tests on a one-GPU box.
+//
+// The reference has no counterpart file: its reduce is rayon's fold/reduce inside one address space
+// (stats.rs:1365-1461) and the serial sums of 1554-1623 / 2145-2374.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstdlib>
+#include <memory>
+#include <set>
+
+#include "abi_internal.hpp"
+
+using namespace fmh;
+using namespace fmhi;
+
+// ---- the slice of the RCCL API this file uses (types as in <rccl/rccl.h>, NCCL 2.x ABI) ----------------------------
+namespace {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+static_assert(sizeof(ncclUniqueId) == FMH_COMM_ID_BYTES, "FMH_COMM_ID_BYTES is NCCL_UNIQUE_ID_BYTES");
+typedef int ncclResult_t;  // ncclSuccess == 0
+constexpr int kNcclSum = 0;
+constexpr int kNcclUint64 = 5, kNcclFloat64 = 8;  // ncclDataType_t
+
+struct RcclApi {
+  void* handle = nullptr;
+  std::string origin;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_api(RcclApi** out) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!g_rccl.handle) {
+    void* h = nullptr;
+    std::string origin;
+    // (1) a copy this process already maps (torch.distributed's), (2) an explicit path, (3) the system's
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      if (!h && (h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) origin = std::string(name) + " (already loaded)";
+    }
+    if (!h) {
+      if (const char* env = getenv("FMH_RCCL_LIBRARY")) { if ((h = dlopen(env, RTLD_NOW | RTLD_LOCAL))) origin = env; }
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      if (!h && (h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) origin = name;
+    }
+    if (!h) return fail(FMH_ERR_UNSUPPORTED, "RCCL is not available (dlopen librccl.so: %s); set FMH_RCCL_LIBRARY", dlerror());
+    RcclApi api;
+    api.handle = h;
+    api.origin = origin;
+#define BIND(field, sym)                                                     \
+  api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, sym));          \
+  if (!api.field) return fail(FMH_ERR_UNSUPPORTED, "RCCL (%s) lacks %s", origin.c_str(), sym)
+    BIND(GetUniqueId, "ncclGetUniqueId");
+    BIND(CommInitRank, "ncclCommInitRank");
+    BIND(CommInitAll, "ncclCommInitAll");
+    BIND(CommDestroy, "ncclCommDestroy");
+    BIND(AllReduce, "ncclAllReduce");
+    BIND(GroupStart, "ncclGroupStart");
+    BIND(GroupEnd, "ncclGroupEnd");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+    g_rccl = api;
+  }
+  *out = &g_rccl;
+  return FMH_OK;
+}
+
+#define RCCL_TRY(api, expr)                                                                                           \
+  do {                                                                                                                \
+    ncclResult_t _r = (expr);                                                                                         \
+    if (_r != 0) return fail(FMH_ERR_HIP, "%s: %s (%s:%d)", #expr, (api)->GetErrorString(_r), __FILE__, __LINE__);   \
+  } while (0)
+
+// in-process rendezvous shared by the handles of one fmh_comm_init_all call (transport 1)
+struct HostGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n = 0, arrived = 0;
+  uint64_t generation = 0;
+  bool mismatch = false;
+  std::vector<std::vector<double>> f;
+  std::vector<std::vector<uint64_t>> u;
+  std::vector<double> rf;
+  std::vector<uint64_t> ru;
+
+  // sums in rank order (deterministic), every rank leaves with the same vectors
+  int allreduce(int rank, double* f64, size_t nf, uint64_t* u64, size_t nu) {
+    std::unique_lock<std::mutex> lock(mu);
+    f[rank].assign(f64, f64 + nf);
+    u[rank].assign(u64, u64 + nu);
+    const uint64_t gen = generation;
+    if (++arrived == n) {
+      mismatch = false;
+      for (int r = 1; r < n; ++r) mismatch |= f[r].size() != f[0].size() || u[r].size() != u[0].size();
+      if (!mismatch) {
+        rf.assign(f[0].size(), 0.0);
+        ru.assign(u[0].size(), 0);
+        for (int r = 0; r < n; ++r) {
+          for (size_t i = 0; i < rf.size(); ++i) rf[i] += f[r][i];
+          for (size_t i = 0; i < ru.size(); ++i) ru[i] += u[r][i];
+        }
+      }
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return generation != gen; });
+    }
+    if (mismatch) return fail(FMH_ERR_INVALID, "fmh_allreduce_totals: the ranks passed vectors of different lengths");
+    // still under the lock: no rank can complete the NEXT round (and overwrite rf / ru) before this one has re-entered
+    for (size_t i = 0; i < nf; ++i) f64[i] = rf[i];
+    for (size_t i = 0; i < nu; ++i) u64[i] = ru[i];
+    return FMH_OK;
+  }
+};
+
+// one pipelined sharded sweep in flight
+struct ShardSlot {
+  double* part_f64 = nullptr;
+  unsigned long long* part_u64 = nullptr;
+  double* out_f64 = nullptr;   // device: finalised local totals, reduced in place
+  unsigned long long* out_u64 = nullptr;
+  double* h_f64 = nullptr;     // pinned
+  unsigned long long* h_u64 = nullptr;
+  hipEvent_t swept = nullptr, reduced = nullptr, ev0 = nullptr, ev1 = nullptr;
+  bool busy = false, launched = false, timed = false;
+  uint64_t sizes[2] = {0, 0};
+};
+}  // namespace
+
+struct fmh_comm {
+  int world = 1, rank = 0, device = 0;
+  int transport = 0;
+  ncclComm_t nccl = nullptr;
+  std::shared_ptr<HostGroup> host;
+  hipStream_t stream = nullptr;  // the reduce runs here, beside the sweeps on the caller's stream
+  int cus = 0, max_grid = 0;
+  // fmh_allreduce_totals staging
+  double* d_f64 = nullptr;
+  unsigned long long* d_u64 = nullptr;
+  double* h_f64 = nullptr;  // pinned
+  unsigned long long* h_u64 = nullptr;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  size_t pend_nf = 0, pend_nu = 0;
+  // fmh_hudson_sweep_sharded_*: FIFO of slots
+  ShardSlot slot[FMH_SHARDED_IN_FLIGHT];
+  unsigned long long head = 0, tail = 0;
+};
+
+namespace {
+
+int comm_alloc(fmh_comm* c) {
+  FMH_TRY(use_device(c->device));
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(c->device, &w));
+  c->cus = w->cus;
+  c->max_grid = w->max_grid;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void**)&c->d_f64, FMH_COMM_MAX_VALUES * 8));
+  HIP_TRY(hipMalloc((void**)&c->d_u64, FMH_COMM_MAX_VALUES * 8));
+  HIP_TRY(hipHostMalloc((void**)&c->h_f64, FMH_COMM_MAX_VALUES * 8, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&c->h_u64, FMH_COMM_MAX_VALUES * 8, hipHostMallocDefault));
+  HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  for (auto& s : c->slot) {
+    HIP_TRY(hipMalloc((void**)&s.part_f64, (size_t)c->max_grid * kMaxF64 * 8));
+    HIP_TRY(hipMalloc((void**)&s.part_u64, (size_t)c->max_grid * kMaxU64 * 8));
+    HIP_TRY(hipMalloc((void**)&s.out_f64, kMaxF64 * 8));
+    HIP_TRY(hipMalloc((void**)&s.out_u64, kMaxU64 * 8));
+    HIP_TRY(hipHostMalloc((void**)&s.h_f64, kMaxF64 * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&s.h_u64, kMaxU64 * 8, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&s.swept, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.reduced, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&s.ev0));
+    HIP_TRY(hipEventCreate(&s.ev1));
+  }
+  return FMH_OK;
+}
+
+void comm_free(fmh_comm* c) {
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+  (void)hipFree(c->d_f64); (void)hipFree(c->d_u64);
+  (void)hipHostFree(c->h_f64); (void)hipHostFree(c->h_u64);
+  if (c->done) (void)hipEventDestroy(c->done);
+  for (auto& s : c->slot) {
+    (void)hipFree(s.part_f64); (void)hipFree(s.part_u64); (void)hipFree(s.out_f64); (void)hipFree(s.out_u64);
+    (void)hipHostFree(s.h_f64); (void)hipHostFree(s.h_u64);
+    for (hipEvent_t e : {s.swept, s.reduced, s.ev0, s.ev1}) if (e) (void)hipEventDestroy(e);
+  }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  (void)hipGetLastError();
+  delete c;
+}
+
+// the two vectors, resident on the device, summed over the ranks on the communicator's stream (RCCL transport)
+int rccl_reduce_on_stream(fmh_comm* c, double* d_f64, size_t nf, unsigned long long* d_u64, size_t nu) {
+  RcclApi* api = nullptr;
+  FMH_TRY(rccl_api(&api));
+  RCCL_TRY(api, api->GroupStart());
+  if (nf) RCCL_TRY(api, api->AllReduce(d_f64, d_f64, nf, kNcclFloat64, kNcclSum, c->nccl, c->stream));
+  if (nu) RCCL_TRY(api, api->AllReduce(d_u64, d_u64, nu, kNcclUint64, kNcclSum, c->nccl, c->stream));
+  RCCL_TRY(api, api->GroupEnd());
+  return FMH_OK;
+}
+
+}  // namespace
+
+extern "C" int fmh_comm_get_unique_id(void* h_id) {
+  if (!h_id) return fail(FMH_ERR_INVALID, "h_id is NULL");
+  int n = 0;
+  FMH_TRY(fmh_device_count(&n));
+  RcclApi* api = nullptr;
+  FMH_TRY(rccl_api(&api));
+  ncclUniqueId id;
+  RCCL_TRY(api, api->GetUniqueId(&id));
+  memcpy(h_id, &id, sizeof id);
+  return FMH_OK;
+}
+
+extern "C" int fmh_comm_init_rank(const void* h_id, int world, int rank, int device, fmh_comm** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!h_id) return fail(FMH_ERR_INVALID, "h_id is NULL");
+  if (world < 1 || rank < 0 || rank >= world) return fail(FMH_ERR_INVALID, "rank %d of %d out of range", rank, world);
+  FMH_TRY(use_device(device));
+  RcclApi* api = nullptr;
+  FMH_TRY(rccl_api(&api));
+  fmh_comm* c = new fmh_comm();
+  c->world = world; c->rank = rank; c->device = device; c->transport = 0;
+  int rc = comm_alloc(c);
+  if (rc == FMH_OK) {
+    ncclUniqueId id;
+    memcpy(&id, h_id, sizeof id);
+    ncclResult_t r = api->CommInitRank(&c->nccl, world, id, rank);
+    if (r != 0) rc = fail(FMH_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, api->GetErrorString(r));
+  }
+  if (rc != FMH_OK) { comm_free(c); return rc; }
+  *out = c;
+  return FMH_OK;
+}
+
+extern "C" int fmh_comm_init_all(const int* h_devices, int n, fmh_comm** h_out) {
+  if (!h_devices || !h_out) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n < 1 || n > 64) return fail(FMH_ERR_INVALID, "communicator size %d out of range 1..64", n);
+  for (int i = 0; i < n; ++i) h_out[i] = nullptr;
+  std::set<int> distinct(h_devices, h_devices + n);
+  const char* env = getenv("FMH_COMM_TRANSPORT");
+  const bool host = distinct.size() != (size_t)n || (env && strcmp(env, "host") == 0);
+  std::vector<fmh_comm*> made;
+  auto bail = [&](int code) { for (fmh_comm* c : made) comm_free(c); for (int i = 0; i < n; ++i) h_out[i] = nullptr; return code; };
+  std::shared_ptr<HostGroup> group;
+  if (host) {
+    group = std::make_shared<HostGroup>();
+    group->n = n;
+    group->f.resize(n);
+    group->u.resize(n);
+  }
+  for (int i = 0; i < n; ++i) {
+    if (use_device(h_devices[i]) != FMH_OK) return bail(FMH_ERR_INVALID);
+    fmh_comm* c = new fmh_comm();
+    made.push_back(c);
+    c->world = n; c->rank = i; c->device = h_devices[i]; c->transport = host ? 1 : 0;
+    c->host = group;
+    const int rc = comm_alloc(c);
+    if (rc != FMH_OK) return bail(rc);
+  }
+  if (!host) {
+    RcclApi* api = nullptr;
+    const int rc = rccl_api(&api);
+    if (rc != FMH_OK) return bail(rc);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    ncclResult_t r = api->CommInitAll(comms.data(), n, h_devices);
+    if (r != 0) return bail(fail(FMH_ERR_HIP, "ncclCommInitAll over %d devices: %s", n, api->GetErrorString(r)));
+    for (int i = 0; i < n; ++i) made[i]->nccl = comms[i];
+  }
+  for (int i = 0; i < n; ++i) h_out[i] = made[i];
+  return FMH_OK;
+}
+
+extern "C" int fmh_comm_destroy(fmh_comm* c) {
+  if (c) comm_free(c);
+  return FMH_OK;
+}
+
+extern "C" int fmh_comm_info(const fmh_comm* c, int* world, int* rank, int* device, int* transport) {
+  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
+  if (world) *world = c->world;
+  if (rank) *rank = c->rank;
+  if (device) *device = c->device;
+  if (transport) *transport = c->transport;
+  return FMH_OK;
+}
+
+extern "C" int fmh_allreduce_totals_begin(fmh_comm* c, const double* h_f64, size_t n_f64, const uint64_t* h_u64, size_t n_u64) {
+  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
+  if ((n_f64 && !h_f64) || (n_u64 && !h_u64)) return fail(FMH_ERR_INVALID, "NULL vector");
+  if (n_f64 > FMH_COMM_MAX_VALUES || n_u64 > FMH_COMM_MAX_VALUES) return fail(FMH_ERR_INVALID, "at most %d values per vector", FMH_COMM_MAX_VALUES);
+  if (c->pending) return fail(FMH_ERR_INVALID, "a reduce is already in flight on this communicator: call fmh_allreduce_totals_end first");
+  FMH_TRY(use_device(c->device));
+  memcpy(c->h_f64, h_f64, n_f64 * 8);
+  memcpy(c->h_u64, h_u64, n_u64 * 8);
+  c->pend_nf = n_f64;
+  c->pend_nu = n_u64;
+  if (c->transport == 0) {
+    if (n_f64) HIP_TRY(hipMemcpyAsync(c->d_f64, c->h_f64, n_f64 * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_u64) HIP_TRY(hipMemcpyAsync(c->d_u64, c->h_u64, n_u64 * 8, hipMemcpyHostToDevice, c->stream));
+    FMH_TRY(rccl_reduce_on_stream(c, c->d_f64, n_f64, c->d_u64, n_u64));
+    if (n_f64) HIP_TRY(hipMemcpyAsync(c->h_f64, c->d_f64, n_f64 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_u64) HIP_TRY(hipMemcpyAsync(c->h_u64, c->d_u64, n_u64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->done, c->stream));
+  }
+  c->pending = true;
+  return FMH_OK;
+}
+
+extern "C" int fmh_allreduce_totals_end(fmh_comm* c, double* h_f64, uint64_t* h_u64) {
+  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
+  if (!c->pending) return fail(FMH_ERR_INVALID, "no reduce in flight on this communicator");
+  if ((c->pend_nf && !h_f64) || (c->pend_nu && !h_u64)) return fail(FMH_ERR_INVALID, "NULL vector");
+  c->pending = false;
+  if (c->transport == 0) {
+    FMH_TRY(use_device(c->device));
+    HIP_TRY(hipEventSynchronize(c->done));
+  } else {
+    FMH_TRY(c->host->allreduce(c->rank, c->h_f64, c->pend_nf, reinterpret_cast<uint64_t*>(c->h_u64), c->pend_nu));
+  }
+  memcpy(h_f64, c->h_f64, c->pend_nf * 8);
+  memcpy(h_u64, c->h_u64, c->pend_nu * 8);
+  return FMH_OK;
+}
+
+extern "C" int fmh_allreduce_totals(fmh_comm* c, double* h_f64, size_t n_f64, uint64_t* h_u64, size_t n_u64) {
+  FMH_TRY(fmh_allreduce_totals_begin(c, h_f64, n_f64, h_u64, n_u64));
+  return fmh_allreduce_totals_end(c, h_f64, h_u64);
+}
+
+// ---- pipelined sharded Hudson sweep ------------------------------------------------------------------------------------
+extern "C" int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                              int formula, const fmh_hudson_sites* sites, void* stream) {
+  if (!c || !m || !g) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (formula != FMH_FORMULA_SPARSE && formula != FMH_FORMULA_DENSE && formula != FMH_FORMULA_SUMMARY) return fail(FMH_ERR_INVALID, "unknown formula %d", formula);
+  if (g->n_groups != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups, got %d", g->n_groups);
+  if (m->device != c->device) return fail(FMH_ERR_INVALID, "matrix lives on device %d, the communicator on device %d", m->device, c->device);
+  if (c->head - c->tail >= FMH_SHARDED_IN_FLIGHT) return fail(FMH_ERR_INVALID, "%d sharded sweeps already in flight: call fmh_hudson_sweep_sharded_end first", FMH_SHARDED_IN_FLIGHT);
+  FMH_TRY(use_device(c->device));
+  ShardSlot& s = c->slot[c->head % FMH_SHARDED_IN_FLIGHT];
+  hipStream_t st = (hipStream_t)stream;
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = formula;
+  if (sites) {
+    a.fst = sites->d_fst; a.dxy = sites->d_dxy; a.pi1 = sites->d_pi1; a.pi2 = sites->d_pi2;
+    a.num = sites->d_num; a.den = sites->d_den; a.alt = sites->d_alt; a.called = sites->d_called;
+  }
+  s.timed = timing_enabled();
+  const LaunchCtx ctx{c->cus, c->max_grid, s.ev0, s.ev1, s.timed};
+  const SweepBuffers bufs{s.part_f64, s.part_u64, s.out_f64, s.out_u64};
+  s.launched = false;
+  FMH_TRY(enqueue_sweep(m, g, kModeSummary | kModeHudson, a, st, ctx, bufs, nullptr, &s.launched));
+  if (!s.launched) {  // an empty slab still takes part in the collective, with zeros
+    HIP_TRY(hipMemsetAsync(s.out_f64, 0, kMaxF64 * 8, st));
+    HIP_TRY(hipMemsetAsync(s.out_u64, 0, kMaxU64 * 8, st));
+  }
+  s.sizes[0] = g->sizes[0];
+  s.sizes[1] = g->sizes[1];
+  HIP_TRY(hipEventRecord(s.swept, st));
+  HIP_TRY(hipStreamWaitEvent(c->stream, s.swept, 0));
+  if (c->transport == 0) FMH_TRY(rccl_reduce_on_stream(c, s.out_f64, kMaxF64, s.out_u64, kMaxU64));
+  HIP_TRY(hipMemcpyAsync(s.h_f64, s.out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(s.h_u64, s.out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(s.reduced, c->stream));
+  s.busy = true;
+  ++c->head;
+  return FMH_OK;
+}
+
+extern "C" int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* t) {
+  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
+  if (c->head == c->tail) return fail(FMH_ERR_INVALID, "no sharded sweep in flight on this communicator");
+  FMH_TRY(use_device(c->device));
+  ShardSlot& s = c->slot[c->tail % FMH_SHARDED_IN_FLIGHT];
+  ++c->tail;
+  s.busy = false;
+  HIP_TRY(hipEventSynchronize(s.reduced));
+  if (c->transport == 1) FMH_TRY(c->host->allreduce(c->rank, s.h_f64, kMaxF64, reinterpret_cast<uint64_t*>(s.h_u64), kMaxU64));
+  if (s.timed && s.launched) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) timing_add(ms); else (void)hipGetLastError();
+  }
+  if (t) {
+    memset(t, 0, sizeof *t);
+    const double* f = s.h_f64;
+    const unsigned long long* u = s.h_u64;
+    t->numerator_sum = f[kOffHudF64 + 0]; t->denominator_sum = f[kOffHudF64 + 1];
+    t->pi1_sum = f[kOffHudF64 + 2]; t->pi2_sum = f[kOffHudF64 + 3]; t->dxy_sum_all = f[kOffHudF64 + 4];
+    t->site_num_sum = f[kOffHudF64 + 5]; t->site_den_sum = f[kOffHudF64 + 6]; t->site_dxy_sum = f[kOffHudF64 + 7];
+    t->dxy_uncallable_sites = u[kOffHudU64 + 0]; t->sites_with_components = u[kOffHudU64 + 1]; t->site_dxy_skipped = u[kOffHudU64 + 2];
+    for (int p = 0; p < 2; ++p) {
+      t->pop[p].haplotype_capacity = s.sizes[p];
+      t->pop[p].segregating_sites = u[kOffPopSeg + p];
+      t->pop[p].uncallable_sites = u[kOffPopUnc + p];
+      t->pop[p].pi_sum = f[kOffPopF64 + p];
+    }
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_hudson_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int formula,
+                                        const fmh_hudson_sites* sites, fmh_hudson_totals* t, void* stream) {
+  if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with fmh_hudson_sweep_sharded_end first");
+  FMH_TRY(fmh_hudson_sweep_sharded_begin(c, m, g, row_begin, row_count, formula, sites, stream));
+  return fmh_hudson_sweep_sharded_end(c, t);
+}
+
+// ---- packing of the totals structs ----------------------------------------------------------------------------------------
+extern "C" int fmh_hudson_totals_pack(const fmh_hudson_totals* t, double* f, uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  f[0] = t->numerator_sum; f[1] = t->denominator_sum; f[2] = t->pi1_sum; f[3] = t->pi2_sum;
+  f[4] = t->dxy_sum_all; f[5] = t->site_num_sum; f[6] = t->site_den_sum; f[7] = t->site_dxy_sum;
+  f[8] = t->pop[0].pi_sum; f[9] = t->pop[1].pi_sum;
+  u[0] = t->dxy_uncallable_sites; u[1] = t->sites_with_components; u[2] = t->site_dxy_skipped;
+  u[3] = t->pop[0].segregating_sites; u[4] = t->pop[0].uncallable_sites;
+  u[5] = t->pop[1].segregating_sites; u[6] = t->pop[1].uncallable_sites;
+  u[7] = t->pop[0].haplotype_capacity; u[8] = t->pop[1].haplotype_capacity;  // identical on every rank; divide after a sum
+  u[9] = 1;  // ranks summed
+  return FMH_OK;
+}
+
+extern "C" int fmh_hudson_totals_unpack(fmh_hudson_totals* t, const double* f, const uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  memset(t, 0, sizeof *t);
+  t->numerator_sum = f[0]; t->denominator_sum = f[1]; t->pi1_sum = f[2]; t->pi2_sum = f[3];
+  t->dxy_sum_all = f[4]; t->site_num_sum = f[5]; t->site_den_sum = f[6]; t->site_dxy_sum = f[7];
+  t->pop[0].pi_sum = f[8]; t->pop[1].pi_sum = f[9];
+  t->dxy_uncallable_sites = u[0]; t->sites_with_components = u[1]; t->site_dxy_skipped = u[2];
+  t->pop[0].segregating_sites = u[3]; t->pop[0].uncallable_sites = u[4];
+  t->pop[1].segregating_sites = u[5]; t->pop[1].uncallable_sites = u[6];
+  const uint64_t ranks = u[9] ? u[9] : 1;
+  t->pop[0].haplotype_capacity = u[7] / ranks;
+  t->pop[1].haplotype_capacity = u[8] / ranks;
+  return FMH_OK;
+}
+
+extern "C" int fmh_pop_totals_pack(const fmh_pop_totals* t, int n, double* f, uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n < 1 || n > FMH_MAX_GROUPS_MANY) return fail(FMH_ERR_INVALID, "population count %d out of range", n);
+  for (int p = 0; p < n; ++p) {
+    f[p] = t[p].pi_sum;
+    u[3 * p + 0] = t[p].segregating_sites;
+    u[3 * p + 1] = t[p].uncallable_sites;
+    u[3 * p + 2] = t[p].haplotype_capacity;  // identical on every rank; divide after a sum
+  }
+  u[3 * n] = 1;  // ranks summed
+  return FMH_OK;
+}
+
+extern "C" int fmh_pop_totals_unpack(fmh_pop_totals* t, int n, const double* f, const uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n < 1 || n > FMH_MAX_GROUPS_MANY) return fail(FMH_ERR_INVALID, "population count %d out of range", n);
+  const uint64_t ranks = u[3 * n] ? u[3 * n] : 1;
+  for (int p = 0; p < n; ++p) {
+    t[p].pi_sum = f[p];
+    t[p].segregating_sites = u[3 * p + 0];
+    t[p].uncallable_sites = u[3 * p + 1];
+    t[p].haplotype_capacity = u[3 * p + 2] / ranks;
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_wc_totals_pack(const fmh_wc_totals* t, int n_groups, double* f, uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n_groups < 2 || n_groups > FMH_MAX_GROUPS) return fail(FMH_ERR_INVALID, "n_groups %d out of range 2..%d", n_groups, FMH_MAX_GROUPS);
+  const int slots = 1 + n_groups * (n_groups - 1) / 2;
+  for (int k = 0; k < slots; ++k) { f[k] = t->sum_a[k]; f[slots + k] = t->sum_b[k]; u[k] = t->informative_sites[k]; }
+  u[slots] = t->sites_attempted;  // rows swept: a plain sum over slabs
+  return FMH_OK;
+}
+
+extern "C" int fmh_wc_totals_unpack(fmh_wc_totals* t, int n_groups, const double* f, const uint64_t* u) {
+  if (!t || !f || !u) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (n_groups < 2 || n_groups > FMH_MAX_GROUPS) return fail(FMH_ERR_INVALID, "n_groups %d out of range 2..%d", n_groups, FMH_MAX_GROUPS);
+  const int slots = 1 + n_groups * (n_groups - 1) / 2;
+  memset(t, 0, sizeof *t);
+  for (int k = 0; k < slots; ++k) { t->sum_a[k] = f[k]; t->sum_b[k] = f[slots + k]; t->informative_sites[k] = u[k]; }
+  t->sites_attempted = u[slots];
+  return FMH_OK;
+}

@@ -12,6 +12,7 @@
 #include <pybind11/stl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -67,8 +68,27 @@ int64_t sat_sub(int64_t a, int64_t b) {
 // ---------------------------------------------------------------------------------------------------------------
 // device plumbing (RAII over the C-ABI handles)
 // ---------------------------------------------------------------------------------------------------------------
+// Which GPU new matrices go to: FERROMIC_HIP_DEVICES (a device index or a comma-separated list whose
+// first entry is taken - one process drives one GPU on this path), else device 0; ferromic.set_device() overrides it.
+// A matrix stays on the device it was uploaded to, and so do the buffers of every statistic computed from it.
+std::atomic<int> g_device{-1};
+int current_device() {
+  int d = g_device.load();
+  if (d >= 0) return d;
+  d = 0;
+  if (const char* env = getenv("FERROMIC_HIP_DEVICES")) {
+    char* end = nullptr;
+    const long v = strtol(env, &end, 10);
+    if (end == env || v < 0 || v > 63 || (*end != '\0' && *end != ',')) value_error(string("FERROMIC_HIP_DEVICES: cannot read a device index from \"") + env + "\"");
+    d = (int)v;
+  }
+  g_device.store(d);
+  return d;
+}
+
 struct DevMatrix {
   fmh_matrix* h = nullptr;
+  int device = 0;
   size_t variants = 0, samples = 0, ploidy = 0;
   ~DevMatrix() { if (h) fmh_matrix_destroy(h); }
   size_t columns() const { return samples * ploidy; }
@@ -78,10 +98,11 @@ shared_ptr<DevMatrix> upload_matrix(const uint8_t* data, const uint64_t* missing
                                     uint8_t max_allele) {
   auto m = std::make_shared<DevMatrix>();
   m->variants = variants; m->samples = samples; m->ploidy = ploidy;
+  m->device = current_device();
   int rc;
   {
     py::gil_scoped_release nogil;
-    rc = fmh_matrix_create(data, missing_words, variants, samples, ploidy, max_allele, 0, &m->h);
+    rc = fmh_matrix_create(data, missing_words, variants, samples, ploidy, max_allele, m->device, &m->h);
   }
   fmh_check(rc);
   return m;
@@ -112,14 +133,15 @@ struct Groups {
 
 struct DevBuf {
   void* p = nullptr;
-  explicit DevBuf(size_t bytes) { fmh_check(fmh_device_alloc(0, std::max<size_t>(bytes, 1), &p)); }
+  int device = 0;
+  DevBuf(int dev, size_t bytes) : device(dev) { fmh_check(fmh_device_alloc(device, std::max<size_t>(bytes, 1), &p)); }
   DevBuf(const DevBuf&) = delete;
-  ~DevBuf() { if (p) fmh_device_free(0, p); }
+  ~DevBuf() { if (p) fmh_device_free(device, p); }
   template <class T> vector<T> fetch(size_t n) const {
     vector<T> out(n);
     if (n) {
       int rc;
-      { py::gil_scoped_release nogil; rc = fmh_copy_to_host(0, out.data(), p, n * sizeof(T), nullptr); }
+      { py::gil_scoped_release nogil; rc = fmh_copy_to_host(device, out.data(), p, n * sizeof(T), nullptr); }
       fmh_check(rc);
     }
     return out;

@@ -2,18 +2,89 @@
 
 Sites are independent units: rank r owns one contiguous genomic slab and sweeps only that slab;
 per-site tracks never leave the owning GPU.  The only exchange step is the sum of the regional
-accumulators (20 scalars for a Hudson pair), done with one all-reduce over RCCL/xGMI
-(torch.distributed backend "nccl" on ROCm) — latency-bound, a few microseconds of payload.
-Integer totals are exact; f64 totals are summed rank-by-rank by the collective, inside the
-1e-9 contract.
+accumulators, a few hundred bytes - latency-bound.  Integer totals are exact; f64 totals are summed
+in the collective's order, inside the 1e-9 contract.
+
+Two carriers of that sum:
+  * `Comm` - the product path: libferromic_hip.so's own communicator (fmh_comm_*), RCCL over xGMI
+    issued by the library on its own stream, with the pipelined fmh_hudson_sweep_sharded_begin/_end.
+  * `allreduce_*_totals(..., dist, device)` - the packed vectors through torch.distributed: the "any
+    other transport" form of the same packing (gloo in the CPU tests and in the one-GPU rehearsal).
 """
 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
+from typing import List, Sequence, Tuple
 
 from . import _abi
+
+
+class Comm:
+    """fmh_comm handle.  One process per GPU: `from_torch_distributed` lets rank 0 create the RCCL id and ships its
+    128 bytes through the process group the launcher set up (any backend; CPU tensors); one process: `single`."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+        lib = _abi.load()
+        w, r, d, t = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _abi.check(lib.fmh_comm_info(handle, C.byref(w), C.byref(r), C.byref(d), C.byref(t)))
+        self.world, self.rank, self.device, self.transport = w.value, r.value, d.value, ("rccl", "host")[t.value]
+
+    @classmethod
+    def from_unique_id(cls, uid: bytes, world: int, rank: int, device: int) -> "Comm":
+        if len(uid) != _abi.COMM_ID_BYTES:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        buf = (C.c_char * _abi.COMM_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        _abi.check(_abi.load().fmh_comm_init_rank(buf, world, rank, device, C.byref(h)))
+        return cls(h.value)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * _abi.COMM_ID_BYTES)()
+        _abi.check(_abi.load().fmh_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def single(cls, device: int = 0) -> "Comm":
+        """A one-rank communicator (the collective is then an identity, but runs through RCCL all the same)."""
+        return cls.from_unique_id(cls.unique_id(), 1, 0, device)
+
+    @classmethod
+    def from_torch_distributed(cls, dist, device: int) -> "Comm":
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.from_unique_id(box[0], world, rank, device)
+
+    @classmethod
+    def init_all(cls, devices: Sequence[int]) -> List["Comm"]:
+        """One process driving several GPUs (one thread each); a device listed twice selects the in-process host rendezvous."""
+        n = len(devices)
+        arr = (C.c_int * n)(*devices)
+        out = (C.c_void_p * n)()
+        _abi.check(_abi.load().fmh_comm_init_all(arr, n, out))
+        return [cls(out[i]) for i in range(n)]
+
+    def allreduce(self, f64: Sequence[float], u64: Sequence[int]):
+        """Element-wise sum over the ranks of one f64 and one u64 vector (fmh_allreduce_totals)."""
+        nf, nu = len(f64), len(u64)
+        f = (C.c_double * max(nf, 1))(*f64)
+        u = (C.c_uint64 * max(nu, 1))(*u64)
+        _abi.check(_abi.load().fmh_allreduce_totals(self._h, f, nf, u, nu))
+        return list(f)[:nf], [int(x) for x in u][:nu]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _abi.load().fmh_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def slab_for_rank(total_sites: int, rank: int, world: int) -> Tuple[int, int]:
@@ -84,3 +155,43 @@ class HudsonTotalsPipeline:
             self._collect(self.pending)
             self.pending = None
         return self.latest
+
+
+def _sum_vectors(f64, u64, dist, device):
+    """One collective for both vectors: the counts ride as f64 (exact below 2^53, refused above)."""
+    import torch
+
+    ints = [int(x) for x in u64]
+    if any(x >= _EXACT_IN_F64 for x in ints):
+        raise OverflowError("a count accumulator reached 2^53: reduce the integer totals separately")
+    t = torch.tensor(list(f64) + [float(x) for x in ints], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    v = t.cpu().tolist()
+    return v[:len(f64)], [int(x) for x in v[len(f64):]]
+
+
+def allreduce_wc_totals(totals: _abi.WcTotals, n_groups: int, dist, device) -> _abi.WcTotals:
+    """W&C regional sums of every slot (calculate_overall_fst_wc, stats.rs:2145-2374) summed over the ranks."""
+    lib = _abi.load()
+    slots = 1 + n_groups * (n_groups - 1) // 2
+    f = (C.c_double * (2 * slots))()
+    u = (C.c_uint64 * (slots + 1))()
+    _abi.check(lib.fmh_wc_totals_pack(C.byref(totals), n_groups, f, u))
+    fs, us = _sum_vectors(list(f), list(u), dist, device)
+    out = _abi.WcTotals()
+    _abi.check(lib.fmh_wc_totals_unpack(C.byref(out), n_groups, (C.c_double * (2 * slots))(*fs), (C.c_uint64 * (slots + 1))(*us)))
+    return out
+
+
+def allreduce_pop_totals(totals: Sequence[_abi.PopTotals], dist, device) -> List[_abi.PopTotals]:
+    """Per-population summaries (build_dense_population_summary's fold/reduce, stats.rs:1365-1461) summed over the ranks."""
+    lib = _abi.load()
+    n = len(totals)
+    arr = (_abi.PopTotals * n)(*totals)
+    f = (C.c_double * n)()
+    u = (C.c_uint64 * (3 * n + 1))()
+    _abi.check(lib.fmh_pop_totals_pack(arr, n, f, u))
+    fs, us = _sum_vectors(list(f), list(u), dist, device)
+    out = (_abi.PopTotals * n)()
+    _abi.check(lib.fmh_pop_totals_unpack(out, n, (C.c_double * n)(*fs), (C.c_uint64 * (3 * n + 1))(*us)))
+    return list(out)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FMH_ABI_VERSION 1
+#define FMH_ABI_VERSION 2
 #define FMH_MAX_GROUPS 8 /* populations per sweep */
 #define FMH_MAX_PAIRS 28 /* FMH_MAX_GROUPS choose 2 */
 
@@ -67,6 +67,8 @@ int fmh_device_info(int device, char* h_name, size_t name_cap, int* h_compute_un
 
 /* ---- raw device memory helpers for hosts that do not bring their own allocator --------------- */
 int fmh_device_alloc(int device, size_t bytes, void** d_out);
+/* Blocks are recycled through a pool without stream ordering: the caller's outstanding stream work on the block must be
+ * complete (every fmh_* call that fills host totals has synchronised its stream; fmh_device_zero has not). */
 int fmh_device_free(int device, void* d_ptr);
 int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
 int fmh_copy_to_device(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
@@ -86,7 +88,9 @@ int fmh_device_release_scratch(int device);
  * plane per allele bit plus one "called" plane, 128 columns per 16-byte vector - and the sweeps read 1/8 (1/4 with
  * alleles 2..3) of the bytes the u8 layout would cost; the bytes only pass through a staging slab.  Other matrices
  * (max_allele > 3, rows beyond 600 000 columns, FMH_LAYOUT=bytes) keep the u8 rows, padded to a 16-byte pitch, with the
- * missing bitset re-laid as one "called" bit-row per site.  Values above max_allele are a caller error.
+ * missing bitset re-laid as one "called" bit-row per site.  A called value above max_allele is a caller error: the packed
+ * layout would lose its high bits, so fmh_matrix_create / fmh_matrix_pack detect it on the device and return
+ * FMH_ERR_INVALID (the u8 layout keeps the bytes as they are and only uses max_allele as a loop bound).
  */
 int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing_or_null, size_t variants,
                       size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out);
@@ -95,7 +99,7 @@ int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, int with_mi
                      int device, fmh_matrix** out);
 /* Wrap caller-owned device memory (e.g. a torch uint8 tensor): d_data rows of `pitch` bytes
  * (pitch % 16 == 0, pitch >= samples*ploidy); d_called_bits_or_null rows of `bits_pitch` bytes
- * (bit h of a row set = entry h is called; bits_pitch % 4 == 0). The wrapper never frees them. */
+ * (bit h of a row set = entry h is called; bits_pitch % 4 == 0, 4-byte aligned). The wrapper never frees them. */
 int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_called_bits_or_null, size_t bits_pitch,
                     size_t variants, size_t samples, size_t ploidy, uint8_t max_allele, int device,
                     fmh_matrix** out);
@@ -267,17 +271,79 @@ int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_mask, int n_g
 int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, unsigned long long* d_diff,
                              unsigned long long* d_both, void* stream);
 
-/* ---- multi-GPU ---------------------------------------------------------------------------------- */
+/* ---- multi-GPU: region sharding + RCCL reduce of the regional accumulators -------------------------------- */
 /*
- * The region-sharded totals are plain sums: these pack/unpack them into the f64 + u64 vectors a
- * single all-reduce(sum) moves (RCCL via torch.distributed, or MPI/any other transport).  Integer
- * totals are exact; f64 totals are order-dependent within 1e-9.
+ * Sites are independent: rank r of G sweeps only its contiguous slab of the region and writes its own
+ * per-site tracks; the only exchange is the SUM of the regional accumulators - what the reference's rayon fold/reduce
+ * does across its worker threads (stats.rs:1365-1461 for the summaries, the serial sums of 1554-1623 and 2145-2374
+ * for Hudson and W&C).  A communicator carries that sum over RCCL (xGMI inside a node): one ncclAllReduce per vector
+ * type, a few hundred bytes, latency-bound.  RCCL is bound at run time (dlopen), so single-GPU hosts never load it.
+ * Integer totals are exact; f64 totals depend on the reduction order (1e-9 contract, as with rayon).
+ *
+ *   one process per GPU (MPI / torch.distributed.run):  rank 0 calls fmh_comm_get_unique_id, ships the 128 bytes to the
+ *     other ranks over any channel, every rank calls fmh_comm_init_rank.
+ *   one process, several GPUs (run_vcf --devices):       fmh_comm_init_all; each device's thread then uses its own handle
+ *     concurrently.  When a device appears more than once in the list (rehearsal on a one-GPU box) or
+ *     FMH_COMM_TRANSPORT=host is set, the handles share an in-process rendezvous that sums in rank order on the host
+ *     instead - RCCL cannot place two ranks on one GPU.
+ */
+typedef struct fmh_comm fmh_comm;
+#define FMH_COMM_ID_BYTES 128
+int fmh_comm_get_unique_id(void* h_id /*[FMH_COMM_ID_BYTES]*/);
+int fmh_comm_init_rank(const void* h_id, int world, int rank, int device, fmh_comm** out);
+int fmh_comm_init_all(const int* h_devices, int n, fmh_comm** h_out /*[n]*/);
+int fmh_comm_destroy(fmh_comm* c);
+/* transport: 0 = RCCL, 1 = in-process host rendezvous */
+int fmh_comm_info(const fmh_comm* c, int* world, int* rank, int* device, int* transport);
+
+/* Element-wise sum over all ranks, in place, blocking (collective: every rank calls it with the same lengths;
+ * n_f64, n_u64 <= FMH_COMM_MAX_VALUES). */
+#define FMH_COMM_MAX_VALUES 512
+int fmh_allreduce_totals(fmh_comm* c, double* h_f64, size_t n_f64, uint64_t* h_u64, size_t n_u64);
+/* The same in two halves: _begin enqueues the reduce on the communicator's own stream and returns, _end waits for it
+ * and writes the sums.  One reduce may be in flight per communicator. */
+int fmh_allreduce_totals_begin(fmh_comm* c, const double* h_f64, size_t n_f64, const uint64_t* h_u64, size_t n_u64);
+int fmh_allreduce_totals_end(fmh_comm* c, double* h_f64, uint64_t* h_u64);
+
+/*
+ * Region-sharded Hudson sweep: this rank's rows [row_begin, row_begin + row_count) of ITS slab matrix, then the sum of the
+ * regional accumulators over all ranks - fmh_hudson_sweep + fmh_allreduce_totals without a host hop in between: the
+ * partials are finalised on the device, reduced there by RCCL on the communicator's stream and land in pinned memory.
+ * _begin returns as soon as the work is enqueued (up to FMH_SHARDED_IN_FLIGHT sweeps per communicator), _end waits for
+ * the OLDEST outstanding one and returns its region-wide totals (pop[].haplotype_capacity is the local mask popcount,
+ * identical on every rank).  A loop `begin(k); if (k) end(k-1)` overlaps the reduce of one window with the sweep of the
+ * next, which is what keeps small slabs (1.25 M sites x 5 000 haplotypes is 0.16 ms of kernel) from paying the
+ * collective's latency.  fmh_hudson_sweep_sharded = _begin + _end.
+ */
+#define FMH_SHARDED_IN_FLIGHT 2
+int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                   int formula, const fmh_hudson_sites* sites_or_null, void* stream);
+int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* h_global_totals);
+int fmh_hudson_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                             int formula, const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_global_totals, void* stream);
+
+/*
+ * Packing of the totals structs into the f64 + u64 vectors a sum-reduce moves (fmh_allreduce_totals, or MPI / any other
+ * transport).  Everything packed is a plain sum over slabs, except haplotype_capacity / sites_attempted-style constants,
+ * which unpack restores from the rank count carried in the last u64 slot.
  */
 #define FMH_HUDSON_PACK_F64 10
 #define FMH_HUDSON_PACK_U64 10
 int fmh_hudson_totals_pack(const fmh_hudson_totals* t, double* h_f64 /*[FMH_HUDSON_PACK_F64]*/,
                            uint64_t* h_u64 /*[FMH_HUDSON_PACK_U64]*/);
 int fmh_hudson_totals_unpack(fmh_hudson_totals* t, const double* h_f64, const uint64_t* h_u64);
+/* per-population summaries (fmh_population_summaries, fmh_diversity_sites): n entries -> n f64 (pi_sum) and 3n + 1 u64
+ * (segregating, uncallable, haplotype_capacity per population, then the rank count) */
+#define FMH_POP_PACK_F64(n) ((size_t)(n))
+#define FMH_POP_PACK_U64(n) (3 * (size_t)(n) + 1)
+int fmh_pop_totals_pack(const fmh_pop_totals* t, int n, double* h_f64, uint64_t* h_u64);
+int fmh_pop_totals_unpack(fmh_pop_totals* t, int n, const double* h_f64, const uint64_t* h_u64);
+/* W&C regional sums (calculate_overall_fst_wc, stats.rs:2145-2374): slots = 1 + n_groups (n_groups - 1) / 2 ->
+ * 2 * slots f64 (sum_a, sum_b) and slots + 1 u64 (informative_sites per slot, sites_attempted) */
+#define FMH_WC_PACK_F64(slots) (2 * (size_t)(slots))
+#define FMH_WC_PACK_U64(slots) ((size_t)(slots) + 1)
+int fmh_wc_totals_pack(const fmh_wc_totals* t, int n_groups, double* h_f64, uint64_t* h_u64);
+int fmh_wc_totals_unpack(fmh_wc_totals* t, int n_groups, const double* h_f64, const uint64_t* h_u64);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* Accumulated HIP-event time (ms) and launch count of the dominant sweep kernel since the last

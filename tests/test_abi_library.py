@@ -36,7 +36,7 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(lib, name), f"{name} declared in include/ferromic_hip.h but not exported"
         assert name in _abi.SYMBOLS, f"{name} has no ctypes prototype in ferromic_amd/_abi.py"
     assert sorted(_abi.SYMBOLS) == names
-    assert lib.fmh_abi_version() == 1
+    assert lib.fmh_abi_version() == 2
 
 
 def test_struct_layouts_match_header(lib):

@@ -1,5 +1,6 @@
 """bench.py's N > 1 path rehearsed on one GPU: two ranks (gloo, both on cuda:0) each own a slab of the cohort,
-sweep it and all-reduce the 20 accumulators; the combined totals must equal one rank sweeping both slabs."""
+sweep it and sum the accumulators; the combined totals must equal one rank sweeping both slabs.  The library's own RCCL
+communicator is exercised with a one-rank group (tests/test_gpu_comm.py covers its in-process multi-rank transport)."""
 
 import json
 import os
@@ -23,28 +24,46 @@ def run(cmd):
 
 
 def test_two_ranks_equal_one_rank():
+    """Two ranks on one GPU (accumulators summed through torch.distributed/gloo: RCCL cannot place two ranks on one device), weak and
+    strong scaling, against one rank sweeping the same cohort."""
     S = 300_000
     common = ["--steps", "2", "--warmup", "1", "--haplotypes", "1000", "--no-cpu-baseline"]
-    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29541", "bench.py", "--gpus", "2", "--sites", str(S), "--backend", "gloo", "--rehearse-on-one-device"] + common)
-    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["steps"] == 2
-    assert two["value"] == pytest.approx(2 * S * 2 / (two["ms_per_step"] * 2 / 1e3), rel=1e-6)  # whole-job sites / max-over-ranks time
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    rehearse = ["--transport", "torch", "--backend", "gloo", "--rehearse-on-one-device"]
+    weak = run(launch + ["--master-port", "29541", "bench.py", "--gpus", "2", "--sites", str(S), "--scaling", "weak", "--no-secondary"] + rehearse + common)
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["steps"] == 2 and weak["config"]["sites_per_gpu"] == S
+    assert weak["value"] == pytest.approx(2 * S * 2 / (weak["ms_per_step"] * 2 / 1e3), rel=1e-6)  # whole-job sites / max-over-ranks time
+    strong = run(launch + ["--master-port", "29542", "bench.py", "--gpus", "2", "--sites", str(2 * S)] + rehearse + common)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["sites_per_gpu"] == S and strong["config"]["total_sites"] == 2 * S
+    assert strong["value"] == pytest.approx(2 * S * 2 / (strong["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert strong["secondary"]["scaling"] == "weak" and strong["secondary"]["sites_per_gpu"] == 2 * S and strong["secondary"]["total_sites"] == 4 * S
     # the same 2 x S sites generated and swept by one rank (same seed recipe: seed = total sites + samples)
     one = run([sys.executable, "bench.py", "--sites", str(2 * S)] + common)
-    assert one["config"]["seed"] == two["config"]["seed"]
-    assert one["results"]["segregating_sites"] == two["results"]["segregating_sites"]
-    for a, b in zip(one["results"]["pi_sum"], two["results"]["pi_sum"]):
-        assert a == pytest.approx(b, rel=1e-9)
-    assert one["results"]["hudson_fst"] == pytest.approx(two["results"]["hudson_fst"], rel=1e-9)
+    assert one["scaling"] == "strong" and "secondary" not in one
+    for two in (weak, strong):
+        assert one["config"]["seed"] == two["config"]["seed"]
+        assert one["results"]["segregating_sites"] == two["results"]["segregating_sites"]
+        for a, b in zip(one["results"]["pi_sum"], two["results"]["pi_sum"]):
+            assert a == pytest.approx(b, rel=1e-9)
+        assert one["results"]["hudson_fst"] == pytest.approx(two["results"]["hudson_fst"], rel=1e-9)
+
+
+def test_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher): the script starts torch.distributed.run itself before touching the GPU."""
+    d = run([sys.executable, "bench.py", "--gpus", "2", "--sites", "200000", "--haplotypes", "400", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--no-secondary", "--transport", "torch", "--backend", "gloo", "--rehearse-on-one-device"])
+    assert d["n_gpus"] == 2 and d["config"]["sites_per_gpu"] == 100000 and d["scaling"] == "strong"
 
 
 def test_rccl_collective_path_with_one_rank():
-    """The collective step through RCCL itself (backend nccl, a one-rank group): async all-reduce on RCCL's stream, collected
-    one step later, flushed by the fence - same totals as the run without it, and both layouts' roofline blocks present."""
+    """The sharded path through the library's own RCCL communicator (a one-rank group): sweep, device-side finalise, ncclAllReduce on the
+    communicator's stream, pipelined one step deep - same totals as the run without it, and both layouts' roofline blocks present."""
     common = ["--steps", "4", "--warmup", "1", "--sites", "250000", "--haplotypes", "1000", "--no-cpu-baseline"]
     plain = run([sys.executable, "bench.py"] + common)
     coll = run([sys.executable, "bench.py", "--force-collective"] + common)
+    assert "RCCL" in coll["config"]["parallelism"] and "no collective" in plain["config"]["parallelism"]
     assert coll["results"] == plain["results"]
+    assert coll["roofline"]["kernel_ms_avg"] > 0  # HIP events of the pipelined launches
     for d in (plain, coll):
         r = d["roofline"]
         assert r["algorithmic_bytes_per_site"] == 125 + 56 and r["u8_layout_bytes_per_site"] == 1000 + 56
@@ -65,12 +84,12 @@ def test_bench_line_contract():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "strong"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "sites/s" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] == pytest.approx(200000 * 3 / (d["ms_per_step"] * 3 / 1e3), rel=1e-6)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
-    assert "traffic" in r and r["algorithmic_bytes_per_site"] == 50 + 56
+    assert "traffic" in r and "traffic_source" in r and r["algorithmic_bytes_per_site"] == 50 + 56
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "sites/s" and "sample" in c
+    assert c["kind"] == "port" and 1 <= c["cores"] == c["cores_usable"] <= c["cores_visible"] and c["value"] > 0 and c["unit"] == "sites/s" and "sample" in c
     assert c["parity_vs_gpu"]["alt_counts_bit_exact"] is True and c["parity_vs_gpu"]["per_site_f64_max_rel_err"] <= 1e-9

@@ -3,7 +3,7 @@
 (in this code base: the DPP ops of the 16-lane row reductions) needs 3 wait states, and hipcc (ROCm 7.2) left only
 2 when the last dot4 of a loop and the reduction sat in different basic blocks - the reduction then missed that dot4.
 
-Compiles the device code of ferromic_amd/csrc/abi.hip to assembly (hipcc, no GPU needed) and walks every v_dot4:
+Compiles the device code of every ferromic_amd/csrc/*.hip to assembly (hipcc, no GPU needed) and walks every v_dot4:
 following fall-through paths and branch targets (s_nop N counts N + 1 wait states, every other instruction 1), a read of the result by
 anything but the accumulator operand of another v_dot4 within fewer than 3 wait states is reported.
 Exit code 1 when anything is reported.  Usage: tools/scan_dot4_hazard.py [existing.s]
@@ -21,10 +21,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NEEDED = 3
 
 
-def device_asm(path: str) -> None:
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-           "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", path, os.path.join(ROOT, "ferromic_amd", "csrc", "abi.hip")]
+def device_asm(path: str, source: str) -> None:
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", path, source]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def all_units_asm(tmp: str) -> list:
+    """One .s per translation unit of the library, compiled a few at a time."""
+    import glob
+    from concurrent.futures import ThreadPoolExecutor
+
+    sources = sorted(glob.glob(os.path.join(ROOT, "ferromic_amd", "csrc", "*.hip")))
+    outs = [os.path.join(tmp, os.path.basename(src)[:-4] + ".s") for src in sources]
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        list(pool.map(lambda so: device_asm(so[1], so[0]), zip(sources, outs)))
+    return outs
 
 
 def regs(tok: str) -> set:
@@ -105,12 +117,15 @@ def scan(path: str):
 
 def main() -> int:
     if len(sys.argv) > 1:
-        path, tmp = sys.argv[1], None
+        paths, tmp = sys.argv[1:], None
     else:
         tmp = tempfile.mkdtemp(prefix="fmh_asm_")
-        path = os.path.join(tmp, "abi.s")
-        device_asm(path)
-    dots, findings = scan(path)
+        paths = all_units_asm(tmp)
+    dots, findings = 0, []
+    for path in paths:
+        d, f = scan(path)
+        dots += d
+        findings += f
     for fn, no, waits, text in findings:
         print(f"{fn}: line {no}: dot4 result read after {waits} wait state(s) by `{text}`")
     print(f"{dots} v_dot4 instructions scanned, {len(findings)} hazard(s)")
