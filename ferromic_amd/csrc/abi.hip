@@ -18,6 +18,7 @@
 
 #include "abi_internal.hpp"
 #include "util_kernels.hpp"
+#include "sweep_mfma_kernels.hpp"
 #include "wc_counts_kernels.hpp"
 
 using namespace fmh;
@@ -245,7 +246,7 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
 // ---- bit-packed image -------------------------------------------------------------------------------------------
 // Rows wider than this keep the byte layout: their masks would not fit LDS even as bits for two groups.
 static const uint32_t kPackMaxColumns = 600000;
-static bool packable(uint8_t max_allele, uint32_t columns) { return max_allele <= 3 && columns <= kPackMaxColumns; }
+static bool packable(uint8_t max_allele, uint32_t columns) { return max_allele <= 7 && columns <= kPackMaxColumns; }
 
 static int alloc_planes(fmh_matrix* m) {
   m->plane_pitch = round_up(((size_t)m->columns + 7) / 8, 16);
@@ -253,17 +254,18 @@ static int alloc_planes(fmh_matrix* m) {
   const size_t bytes = std::max<size_t>(m->variants, 1) * m->plane_pitch;
   hipError_t e = pool_malloc(m->device, (void**)&m->p0, bytes);
   if (e == hipSuccess && m->max_allele >= 2) e = pool_malloc(m->device, (void**)&m->p1, bytes);
+  if (e == hipSuccess && m->max_allele >= 4) e = pool_malloc(m->device, (void**)&m->p2, bytes);
   if (e == hipSuccess && m->has_missing) e = pool_malloc(m->device, (void**)&m->pc, bytes);
   if (e != hipSuccess) {
-    pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->pc);
-    m->p0 = m->p1 = m->pc = nullptr;
+    pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->p2); pool_free(m->device, m->pc);
+    m->p0 = m->p1 = m->p2 = m->pc = nullptr;
     return fail(FMH_ERR_HIP, "hipMalloc of the %zu-byte packed planes failed: %s", bytes, hipGetErrorString(e));
   }
   return FMH_OK;
 }
 static void free_planes(fmh_matrix* m) {
-  pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->pc);
-  m->p0 = m->p1 = m->pc = nullptr;
+  pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->p2); pool_free(m->device, m->pc);
+  m->p0 = m->p1 = m->p2 = m->pc = nullptr;
 }
 // byte rows (and, when `bits` is given, their called rows) -> planes rows [row0, row0 + rows)
 // `d_overflow` (one zeroed device word, may be null) is set when a called entry carries an allele bit the planes do not store
@@ -274,16 +276,16 @@ static hipError_t pack_rows(fmh_matrix* m, const uint8_t* data, size_t pitch, co
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
   const size_t off = row0 * m->plane_pitch;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, data, pitch, bits, bits_pitch, rows, m->columns, m->p0 + off,
-                     m->p1 ? m->p1 + off : nullptr, m->pc ? m->pc + off : nullptr, m->plane_pitch, d_overflow);
+                     m->p1 ? m->p1 + off : nullptr, m->p2 ? m->p2 + off : nullptr, m->pc ? m->pc + off : nullptr, m->plane_pitch, d_overflow);
   return hipGetLastError();
 }
 // planes rows [row0, row0 + rows) -> byte rows of `pitch` bytes
-static hipError_t unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* data, size_t pitch, hipStream_t st) {
+hipError_t fmhi::unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* data, size_t pitch, hipStream_t st) {
   if (rows == 0) return hipSuccess;
   const size_t total = rows * (pitch / 16);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
   const size_t off = row0 * m->plane_pitch;
-  hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, st, m->p0 + off, m->p1 ? m->p1 + off : nullptr, m->plane_pitch, rows, data, pitch);
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, st, m->p0 + off, m->p1 ? m->p1 + off : nullptr, m->p2 ? m->p2 + off : nullptr, m->plane_pitch, rows, data, pitch);
   return hipGetLastError();
 }
 
@@ -291,10 +293,10 @@ extern "C" int fmh_matrix_pack(fmh_matrix* m, int release_bytes) {
   if (!m) return fail(FMH_ERR_INVALID, "matrix is NULL");
   if (!m->data) return m->p0 ? FMH_OK : fail(FMH_ERR_INVALID, "matrix has no byte image to pack");
   if (!packable(m->max_allele, m->columns))
-    return fail(FMH_ERR_UNSUPPORTED, "the packed layout holds alleles 0..3 on rows of at most %u columns (max_allele %u, %u columns)", kPackMaxColumns,
+    return fail(FMH_ERR_UNSUPPORTED, "the packed layout holds alleles 0..7 on rows of at most %u columns (max_allele %u, %u columns)", kPackMaxColumns,
                 (unsigned)m->max_allele, m->columns);
   FMH_TRY(use_device(m->device));
-  if (m->p0 && ((m->max_allele >= 2) != (m->p1 != nullptr))) free_planes(m);  // max_allele changed since the last pack
+  if (m->p0 && (((m->max_allele >= 2) != (m->p1 != nullptr)) || ((m->max_allele >= 4) != (m->p2 != nullptr)))) free_planes(m);  // max_allele changed since the last pack
   if (!m->p0) FMH_TRY(alloc_planes(m));
   unsigned int* d_overflow = nullptr;
   unsigned int overflow = 0;
@@ -525,7 +527,7 @@ extern "C" int fmh_matrix_scan_max_allele(const fmh_matrix* m, uint8_t* h_max, v
   } else if (e == hipSuccess && m->variants) {
     const size_t total = m->variants * (m->plane_pitch / 4);
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(packed_max_allele_kernel, dim3(blocks), dim3(256), 0, st, m->p0, m->p1, m->pc, m->plane_pitch, m->variants, d_out);
+    hipLaunchKernelGGL(packed_max_allele_kernel, dim3(blocks), dim3(256), 0, st, m->p0, m->p1, m->p2, m->pc, m->plane_pitch, m->variants, d_out);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(&host, d_out, 4, hipMemcpyDeviceToHost, st);
@@ -724,6 +726,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   if (packed) {
     a.mv.data = m->p0;
     a.mv.data1 = m->p1;
+    a.mv.data2 = m->p2;
     a.mv.bits = m->pc;
     a.mv.pitch = m->plane_pitch;
     a.mv.bits_pitch = m->plane_pitch;
@@ -732,6 +735,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     if (!m->data) return fail(FMH_ERR_INVALID, "matrix holds neither a byte nor a packed image");
     a.mv.data = m->data;
     a.mv.data1 = nullptr;
+    a.mv.data2 = nullptr;
     a.mv.bits = m->bits;
     a.mv.pitch = m->pitch;
     a.mv.bits_pitch = m->bits_pitch;
@@ -784,9 +788,11 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;  // read per call: tests flip them
     const int env_lpr = getenv("FMH_PACKED_LPR") ? atoi(getenv("FMH_PACKED_LPR")) : 0;
     lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
+    // eight groups on the multi-allelic path: only the shallow batches are built (deeper ones spilled to scratch)
+    const bool shallow = general && P == 8;
     const int us4[4] = {1, 2, 3, 5}, us16[3] = {2, 3, 4};
     const int* us = lpr != 16 ? us4 : us16;
-    const int nus = lpr != 16 ? 4 : 3;
+    const int nus = shallow ? (lpr != 16 ? 2 : 1) : (lpr != 16 ? 4 : 3);
     int best_u = us[0];
     size_t best = SIZE_MAX;
     for (int k = 0; k < nus; ++k) {
@@ -806,7 +812,20 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     mask_mode = kMaskLdsBits;
     if (smem > kSweepLdsLimit) { smem = 0; mask_mode = kMaskGlobalBytes; }
   }
-  const char* force = packed ? nullptr : getenv("FMH_MASK_MODE");
+  // BASELINE config C5: the counts as an int8 matrix-core contraction (sweep_mfma_kernels.hpp), for u8 rows that are biallelic with
+  // nothing missing and at most four (padded) groups.  An alternative route: the contraction has <= 4 output rows and stays HBM-bound,
+  // so it is measured beside the dot4 route, not chosen by default.  Read per call: tests flip it.
+  const char* env_mfma = getenv("FMH_COUNTS_MFMA");
+  const int mfma_unroll = env_mfma && atoi(env_mfma) == 2 ? 2 : 4;
+  // (rows whose byte masks do not fit LDS stay on the dot4 routes)
+  const bool mfma = !packed && env_mfma && atoi(env_mfma) != 0 && !missing && !general && P <= 4 &&
+                    (size_t)P * mfma_mask_stride(m->nvec, mfma_unroll) * 16 <= kSweepLdsLimit;
+  if (mfma) {
+    a.unroll = mfma_unroll;
+    a.nvec_pad = mfma_mask_stride(m->nvec, a.unroll);
+    smem = (size_t)P * a.nvec_pad * 16;
+  }
+  const char* force = packed || mfma ? nullptr : getenv("FMH_MASK_MODE");
   if (force) {  // tests and measurements: take a slower mask route than needed
     const int want = atoi(force);
     const bool global_ok = P <= 2 && mode != kModeWc;
@@ -823,7 +842,10 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   if (mask_mode == kMaskGlobalBytes && (P > 2 || mode == kModeWc))
     return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
   int rc;
-  if (mask_mode == kMaskPacked) rc = lpr == 4 ? launch_sweep_packed4(P, mode, missing, general, a, smem, st, ctx, &grid) : launch_sweep_packed16(P, mode, missing, general, a, smem, st, ctx, &grid);
+  if (mfma) rc = launch_sweep_mfma(P, mode, a, smem, st, ctx, &grid);
+  else if (mask_mode == kMaskPacked && general && m->p2)  // alleles 4..7: three planes
+    rc = lpr == 4 ? launch_sweep_packed4_3p(P, mode, missing, general, a, smem, st, ctx, &grid) : launch_sweep_packed16_3p(P, mode, missing, general, a, smem, st, ctx, &grid);
+  else if (mask_mode == kMaskPacked) rc = lpr == 4 ? launch_sweep_packed4(P, mode, missing, general, a, smem, st, ctx, &grid) : launch_sweep_packed16(P, mode, missing, general, a, smem, st, ctx, &grid);
   else if (mask_mode == kMaskGlobalBytes) rc = launch_sweep_global(P, mode, missing, general, a, smem, st, ctx, &grid);
   else if (mask_mode == kMaskLdsBits) rc = launch_sweep_bits(P, mode, missing, general, a, smem, st, ctx, &grid);
   else rc = launch_sweep_bytes(P, mode, missing, general, a, smem, st, ctx, &grid);
@@ -1016,8 +1038,10 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
         }
       }
   }
-  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit) {
-    // rows too wide for all groups' masks to sit in LDS at once: count in smaller batches, components from the count tables
+  // the fused kernel for 5..8 groups keeps the counts of alleles 0..3 per site; cohorts with alleles beyond 3 take the counts route
+  const bool many_alleles8 = m && g && g->padded == 8 && m->max_allele > 3;
+  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit)) {
+    // (or: rows too wide for all groups' masks to sit in LDS at once) count in smaller batches, components from the count tables
     const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
     std::vector<double> sa(nslots), sb(nslots);
     std::vector<uint64_t> si(nslots);

@@ -116,6 +116,8 @@ struct SweepBuffers {
 struct fmh_matrix;
 struct fmh_groups;
 namespace fmhi {
+// planes rows [row0, row0 + rows) of a packed matrix -> byte rows of `pitch` bytes (abi.hip)
+hipError_t unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* data, size_t pitch, hipStream_t st);
 // sweep + finalize enqueued on `st`, no synchronisation (abi.hip)
 int enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, fmh::SweepArgs& a, hipStream_t st, const LaunchCtx& ctx,
                   const SweepBuffers& b, const double* harmonic, bool* launched);
@@ -124,9 +126,14 @@ int enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, fmh::Sweep
 // persistent grid and launches.  FMH_ERR_UNSUPPORTED for a combination the route does not build.
 int launch_sweep_packed4(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 int launch_sweep_packed16(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+// three-plane packed matrices (alleles 4..7): the multi-allelic kernels only
+int launch_sweep_packed4_3p(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+int launch_sweep_packed16_3p(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 int launch_sweep_bytes(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 int launch_sweep_bits(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 int launch_sweep_global(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+// counts on the int8 matrix cores (sweep_mfma.hip): u8 rows, biallelic, nothing missing, at most 4 (padded) groups
+int launch_sweep_mfma(int P, int mode, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 
 }  // namespace fmhi
 
@@ -141,9 +148,10 @@ struct fmh_matrix {
   uint8_t max_allele = 0;
   bool owns = true;
   bool has_missing = false;  // a called mask exists (bits and / or pc)
-  // bit-packed image (fmh_matrix_pack): p0 = allele & 1, p1 = allele >> 1 (max_allele 2..3), pc = called bits; plane_pitch
-  // bytes per row, pvec = ceil(columns / 128) 16-byte vectors.  data / bits may have been released (nullptr).
-  uint8_t *p0 = nullptr, *p1 = nullptr, *pc = nullptr;
+  // bit-packed image (fmh_matrix_pack): plane k = bit k of the allele value (p1: max_allele >= 2, p2: max_allele >= 4),
+  // pc = called bits; plane_pitch bytes per row, pvec = ceil(columns / 128) 16-byte vectors.  data / bits may have been
+  // released (nullptr).
+  uint8_t *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *pc = nullptr;
   size_t plane_pitch = 0;
   uint32_t pvec = 0;
 };

@@ -37,7 +37,10 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK) / kPdStageK * ksites;
   slab = std::min(round_up(m->variants, ksites), slab);
   // a matrix with a packed image feeds the planes kernel its bit rows (1/8 of the bytes); FMH_LAYOUT=bytes keeps the u8 route
-  const bool from_packed = m->p0 && !(m->data && layout_bytes_forced());
+  // (a three-plane image, alleles 4..7, is unpacked slab by slab into scratch bytes and takes the u8 planes kernel)
+  const bool packed_only = m->p0 && !(m->data && layout_bytes_forced());
+  const bool from_packed = packed_only && !m->p2;
+  const bool via_unpack = packed_only && m->p2;
   Workspace* w = nullptr;
   FMH_TRY(workspace(m->device, &w));
   std::lock_guard<std::mutex> busy(w->in_use);
@@ -64,6 +67,10 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   }
   const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
   static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
+  uint8_t* unpacked = nullptr;
+  if (via_unpack) {
+    HIP_TRY(hipMalloc((void**)&unpacked, std::min(slab, m->variants) * m->pitch));
+  }
   for (size_t row0 = 0; row0 < m->variants && e == hipSuccess; row0 += slab) {
     const size_t rows = std::min(slab, m->variants - row0);
     const size_t s_pad = round_up(rows, ksites);  // sites
@@ -86,14 +93,21 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
         hipLaunchKernelGGL(pd_planes_packed_kernel<false>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
                            (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
     } else {
-      if (!m->data) { e = hipErrorInvalidValue; break; }
+      if (!m->data && !via_unpack) { e = hipErrorInvalidValue; break; }
       MatrixView mv{};
       mv.pitch = m->pitch;
       mv.columns = m->columns;
       mv.nvec = m->nvec;
-      mv.data = m->data + row0 * m->pitch;
-      mv.bits = m->bits ? m->bits + row0 * m->bits_pitch : nullptr;
-      mv.bits_pitch = m->bits_pitch;
+      if (via_unpack) {
+        if ((e = unpack_rows(m, row0, rows, unpacked, m->pitch, st)) != hipSuccess) break;
+        mv.data = unpacked;
+        mv.bits = m->pc ? m->pc + row0 * m->plane_pitch : nullptr;  // a called plane row has the bit order of a called bit-row
+        mv.bits_pitch = m->plane_pitch;
+      } else {
+        mv.data = m->data + row0 * m->pitch;
+        mv.bits = m->bits ? m->bits + row0 * m->bits_pitch : nullptr;
+        mv.bits_pitch = m->bits_pitch;
+      }
       // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
       // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
       // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
@@ -169,6 +183,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (unpacked) { if (e != hipSuccess) (void)hipStreamSynchronize(st); (void)hipFree(unpacked); }
   if (e != hipSuccess) return fail(FMH_ERR_HIP, "pairwise differences failed: %s", hipGetErrorString(e));
   scratch.settled = true;
   return FMH_OK;

@@ -41,7 +41,8 @@ enum Formula : int { kFormulaSparse = 0, kFormulaDense = 1, kFormulaSummary = 2 
 
 struct MatrixView {
   const uint8_t* data;   // byte layout: genotype bytes; packed layout: bit plane 0 (allele & 1), one bit per column
-  const uint8_t* data1;  // packed layout with alleles 2..3: bit plane 1 (allele >> 1); else null
+  const uint8_t* data1;  // packed layout with alleles 2..7: bit plane 1 ((allele >> 1) & 1); else null
+  const uint8_t* data2;  // packed layout with alleles 4..7: bit plane 2 (allele >> 2); else null
   const uint8_t* bits;  // called bits, may be null
   size_t pitch;
   size_t bits_pitch;
@@ -474,9 +475,11 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
   if (MISSING && NEED_ALL) n_all = row16_sum(n_all);
 }
 
-// Bit-packed row (fmh_matrix_pack): plane 0 holds allele & 1, plane 1 (NPL == 2, alleles up to 3) allele >> 1, the called
-// plane one bit per column; masks are bit vectors too.  s0[p] = members with bit 0 set (the alt count when NPL == 1),
-// s1 / s01 as in count_row_planes, n[p] = called members, allele_or = OR of the called allele values.  Same batching as
+// Bit-packed row (fmh_matrix_pack): plane k holds bit k of the allele value (NPL planes: alleles up to 2^NPL - 1), the called
+// plane one bit per column; masks are bit vectors too.  For every non-empty subset T of the planes (index T - 1, T a bit set
+// over the planes) s[p][T - 1] = members whose allele has ALL bits of T set: s0 (the alt count when NPL == 1), s1, s01, s2,
+// s02, s12, s012.  The exact count of every allele value follows by inclusion-exclusion (allele_count_from_planes) without
+// touching the row again.  n[p] = called members, allele_or = OR of the called allele values.  Same batching as
 // the byte cores: U 16-byte vectors (128 columns each) per lane in flight, clamped addresses, zero-padded masks.
 // LPR lanes share a row: 16 (one DPP row, 256 B contiguous per load instruction) or 4 (one quad, 64 B per instruction and
 // a two-step reduction: packed rows are short - C4 is 40 vectors - and four lanes cover them with no idle slots).
@@ -485,59 +488,89 @@ __device__ __forceinline__ uint32_t popc128(const uint4& v, uint32_t acc) {
   return acc;
 }
 __device__ __forceinline__ uint4 and128(const uint4& a, const uint4& b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
+__device__ __forceinline__ uint32_t any128(const uint4& a) { return a.x | a.y | a.z | a.w; }
 
 template <int P, bool MISSING, bool NEED_ALL, int NPL, int U, int LPR>
 __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uint4* __restrict__ lds_mask, uint32_t nvec_pad,
                                                  const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1,
-                                                 const uint8_t* __restrict__ called_ptr, int gl, uint32_t (&n)[P], uint32_t& n_all,
-                                                 uint32_t& allele_or, uint32_t (&s0)[P], uint32_t (&s1)[P], uint32_t (&s01)[P]) {
+                                                 const uint8_t* __restrict__ row2, const uint8_t* __restrict__ called_ptr, int gl,
+                                                 uint32_t (&n)[P], uint32_t& n_all, uint32_t& allele_or, uint32_t (&s)[P][(1 << NPL) - 1]) {
+  constexpr int NS = (1 << NPL) - 1;
 #pragma unroll
-  for (int p = 0; p < P; ++p) { n[p] = 0; s0[p] = 0; s1[p] = 0; s01[p] = 0; }
+  for (int p = 0; p < P; ++p) {
+    n[p] = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s[p][k] = 0;
+  }
   n_all = 0;
   allele_or = 0;
   const uint32_t last = mv.nvec - 1;
   for (uint32_t v0 = gl; v0 < nvec_pad; v0 += LPR * U) {
-    uint4 x0[U], x1[U], cb[U];
+    uint4 x[NPL][U], cb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t v = v0 + LPR * u;
       const uint32_t vc = v < last ? v : last;
-      x0[u] = load_stream(row0 + (size_t)vc * 16);
-      if (NPL == 2) x1[u] = load_stream(row1 + (size_t)vc * 16);
+      x[0][u] = load_stream(row0 + (size_t)vc * 16);
+      if constexpr (NPL >= 2) x[1][u] = load_stream(row1 + (size_t)vc * 16);
+      if constexpr (NPL >= 3) x[2][u] = load_stream(row2 + (size_t)vc * 16);
       if (MISSING) cb[u] = load_stream(called_ptr + (size_t)vc * 16);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t v = v0 + LPR * u;
       const bool inside = v <= last;
-      uint4 a0 = x0[u], a1 = NPL == 2 ? x1[u] : make_uint4(0, 0, 0, 0);
+      // sub[T - 1] = AND of the planes in T, restricted to called entries
+      uint4 sub[NS];
+      sub[0] = x[0][u];
+      if constexpr (NPL >= 2) sub[1] = x[1][u];
+      if constexpr (NPL >= 3) sub[3] = x[2][u];
       if (MISSING) {
-        a0 = and128(a0, cb[u]);
-        if (NPL == 2) a1 = and128(a1, cb[u]);
+        sub[0] = and128(sub[0], cb[u]);
+        if constexpr (NPL >= 2) sub[1] = and128(sub[1], cb[u]);
+        if constexpr (NPL >= 3) sub[3] = and128(sub[3], cb[u]);
         if (NEED_ALL) n_all = inside ? popc128(cb[u], n_all) : n_all;
       }
-      if (NPL == 2) {
-        const uint32_t any0 = a0.x | a0.y | a0.z | a0.w, any1 = a1.x | a1.y | a1.z | a1.w;
-        allele_or |= inside ? ((any0 ? 1u : 0u) | (any1 ? 2u : 0u)) : 0u;
+      if constexpr (NPL >= 2) {
+        uint32_t seen = (any128(sub[0]) ? 1u : 0u) | (any128(sub[1]) ? 2u : 0u);
+        if constexpr (NPL >= 3) seen |= any128(sub[3]) ? 4u : 0u;
+        allele_or |= inside ? seen : 0u;
+        sub[2] = and128(sub[0], sub[1]);
       }
-      const uint4 a01 = NPL == 2 ? and128(a0, a1) : make_uint4(0, 0, 0, 0);
+      if constexpr (NPL >= 3) {
+        sub[4] = and128(sub[0], sub[3]);
+        sub[5] = and128(sub[1], sub[3]);
+        sub[6] = and128(sub[2], sub[3]);
+      }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
         if (MISSING) { m = and128(m, cb[u]); n[p] = popc128(m, n[p]); }
-        s0[p] = popc128(and128(a0, m), s0[p]);
-        if (NPL == 2) { s1[p] = popc128(and128(a1, m), s1[p]); s01[p] = popc128(and128(a01, m), s01[p]); }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[p][k] = popc128(and128(sub[k], m), s[p][k]);
       }
     }
   }
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     if (MISSING) n[p] = group_sum<LPR>(n[p]);
-    s0[p] = group_sum<LPR>(s0[p]);
-    if (NPL == 2) { s1[p] = group_sum<LPR>(s1[p]); s01[p] = group_sum<LPR>(s01[p]); }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s[p][k] = group_sum<LPR>(s[p][k]);
   }
   if (MISSING && NEED_ALL) n_all = group_sum<LPR>(n_all);
-  if (NPL == 2) allele_or = group_or<LPR>(allele_or);
+  if (NPL >= 2) allele_or = group_or<LPR>(allele_or);
+}
+
+// Calls of allele value `a` among n called members, from the subset sums of count_row_packed / count_row_planes
+// (inclusion-exclusion over the supersets of a's bit set; a == 0: n minus the members with any bit set).  Exact integers.
+template <int NPL>
+__device__ __forceinline__ uint32_t allele_count_from_planes(uint32_t a, uint32_t n, const uint32_t (&s)[(1 << NPL) - 1]) {
+  uint32_t c = a == 0 ? n : 0u;
+#pragma unroll
+  for (uint32_t T = 1; T < (1u << NPL); ++T) {
+    if ((T & a) == a) c += (__builtin_popcount(T ^ a) & 1) ? 0u - s[T - 1] : s[T - 1];
+  }
+  return c;
 }
 
 // The LPR rows a group owns in one tile, for the commonest packed shape: biallelic, nothing missing, and a row that one
@@ -596,8 +629,8 @@ template <int P, bool MISSING, int U, int MM>
 __device__ __forceinline__ void count_row_planes(const MatrixView& mv, const void* __restrict__ lds_mask,
                                                  uint32_t nvec_pad, const uint8_t* __restrict__ row_ptr,
                                                  const uint8_t* __restrict__ bits_ptr, int gl, uint32_t (&n)[P],
-                                                 uint32_t& n_all, uint32_t& allele_or, uint32_t (&s0)[P],
-                                                 uint32_t (&s1)[P], uint32_t (&s01)[P]) {
+                                                 uint32_t& n_all, uint32_t& allele_or, uint32_t (&s)[P][3]) {
+  uint32_t s0[P], s1[P], s01[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) { n[p] = 0; s0[p] = 0; s1[p] = 0; s01[p] = 0; }
   n_all = 0;
@@ -645,7 +678,7 @@ __device__ __forceinline__ void count_row_planes(const MatrixView& mv, const voi
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     if (MISSING) n[p] = row16_sum(n[p]);
-    s0[p] = row16_sum(s0[p]); s1[p] = row16_sum(s1[p]); s01[p] = row16_sum(s01[p]);
+    s[p][0] = row16_sum(s0[p]); s[p][1] = row16_sum(s1[p]); s[p][2] = row16_sum(s01[p]);  // subset order of count_row_packed
   }
   if (MISSING) n_all = row16_sum(n_all);
   allele_or = row16_or(allele_or);
@@ -749,7 +782,7 @@ __device__ __forceinline__ void site_store(T* p, V v) {
 template <int P, int MODE, bool MISSING, bool GENERAL>
 __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx, bool row_ok,
                                               const SiteTally<P>& t, double hud_dot, const WcSite<P>& wc,
-                                              LaneTotals<P, MODE>& T) {
+                                              LaneTotals<P, MODE>& T, const uint32_t (*c4)[P] = nullptr) {
   const bool dense = A.formula != kFormulaSparse;
   // the reference takes the no-missing biallelic arms only on a dense matrix without a mask whose
   // max_allele <= 1 (stats.rs:3191/3218, 4454/4485); build_dense_population_summary (1392, 1409)
@@ -881,6 +914,10 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
 #pragma unroll
       for (int p = 0; p < P; ++p) { cc[1][p] = t.alt[p]; cc[0][p] = t.n[p] - t.alt[p]; }
       wc_for_each_slot<P, 2, !MISSING>(A, t.n, cc, finish);
+    } else if constexpr (P == 8) {
+      // eight groups, multi-allelic: the counts of alleles 0..3 (c4), every slot computed and finished in turn like the biallelic
+      // case - the same per-allele terms in the same allele order as the accumulating form below
+      wc_for_each_slot<P, 4, !MISSING>(A, t.n, *reinterpret_cast<const uint32_t (*)[4][P]>(c4), finish);
     } else {
       finish(0, wc.a[0], wc.b[0], true);
       int k = 1;
@@ -897,12 +934,78 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
   }
 }
 
+// Biallelic site: the tallies that follow from (n, alt) - allele 0 count = n - alt, allele 1 count = alt - and the
+// frequency dot product of the Hudson D_xy (dxy_from_counts, stats.rs:2921-2931, ascending allele order).
+template <int P, int MODE>
+__device__ __forceinline__ void finish_biallelic_site(SiteTally<P>& mine, double& hud_dot) {
+  uint32_t c0[P], c1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    c1[p] = mine.alt[p];
+    c0[p] = mine.n[p] - mine.alt[p];
+    mine.ssq[p] = (unsigned long long)c0[p] * c0[p] + (unsigned long long)c1[p] * c1[p];
+    mine.distinct[p] = (c0[p] != 0 ? 1u : 0u) + (c1[p] != 0 ? 1u : 0u);
+  }
+  if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+    if (mine.n[0] != 0 && mine.n[1] != 0) {
+      double inv1 = 1.0 / (double)mine.n[0], inv2 = 1.0 / (double)mine.n[1];
+      if (c0[0] != 0 && c0[1] != 0) hud_dot += ((double)c0[0] * inv1) * ((double)c0[1] * inv2);
+      if (c1[0] != 0 && c1[1] != 0) hud_dot += ((double)c1[0] * inv1) * ((double)c1[1] * inv2);
+    }
+  }
+  // W&C of a biallelic site is computed slot by slot inside site_epilogue (no per-site slot arrays in registers)
+}
+
+// Block reduction of the per-lane regional accumulators (fixed order: lane tree, then waves 0..3) into this block's row of
+// the partial vectors.  Called once, by every thread of the block, after the tile loop.
+template <int P, int MODE>
+__device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTotals<P, MODE>& T) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __shared__ double s_f64[kWavesPerBlock][kMaxF64];
+  __shared__ unsigned long long s_u64[kWavesPerBlock][kMaxU64];
+  auto put_f64 = [&](int slot, double v) { v = wave_sum(v); if (lane == 0) s_f64[wave][slot] = v; };
+  auto put_u64 = [&](int slot, unsigned long long v) { v = wave_sum(v); if (lane == 0) s_u64[wave][slot] = v; };
+  if (lane < kMaxF64) s_f64[wave][lane] = 0.0;
+  if (lane < kMaxU64) s_u64[wave][lane] = 0;
+  __syncthreads();
+  if constexpr ((MODE & kModeWc) != 0) {
+    if constexpr (LaneTotals<P, MODE>::kWcLaneTotals) {
+      constexpr int NW = 1 + (P * (P - 1)) / 2;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { put_f64(kOffWcA + k, T.wc_a[k]); put_f64(kOffWcB + k, T.wc_b[k]); put_u64(kOffWcInf + k, T.wc_inf[k]); }
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P; ++p) { put_f64(kOffPopF64 + p, T.pop_pi[p]); put_u64(kOffPopSeg + p, T.pop_seg[p]); put_u64(kOffPopUnc + p, T.pop_unc[p]); }
+    if constexpr ((MODE & kModeHudson) != 0) {
+#pragma unroll
+      for (int i = 0; i < kHudF64; ++i) put_f64(kOffHudF64 + i, T.hud[i]);
+#pragma unroll
+      for (int i = 0; i < kHudU64; ++i) put_u64(kOffHudU64 + i, T.hud_u[i]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kMaxF64) {
+    double v = 0.0;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_f64[w][threadIdx.x];
+    A.part_f64[(size_t)blockIdx.x * kMaxF64 + threadIdx.x] = v;
+  } else if (threadIdx.x < kMaxF64 + kMaxU64) {
+    const int i = threadIdx.x - kMaxF64;
+    unsigned long long v = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) v += s_u64[w][i];
+    A.part_u64[(size_t)blockIdx.x * kMaxU64 + i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // the sweep kernel
 // ------------------------------------------------------------------------------------------------
 // MM = where the membership masks live (kMaskLdsBytes / kMaskGlobalBytes / kMaskLdsBits, see mask_vec).
-template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16>
+// NPL = bit planes of a packed multi-allelic matrix (2: alleles up to 3, 3: up to 7); ignored elsewhere.
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
+  static_assert(NPL == 2 || (NPL == 3 && GENERAL && MM == kMaskPacked), "a third plane exists on packed multi-allelic matrices only");
   static_assert(LPR == 16 || ((LPR == 4 || LPR == 8) && MM == kMaskPacked), "four / eight lanes per row exist for the packed cores only");
   extern __shared__ __align__(16) unsigned char smem[];
   const MatrixView mv = A.mv;
@@ -990,186 +1093,157 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         rows_done = true;
       }
     }
+    // planes the counting core separates on the GENERAL path: NPL on a packed matrix, bits 0 and 1 on byte rows
+    constexpr int NPLK = !GENERAL ? 1 : (MM == kMaskPacked ? NPL : 2);
+    constexpr int NS = (1 << NPLK) - 1;
+    uint32_t my_s[P][NS];   // subset sums of the row this lane owns (GENERAL)
+    uint32_t my_or = 0;     // OR of its called allele values
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) my_s[p][k] = 0;
+    // packed cores: the batch depth U is the launch's (A.unroll); with eight groups on the general path only the shallow batches are
+    // built - deeper ones kept P x U mask vectors live and spilled to scratch
+    constexpr bool kShallow = GENERAL && P == 8;
     for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;
-      const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);
+      const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);  // rows past the end are clamped to the last row (their results are discarded by row_ok)
       const uint8_t* row_ptr = mv.data + row * mv.pitch;
       const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
       const bool own = gl == s;
-
-      if constexpr (!GENERAL) {
-        uint32_t alt[P], n[P], n_all;
-        // rows past the end are clamped to the last row (their results are discarded by row_ok)
-        if constexpr (MM == kMaskPacked) {
-          uint32_t aor, s1[P], s01[P];
-          const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-          if constexpr (LPR != 16) {
-            if (A.unroll == 5) count_row_packed<P, MISSING, NEED_ALL, 1, 5, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else if (A.unroll == 2) count_row_packed<P, MISSING, NEED_ALL, 1, 2, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else count_row_packed<P, MISSING, NEED_ALL, 1, 1, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-          } else {
-            if (A.unroll == 4) count_row_packed<P, MISSING, NEED_ALL, 1, 4, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else if (A.unroll == 3) count_row_packed<P, MISSING, NEED_ALL, 1, 3, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-            else count_row_packed<P, MISSING, NEED_ALL, 1, 2, 16>(mv, lm, nvec_pad, row_ptr, nullptr, bits_ptr, gl, n, n_all, aor, alt, s1, s01);
-          }
-        } else if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
-        else count_row_biallelic<P, MISSING, NEED_ALL, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
-        if (own) {
-#pragma unroll
-          for (int p = 0; p < P; ++p) {
-            mine.alt[p] = alt[p];
-            mine.n[p] = MISSING ? n[p] : A.group_size[p];
-          }
-          mine.n_all = MISSING ? n_all : mv.columns;
-        }
-      } else {
-        uint32_t n[P], n_all, aor, s0[P], s1[P], s01[P];
-        if constexpr (MM == kMaskPacked) {
-          const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-          const uint8_t* row_ptr1 = mv.data1 + row * mv.pitch;
-          if constexpr (LPR != 16) {
-            if (A.unroll == 5) count_row_packed<P, MISSING, true, 2, 5, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else if (A.unroll == 2) count_row_packed<P, MISSING, true, 2, 2, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else count_row_packed<P, MISSING, true, 2, 1, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-          } else {
-            if (A.unroll == 4) count_row_packed<P, MISSING, true, 2, 4, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else if (A.unroll == 3) count_row_packed<P, MISSING, true, 2, 3, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-            else count_row_packed<P, MISSING, true, 2, 2, 16>(mv, lm, nvec_pad, row_ptr, row_ptr1, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
-          }
+      uint32_t n[P], n_all, aor, sp[P][NS];
+      if constexpr (MM == kMaskPacked) {
+        const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
+        const uint8_t* row_ptr1 = NPLK >= 2 ? mv.data1 + row * mv.pitch : nullptr;
+        const uint8_t* row_ptr2 = NPLK >= 3 ? mv.data2 + row * mv.pitch : nullptr;
+        constexpr bool NA_ALL = GENERAL || NEED_ALL;
+#define FMH_COUNT_PACKED(UV) count_row_packed<P, MISSING, NA_ALL, NPLK, UV, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, row_ptr2, bits_ptr, gl, n, n_all, aor, sp)
+        if constexpr (LPR != 16) {
+          if constexpr (kShallow) { if (A.unroll == 2) FMH_COUNT_PACKED(2); else FMH_COUNT_PACKED(1); }
+          else if (A.unroll == 5) FMH_COUNT_PACKED(5);
+          else if (A.unroll == 3) FMH_COUNT_PACKED(3);
+          else if (A.unroll == 2) FMH_COUNT_PACKED(2);
+          else FMH_COUNT_PACKED(1);
         } else {
-          count_row_planes<P, MISSING, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, s0, s1, s01);
+          if constexpr (kShallow) FMH_COUNT_PACKED(2);
+          else if (A.unroll == 4) FMH_COUNT_PACKED(4);
+          else if (A.unroll == 3) FMH_COUNT_PACKED(3);
+          else FMH_COUNT_PACKED(2);
         }
-        if (!MISSING) {
+#undef FMH_COUNT_PACKED
+      } else if constexpr (!GENERAL) {
+        uint32_t alt[P];
+        if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+        else count_row_biallelic<P, MISSING, NEED_ALL, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
 #pragma unroll
-          for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
-          n_all = mv.columns;
+        for (int p = 0; p < P; ++p) sp[p][0] = alt[p];
+        aor = 0;
+      } else {
+        count_row_planes<P, MISSING, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, n, n_all, aor, sp);
+      }
+      if (own) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          mine.n[p] = MISSING ? n[p] : A.group_size[p];
+          if constexpr (!GENERAL) mine.alt[p] = sp[p][0];
+#pragma unroll
+          for (int k = 0; k < NS; ++k) my_s[p][k] = sp[p][k];
         }
-        if (own) {
+        mine.n_all = MISSING ? n_all : mv.columns;
+        my_or = aor;
+      }
+    }
+
+    // W&C with eight groups on the general path: no per-slot accumulators across the allele loop (29 slots = 116 registers); the counts of
+    // alleles 0..3 are kept instead and site_epilogue finishes slot by slot (the host sends max_allele > 3 to the counts route)
+    constexpr bool kWc8 = GENERAL && P == 8 && (MODE & kModeWc) != 0;
+    uint32_t c4[kWc8 ? 4 : 1][P];
+    if constexpr (GENERAL) {
+      // The alleles of the tile's 64 sites are consumed here, one site per lane (all 64 lanes busy), from the subset sums each
+      // lane kept of its own row.  `bound` is wave-uniform: the OR of the called allele values over the tile, capped by the matrix's
+      // max_allele; an allele a site does not carry contributes exact zeros to every accumulator.
+      uint32_t bound = my_or;
 #pragma unroll
-          for (int p = 0; p < P; ++p) mine.n[p] = n[p];
-          mine.n_all = n_all;
+      for (int off = 1; off < 64; off <<= 1) bound |= __shfl_xor(bound, off, 64);
+      bound = __builtin_amdgcn_readfirstlane(bound);
+      if (bound > (uint32_t)A.max_allele) bound = (uint32_t)A.max_allele;
+      const size_t my_row = tile_row0 + lane;
+      const bool my_ok = my_row < A.row_count;
+      double inv1 = 0.0, inv2 = 0.0;
+      auto consume = [&](uint32_t a, const uint32_t (&c)[P], bool mine_ok, size_t out_row) {
+        if (A.acounts && mine_ok) {
+#pragma unroll
+          for (int p = 0; p < P; ++p)
+            if (p < A.n_groups) A.acounts[((size_t)a * A.acounts_groups + A.acounts_group0 + p) * A.row_count + out_row] = c[p];
         }
-        // wave-uniform bound: OR of the called allele values over the four rows of this step
-        uint32_t bound = aor;
 #pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) bound |= __shfl_xor(bound, off, 64);
-        bound = __builtin_amdgcn_readfirstlane(bound);
-        if (bound > (uint32_t)A.max_allele) bound = (uint32_t)A.max_allele;
-        double inv1 = 0.0, inv2 = 0.0;
+        for (int p = 0; p < P; ++p) {
+          mine.ssq[p] += (unsigned long long)c[p] * c[p];
+          mine.distinct[p] += c[p] != 0 ? 1u : 0u;
+          if (a == 1) mine.alt[p] = c[p];
+        }
         if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
-          if (n[0] != 0) inv1 = 1.0 / (double)n[0];
-          if (n[1] != 0) inv2 = 1.0 / (double)n[1];
+          // dxy_from_counts 2921-2931 (ascending allele order); a zero count adds +0.0
+          if (c[0] != 0 && c[1] != 0) hud_dot += ((double)c[0] * inv1) * ((double)c[1] * inv2);
         }
-        auto consume = [&](uint32_t a, const uint32_t (&c)[P]) {
-          if (A.acounts && row_ok) {
+        if constexpr ((MODE & kModeWc) != 0 && !kWc8) {
+          // the reference iterates only alleles present among all samples; an absent allele
+          // contributes exact zeros, so iterating it is harmless
+          uint32_t cc[1][P];
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-              if (p < A.n_groups) A.acounts[((size_t)a * A.acounts_groups + A.acounts_group0 + p) * A.row_count + rel] = c[p];
-          }
+          for (int p = 0; p < P; ++p) cc[0][p] = c[p];
+          wc_add_alleles<P, 1, !MISSING>(A, mine.n, cc, wc);
+        }
+      };
+      if (bound < (1u << NPLK)) {
+        if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+          if (mine.n[0] != 0) inv1 = 1.0 / (double)mine.n[0];
+          if (mine.n[1] != 0) inv2 = 1.0 / (double)mine.n[1];
+        }
+        for (uint32_t a = 0; a <= bound; ++a) {
+          uint32_t c[P];
 #pragma unroll
-          for (int p = 0; p < P; ++p) {
-            mine.ssq[p] += (unsigned long long)c[p] * c[p];
-            mine.distinct[p] += c[p] != 0 ? 1u : 0u;
-            if (a == 1) mine.alt[p] = c[p];
-          }
+          for (int p = 0; p < P; ++p) c[p] = allele_count_from_planes<NPLK>(a, mine.n[p], my_s[p]);
+          consume(a, c, my_ok, my_row);
+        }
+        if constexpr (kWc8) {
+#pragma unroll
+          for (uint32_t a = 0; a < 4; ++a)
+#pragma unroll
+            for (int p = 0; p < P; ++p) c4[a][p] = a <= bound ? allele_count_from_planes<NPLK>(a, mine.n[p], my_s[p]) : 0u;
+        }
+      } else if constexpr (MM != kMaskPacked) {
+        // byte rows carrying an allele beyond the planes (>= 4): one pass per allele value over each row, re-read from L2
+        for (int s = 0; s < LPR; ++s) {
+          const size_t rel = tile_row0 + (size_t)grp * LPR + s;
+          const bool row_ok = rel < A.row_count;
+          const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);
+          const uint8_t* row_ptr = mv.data + row * mv.pitch;
+          const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
+          const bool own = gl == s;
           if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
-            // dxy_from_counts 2921-2931 (ascending allele order); a zero count adds +0.0
-            if (c[0] != 0 && c[1] != 0) hud_dot += ((double)c[0] * inv1) * ((double)c[1] * inv2);
-          }
-          if constexpr ((MODE & kModeWc) != 0) {
-            // the reference iterates only alleles present among all samples; an absent allele
-            // contributes exact zeros, so iterating it is harmless
-            uint32_t cc[1][P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) cc[0][p] = c[p];
-            wc_add_alleles<P, 1, !MISSING>(A, n, cc, wc);
-          }
-        };
-        if (bound <= 3) {
-          // every called allele of the four rows is < 4: the counts follow from the bit planes
-          if (own) {
-            uint32_t c[P];
-            for (uint32_t a = 0; a <= bound; ++a) {
-#pragma unroll
-              for (int p = 0; p < P; ++p) {
-                const uint32_t c3 = s01[p], c1 = s0[p] - s01[p], c2 = s1[p] - s01[p];
-                c[p] = a == 0 ? n[p] - c1 - c2 - c3 : (a == 1 ? c1 : (a == 2 ? c2 : c3));
-              }
-              consume(a, c);
+            if (own) {
+              inv1 = mine.n[0] != 0 ? 1.0 / (double)mine.n[0] : 0.0;
+              inv2 = mine.n[1] != 0 ? 1.0 / (double)mine.n[1] : 0.0;
             }
           }
-        } else if constexpr (MM != kMaskPacked) {  // a packed matrix holds alleles 0..3 only
           for (uint32_t a = 0; a <= bound; ++a) {
             uint32_t c[P];
             count_row_allele<P, MISSING, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
-            if (own) consume(a, c);
+            if (own) consume(a, c, row_ok, rel);
           }
         }
       }
     }
 
-    if constexpr (!GENERAL) {
-      // biallelic: allele 0 count = n - alt, allele 1 count = alt
-      uint32_t c0[P], c1[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        c1[p] = mine.alt[p];
-        c0[p] = mine.n[p] - mine.alt[p];
-        mine.ssq[p] = (unsigned long long)c0[p] * c0[p] + (unsigned long long)c1[p] * c1[p];
-        mine.distinct[p] = (c0[p] != 0 ? 1u : 0u) + (c1[p] != 0 ? 1u : 0u);
-      }
-      if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
-        if (mine.n[0] != 0 && mine.n[1] != 0) {
-          double inv1 = 1.0 / (double)mine.n[0], inv2 = 1.0 / (double)mine.n[1];
-          if (c0[0] != 0 && c0[1] != 0) hud_dot += ((double)c0[0] * inv1) * ((double)c0[1] * inv2);
-          if (c1[0] != 0 && c1[1] != 0) hud_dot += ((double)c1[0] * inv1) * ((double)c1[1] * inv2);
-        }
-      }
-      // W&C of a biallelic site is computed slot by slot inside site_epilogue (no per-site slot arrays in registers)
-    }
+    if constexpr (!GENERAL) finish_biallelic_site<P, MODE>(mine, hud_dot);
 
     const size_t my_rel = tile_row0 + lane;
-    site_epilogue<P, MODE, MISSING, GENERAL>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T);
+    site_epilogue<P, MODE, MISSING, GENERAL>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T, c4);
   }
 
-  // ---- block reduction of the regional accumulators (fixed order: lane tree, then waves 0..3) ----
-  __shared__ double s_f64[kWavesPerBlock][kMaxF64];
-  __shared__ unsigned long long s_u64[kWavesPerBlock][kMaxU64];
-  auto put_f64 = [&](int slot, double v) { v = wave_sum(v); if (lane == 0) s_f64[wave][slot] = v; };
-  auto put_u64 = [&](int slot, unsigned long long v) { v = wave_sum(v); if (lane == 0) s_u64[wave][slot] = v; };
-  if (lane < kMaxF64) s_f64[wave][lane] = 0.0;
-  if (lane < kMaxU64) s_u64[wave][lane] = 0;
-  __syncthreads();
-  if constexpr ((MODE & kModeWc) != 0) {
-    if constexpr (LaneTotals<P, MODE>::kWcLaneTotals) {
-      constexpr int NW = 1 + (P * (P - 1)) / 2;
-#pragma unroll
-      for (int k = 0; k < NW; ++k) { put_f64(kOffWcA + k, T.wc_a[k]); put_f64(kOffWcB + k, T.wc_b[k]); put_u64(kOffWcInf + k, T.wc_inf[k]); }
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < P; ++p) { put_f64(kOffPopF64 + p, T.pop_pi[p]); put_u64(kOffPopSeg + p, T.pop_seg[p]); put_u64(kOffPopUnc + p, T.pop_unc[p]); }
-    if constexpr ((MODE & kModeHudson) != 0) {
-#pragma unroll
-      for (int i = 0; i < kHudF64; ++i) put_f64(kOffHudF64 + i, T.hud[i]);
-#pragma unroll
-      for (int i = 0; i < kHudU64; ++i) put_u64(kOffHudU64 + i, T.hud_u[i]);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < kMaxF64) {
-    double v = 0.0;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += s_f64[w][threadIdx.x];
-    A.part_f64[(size_t)blockIdx.x * kMaxF64 + threadIdx.x] = v;
-  } else if (threadIdx.x < kMaxF64 + kMaxU64) {
-    const int i = threadIdx.x - kMaxF64;
-    unsigned long long v = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += s_u64[w][i];
-    A.part_u64[(size_t)blockIdx.x * kMaxU64 + i] = v;
-  }
+  reduce_block_totals<P, MODE>(A, T);
 }
 
 }  // namespace fmh

@@ -123,21 +123,21 @@ __global__ void generate_kernel(uint8_t* __restrict__ data, size_t pitch, uint8_
 
 // ---- bit-packed image (fmh_matrix_pack) ---------------------------------------------------------------------------
 // bytes -> planes: one thread per (row, 32 columns).  Bit c of a plane word = column 32 w + c; bits past the last column
-// are zero whatever the padding bytes hold.  p1 / pc may be null (biallelic / nothing missing).
+// are zero whatever the padding bytes hold.  p1 / p2 / pc may be null (alleles <= 1 / <= 3 / nothing missing).
 __device__ __forceinline__ uint32_t pack_nibble(uint32_t w, int shift) {  // bit `shift` of each of 4 bytes -> 4 bits, LSB = byte 0
   return ((((w >> shift) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
 }
 __global__ void pack_rows_kernel(const uint8_t* __restrict__ data, size_t pitch, const uint8_t* __restrict__ bits, size_t bits_pitch,
-                                 size_t rows, uint32_t columns, uint8_t* __restrict__ p0, uint8_t* __restrict__ p1,
+                                 size_t rows, uint32_t columns, uint8_t* __restrict__ p0, uint8_t* __restrict__ p1, uint8_t* __restrict__ p2,
                                  uint8_t* __restrict__ pc, size_t plane_pitch, unsigned int* __restrict__ overflow_flag) {
   const size_t words = plane_pitch / 4, total = rows * words;
   // allele bits the planes do not store: a CALLED entry that carries one was handed over with a max_allele below the data
-  const uint32_t himask = p1 ? 0xFCFCFCFCu : 0xFEFEFEFEu;
+  const uint32_t himask = p2 ? 0xF8F8F8F8u : (p1 ? 0xFCFCFCFCu : 0xFEFEFEFEu);
   bool overflow = false;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const size_t row = idx / words;
     const uint32_t w = (uint32_t)(idx - row * words), col0 = w * 32;
-    uint32_t b0 = 0, b1 = 0, bc = 0;
+    uint32_t b0 = 0, b1 = 0, b2 = 0, bc = 0;
     if (col0 < columns) {
       const uint32_t valid = columns - col0 >= 32 ? 0xFFFFFFFFu : ((1u << (columns - col0)) - 1u);
       uint32_t live = valid;  // called entries inside the row
@@ -159,51 +159,62 @@ __global__ void pack_rows_kernel(const uint8_t* __restrict__ data, size_t pitch,
           for (int k = 0; k < 4; ++k) {
             b0 |= pack_nibble(d[k], 0) << (16 * q + 4 * k);
             b1 |= pack_nibble(d[k], 1) << (16 * q + 4 * k);
+            b2 |= pack_nibble(d[k], 2) << (16 * q + 4 * k);
             overflow |= (d[k] & himask & (nib_to_bytes(live >> (16 * q + 4 * k)) * 0xFFu)) != 0;
           }
         }
       }
       b0 &= valid;
       b1 &= valid;
+      b2 &= valid;
     }
     *reinterpret_cast<uint32_t*>(p0 + row * plane_pitch + (size_t)w * 4) = b0;
     if (p1) *reinterpret_cast<uint32_t*>(p1 + row * plane_pitch + (size_t)w * 4) = b1;
+    if (p2) *reinterpret_cast<uint32_t*>(p2 + row * plane_pitch + (size_t)w * 4) = b2;
     if (pc && bits) *reinterpret_cast<uint32_t*>(pc + row * plane_pitch + (size_t)w * 4) = bc;
   }
   if (overflow && overflow_flag) atomicOr(overflow_flag, 1u);
 }
 
 // planes -> bytes: one thread per (row, 16 columns); padding columns come out zero
-__global__ void unpack_rows_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, size_t plane_pitch, size_t rows,
+__global__ void unpack_rows_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2, size_t plane_pitch, size_t rows,
                                    uint8_t* __restrict__ data, size_t pitch) {
   const size_t vecs = pitch / 16, total = rows * vecs;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const size_t row = idx / vecs;
     const uint32_t v = (uint32_t)(idx - row * vecs);
-    uint32_t lo = 0, hi = 0;
+    uint32_t lo = 0, hi = 0, top = 0;
     if ((size_t)v * 2 + 2 <= plane_pitch) {
       lo = *reinterpret_cast<const uint16_t*>(p0 + row * plane_pitch + (size_t)v * 2);
       if (p1) hi = *reinterpret_cast<const uint16_t*>(p1 + row * plane_pitch + (size_t)v * 2);
+      if (p2) top = *reinterpret_cast<const uint16_t*>(p2 + row * plane_pitch + (size_t)v * 2);
     }
     uint4 a = called_bytes(lo);
     if (p1) {
       const uint4 b = called_bytes(hi);
       a.x |= b.x << 1; a.y |= b.y << 1; a.z |= b.z << 1; a.w |= b.w << 1;
     }
+    if (p2) {
+      const uint4 b = called_bytes(top);
+      a.x |= b.x << 2; a.y |= b.y << 2; a.z |= b.z << 2; a.w |= b.w << 2;
+    }
     *reinterpret_cast<uint4*>(data + row * pitch + (size_t)v * 16) = a;
   }
 }
 
-// largest called allele of a packed image: 3 if some column has both plane bits, else 2 / 1 / 0
-__global__ void packed_max_allele_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ pc,
-                                         size_t plane_pitch, size_t rows, unsigned int* __restrict__ out) {
+// largest called allele of a packed image: the largest bit pattern any column shows (exact: 7 needs all three plane bits in ONE column)
+__global__ void packed_max_allele_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2,
+                                         const uint8_t* __restrict__ pc, size_t plane_pitch, size_t rows, unsigned int* __restrict__ out) {
   const size_t words = plane_pitch / 4, total = rows * words;
   unsigned int best = 0;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     uint32_t a = reinterpret_cast<const uint32_t*>(p0)[idx];
     uint32_t b = p1 ? reinterpret_cast<const uint32_t*>(p1)[idx] : 0u;
-    if (pc) { const uint32_t c = reinterpret_cast<const uint32_t*>(pc)[idx]; a &= c; b &= c; }
-    const unsigned int v = (a & b) ? 3u : (b ? 2u : (a ? 1u : 0u));
+    uint32_t c = p2 ? reinterpret_cast<const uint32_t*>(p2)[idx] : 0u;
+    if (pc) { const uint32_t k = reinterpret_cast<const uint32_t*>(pc)[idx]; a &= k; b &= k; c &= k; }
+    unsigned int v;
+    if (c) v = (c & b & a) ? 7u : ((c & b) ? 6u : ((c & a) ? 5u : 4u));
+    else v = (a & b) ? 3u : (b ? 2u : (a ? 1u : 0u));
     best = v > best ? v : best;
   }
   for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }

@@ -137,7 +137,7 @@ def test_random_geometry_hudson_and_diversity(dev, seed):
     close(dv.theta, theta, "site theta")
 
 
-@pytest.mark.parametrize("N,S,max_allele,p_missing", [(600, 300, 1, 0.0), (513, 257, 3, 0.05), (300, 1000, 2, 0.0), (257, 129, 1, 0.2)])
+@pytest.mark.parametrize("N,S,max_allele,p_missing", [(600, 300, 1, 0.0), (513, 257, 3, 0.05), (300, 1000, 2, 0.0), (257, 129, 1, 0.2), (300, 200, 6, 0.03), (130, 700, 5, 0.0)])
 def test_pairwise_gram_multi_tile(dev, N, S, max_allele, p_missing):
     """fmh_pairwise_differences across several 256-sample tiles (diagonal and off-diagonal tile pairs, K slices, ragged edges)
     against the same Gram products in numpy int64: diff = sum_s len_i len_j - sum_a cnt_i(a) cnt_j(a), both = sum_s valid_i valid_j."""

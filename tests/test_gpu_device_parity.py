@@ -369,6 +369,60 @@ def test_mask_routes_agree(dev, monkeypatch):
         monkeypatch.delenv("FMH_MASK_MODE", raising=False)
 
 
+def test_matrix_core_counting_route_agrees(dev, monkeypatch):
+    """BASELINE config C5: the counts as an int8 MFMA contraction (FMH_COUNTS_MFMA, u8 rows, biallelic, nothing missing).  Same
+    integers as the dot4 route, the same epilogue code after them: every track and total must be the same bits - and against
+    the oracle on the counts themselves.  Shapes exercise ragged K (columns not a multiple of 16 / 64 / 256), tiles with rows
+    past the end, a row range that starts inside the matrix, and one to four groups."""
+    from oracle import ferromic_ref as R
+
+    rng = np.random.default_rng(90210)
+    monkeypatch.setenv("FMH_LAYOUT", "bytes")
+    for (S, N) in ((70, 900), (129, 37), (64, 128), (1000, 1301), (3, 8), (257, 5000)):
+        m = H.random_dense_matrix(rng, S, N, 2, 1, 0.0)
+        dm = upload(dev, m)
+        cut = N // 3
+        lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, max(cut + 1, N - 5)))]
+        g2 = dev.Groups.from_haplotype_lists(dm, lists)
+        g1 = dev.Groups.from_haplotype_lists(dm, lists[:1])
+        thirds = [H.haps_for_samples(range(i, N, 3)) for i in range(3)]
+        g3 = dev.Groups.from_haplotype_lists(dm, thirds)
+        quarters = [H.haps_for_samples(range(i, N, 4)) for i in range(4)]
+        g4 = dev.Groups.from_haplotype_lists(dm, quarters)
+        r0, rc = (S // 5, S - S // 5 - 1) if S > 10 else (0, S)
+
+        def run():
+            hs = dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE)
+            hr = dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE, r0, rc)
+            dv = dev.diversity_sites(dm, g1)
+            w3, w4, w2 = dev.wc_sweep(dm, g3), dev.wc_sweep(dm, g4), dev.wc_sweep(dm, g2)
+            ps = dev.population_summaries(dm, g4, dev.FORMULA_SUMMARY)
+            return hs, hr, dv, w3, w4, w2, ps
+
+        monkeypatch.delenv("FMH_COUNTS_MFMA", raising=False)
+        base = run()
+        s1 = R.build_dense_population_summary(m, lists[0])
+        assert np.array_equal(base[0].sites["alt"][0], np.array(s1.alt_counts, dtype=np.uint32))
+        for unroll in ("1", "2"):
+            monkeypatch.setenv("FMH_COUNTS_MFMA", unroll)
+            got = run()
+            for i in (0, 1):
+                for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+                    H.assert_bits_equal(got[i].sites[k], base[i].sites[k], f"{k} mfma {unroll} {S}x{N}")
+                assert np.array_equal(got[i].sites["alt"], base[i].sites["alt"]) and np.array_equal(got[i].sites["called"], base[i].sites["called"])
+                assert got[i].totals == base[i].totals and got[i].pop == base[i].pop
+            H.assert_bits_equal(got[2].pi, base[2].pi, "site pi")
+            H.assert_bits_equal(got[2].theta, base[2].theta, "site theta")
+            for i in (3, 4, 5):
+                assert np.array_equal(got[i].a, base[i].a, equal_nan=True) and np.array_equal(got[i].b, base[i].b, equal_nan=True)
+                assert np.array_equal(got[i].state, base[i].state) and np.array_equal(got[i].group_called, base[i].group_called)
+                assert np.array_equal(got[i].sum_a, base[i].sum_a) and np.array_equal(got[i].sum_b, base[i].sum_b)
+                assert np.array_equal(got[i].informative_sites, base[i].informative_sites)
+            assert np.array_equal(got[6].alt, base[6].alt) and np.array_equal(got[6].called, base[6].called)
+            assert got[6].totals == base[6].totals
+        monkeypatch.delenv("FMH_COUNTS_MFMA", raising=False)
+
+
 def test_eight_groups_on_rows_beyond_the_bit_mask_budget(dev):
     """160 000 haplotypes x 8 groups: even as bits the eight masks pass the LDS budget (8 x 10 048 x 2 B > 150 KiB),
     so W&C goes through the counts path in batches of four groups; a fused four-group sweep (bit masks) must give the
@@ -408,7 +462,8 @@ def test_packed_and_byte_layouts_agree(dev, monkeypatch):
     the packed image alone (bytes released); every output must be the same bits.  Then the packed-only matrix is
     downloaded (unpack), scanned for its max allele and sent through the pairwise Gram (unpack staging)."""
     rng = np.random.default_rng(31)
-    for (S, N, max_allele, p_missing) in ((300, 700, 1, 0.0), (257, 333, 1, 0.04), (130, 1100, 3, 0.0), (90, 260, 2, 0.1), (70, 40, 3, 0.02)):
+    for (S, N, max_allele, p_missing) in ((300, 700, 1, 0.0), (257, 333, 1, 0.04), (130, 1100, 3, 0.0), (90, 260, 2, 0.1), (70, 40, 3, 0.02),
+                                          (150, 900, 7, 0.0), (97, 333, 5, 0.06), (64, 2700, 4, 0.01), (40, 70, 6, 0.0)):  # three planes
         m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
         monkeypatch.setenv("FMH_LAYOUT", "bytes")
         dm = upload(dev, m)                       # u8 rows only
@@ -472,10 +527,32 @@ def test_pack_api_contract(dev):
     import ctypes as C
 
     rng = np.random.default_rng(8)
-    wide_alleles = H.random_dense_matrix(rng, 20, 30, 2, 5, 0.0)
-    dm = upload(dev, wide_alleles)                 # max_allele 5: stays on u8 rows
+    wide_alleles = H.random_dense_matrix(rng, 20, 30, 2, 9, 0.0)
+    dm = upload(dev, wide_alleles)                 # max_allele 9: stays on u8 rows (three planes hold alleles 0..7)
     with pytest.raises(_abi.FerromicHipError):
         dm.pack()
+    # a max_allele below the data would silently drop allele bits: the packer detects it on the device and refuses
+    lying = np.frombuffer(wide_alleles.data, dtype=np.uint8)
+    for claimed in (1, 3, 7):
+        with pytest.raises(_abi.FerromicHipError, match="above max_allele"):
+            dev.DeviceMatrix.from_host(lying, None, 20, 30, 2, claimed)
+    # ... but only for CALLED entries: a missing entry may hold any byte
+    masked = lying.copy().reshape(20, 60)
+    words = np.zeros((20 * 60 + 63) // 64, dtype=np.uint64)
+    big = np.argwhere(masked > 3)
+    for (r, c) in big:
+        idx = int(r) * 60 + int(c)
+        words[idx >> 6] |= np.uint64(1) << np.uint64(idx & 63)
+    ok3 = dev.DeviceMatrix.from_host(masked.reshape(-1), words, 20, 30, 2, 3)
+    back = ok3.download()
+    called = ~np.unpackbits(np.asarray(back[1]).view(np.uint8), bitorder="little")[:1200].astype(bool)
+    assert np.array_equal(np.asarray(back[0])[called], masked.reshape(-1)[called])
+    # wrap validation (header: bits_pitch % 4 == 0, 4-byte aligned called rows)
+    buf = dev.DeviceBuffer(0, 4096)
+    with pytest.raises(_abi.FerromicHipError, match="multiple of 4"):
+        dev.DeviceMatrix.wrap(buf.ptr, 64, buf.ptr + 2048, 6, 4, 30, 2, 1)
+    with pytest.raises(_abi.FerromicHipError, match="4-byte aligned"):
+        dev.DeviceMatrix.wrap(buf.ptr, 64, buf.ptr + 2050, 8, 4, 30, 2, 1)
     ok = dev.DeviceMatrix.alloc(40, 25, 2, with_missing=True)
     thr = (rng.random((1, 40)) * (1 << 24)).astype(np.uint32)
     ok.generate(3, 0, thr, np.zeros(50, dtype=np.uint8), missing_threshold24=int(0.1 * (1 << 24)))

@@ -41,7 +41,7 @@ def main():
         seed = S + N
         pop_of_sample = np.minimum(np.arange(N) * P // N, P - 1).astype(np.uint8)
         poc = np.repeat(pop_of_sample, 2)
-        base = synthetic_thresholds(S, 0, S, seed)
+        base = synthetic_thresholds(S, 0, seed)
         thr = np.stack([base[p % 2] for p in range(P)])
         dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=miss > 0, max_allele=1)
         dm.generate(seed, 0, thr, poc, int(miss * (1 << 24)))

@@ -22,7 +22,7 @@ def main():
     for G in (int(x) for x in (sys.argv[1:] or ["2", "4", "5", "8", "12", "26"])):
         pop_of_sample = np.minimum(np.arange(N) * G // N, G - 1).astype(np.uint8)
         poc = np.repeat(pop_of_sample, 2)
-        base = synthetic_thresholds(S, 0, S, 7)
+        base = synthetic_thresholds(S, 0, 7)
         thr = np.stack([base[p % 2] for p in range(G)])
         dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=False, max_allele=1)
         dm.generate(7, 0, thr, poc, 0)
