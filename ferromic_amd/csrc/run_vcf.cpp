@@ -1725,6 +1725,37 @@ vector<TrackFn> fst_tracks(const RegionOutput& r) {  // append_fst_falsta, proce
   return tracks;
 }
 
+const char* kHudsonTsvHeader = "chr\tregion_start_0based\tregion_end_0based\tpop1_id_type\tpop1_id_name\tpop2_id_type\tpop2_id_name\tDxy\tpi_pop1\tpi_pop2\tpi_xy_avg\tFST\n";  // process.rs:1576-1590
+const char* kWcTsvHeader = "chr\tregion_start_1based\tregion_end_1based\tcomparison_type\tpop1\tpop2\tfst\tnumerator_a\tdenominator_a_plus_b\tinformative_sites\n";  // process.rs:1628-1650
+
+// --print_formats (no GPU): the header lines of every output file and the FALSTA records the writers produce for one tiny
+// made-up region, so that the output surface can be pinned against the reference's committed exemplars
+// (data/output.csv, data/FST_data.tsv, data/per_site_diversity_output.falsta.gz) on a machine without a GPU.
+int print_formats() {
+  vector<string> header(kCsvHeader, kCsvHeader + 34);
+  printf("output.csv\t%s\n", join(header, ',', true).c_str());
+  printf("hudson_fst_results.tsv\t%s", kHudsonTsvHeader);
+  printf("wc_fst_results.tsv\t%s", kWcTsvHeader);
+  RegionOutput r;
+  r.seqname = "1";
+  r.region_start1 = 5;
+  r.region_end1 = 12;
+  for (int g = 0; g < 2; ++g)
+    for (int f = 0; f < 2; ++f) {
+      r.diversity.push_back({6, 0.289855, 0.267788, g, f != 0});
+      r.diversity.push_back({9, NAN, NAN, g, f != 0});
+      r.diversity.push_back({11, 0.0, 0.0, g, f != 0});
+    }
+  r.wc_sites.push_back({6, 0.5, 0.25, 0.5, 0.5, 0.25, 0.5});
+  r.wc_sites.push_back({9, NAN, 0.0, 0.0, INFINITY, 1.0, 0.0});
+  r.hudson_sites.push_back({6, 1.0, 1.0, 1.0});
+  r.hudson_sites.push_back({7, -0.5, -0.5, 1.0});
+  r.hudson_sites.push_back({11, NAN, 0.0, 0.0});
+  for (auto& t : diversity_tracks(r)) printf("per_site_diversity_output.falsta\t%s", t().c_str());
+  for (auto& t : fst_tracks(r)) printf("per_site_fst_output.falsta\t%s", t().c_str());
+  return 0;
+}
+
 // ---- per-region driver (process.rs:2468-3653) ----------------------------------------------------------------
 struct Args {
   string vcf_folder, chr, region, config_file, output_file = "output.csv", mask_file, allow_file, reference, gtf, fst_populations;
@@ -1733,6 +1764,7 @@ struct Args {
   bool enable_fst = false, enable_pca = false;
   int device = 0;
   int workers_per_device = 4;  // region workers per GPU: host-side packing, downloads and writers of one region overlap the sweeps of another
+  bool print_formats = false;  // diagnostic: header lines + sample FALSTA records (needs no GPU, no inputs)
   bool ingest_only = false;  // diagnostic: parse the inputs, report counts, compute nothing (needs no GPU)
   vector<int> devices;  // --devices: one worker thread per entry, config regions dealt out dynamically
 };
@@ -2040,12 +2072,12 @@ int run(const Args& args) {
   csv.flush();
   if (args.enable_fst) {  // final rewrite with header (process.rs:1557-1625)
     remove(hudson_path.c_str());
-    string text = "chr\tregion_start_0based\tregion_end_0based\tpop1_id_type\tpop1_id_name\tpop2_id_type\tpop2_id_name\tDxy\tpi_pop1\tpi_pop2\tpi_xy_avg\tFST\n";
+    string text = kHudsonTsvHeader;
     for (auto& r : hudson_rows) text += join(r, '\t') + "\n";
     gz_append(hudson_path, text);
     if (!wc_rows.empty()) {  // process.rs:1628-1726
       remove(wc_path.c_str());
-      string wt = "chr\tregion_start_1based\tregion_end_1based\tcomparison_type\tpop1\tpop2\tfst\tnumerator_a\tdenominator_a_plus_b\tinformative_sites\n";
+      string wt = kWcTsvHeader;
       for (auto& r : wc_rows) wt += join(r, '\t') + "\n";
       gz_append(wc_path, wt);
     }
@@ -2085,6 +2117,7 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--fst") a.enable_fst = true;
     else if (k == "--fst_populations") a.fst_populations = value();
     else if (k == "--ingest_only") a.ingest_only = true;
+    else if (k == "--print_formats") { a.print_formats = true; return a; }
     else if (k == "--workers_per_device") a.workers_per_device = std::max(1, atoi(value().c_str()));
     else if (k == "--device") a.device = atoi(value().c_str());
     else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)
@@ -2110,6 +2143,7 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
 int main(int argc, char** argv) {
   try {
     const Args args = parse_args(argc, argv);
+    if (args.print_formats) return print_formats();
     int n = 0;
     if (!args.ingest_only) fmh_check(fmh_device_count(&n), "GPU required (run_vcf has no CPU fallback)");
     return run(args);

@@ -58,6 +58,39 @@ def main():
             assert getattr(piped, k) == getattr(merged, k), k
     for p in range(2):
         assert piped.pop[p].segregating_sites == merged.pop[p].segregating_sites and piped.pop[p].pi_sum == merged.pop[p].pi_sum
+    # W&C regional sums (every slot of 3 groups) and per-population summaries ride the same way: pack -> one sum -> unpack.
+    # Each rank's slab totals are a deterministic function of the rank, so every rank can check the merged result.
+    G, slots = 3, 4
+
+    def wc_of(r):
+        t = _abi.WcTotals()
+        for k in range(slots):
+            t.sum_a[k] = 0.125 * (r + 1) * (k + 1) + 1e-9 * r
+            t.sum_b[k] = 3.5 * (r + 2) - k
+            t.informative_sites[k] = 1000 * (r + 1) + k
+        t.sites_attempted = 1200 * (r + 1)
+        return t
+
+    def pops_of(r):
+        out = []
+        for p in range(G):
+            t = _abi.PopTotals()
+            t.haplotype_capacity, t.segregating_sites, t.uncallable_sites, t.pi_sum = 20 + p, 300 * (r + 1) + p, 7 * r + p, 11.25 * (r + 1) + 0.5 * p
+            out.append(t)
+        return out
+
+    wc = sharding.allreduce_wc_totals(wc_of(rank), G, dist, "cpu")
+    pops = sharding.allreduce_pop_totals(pops_of(rank), dist, "cpu")
+    for k in range(slots):
+        assert wc.informative_sites[k] == sum(wc_of(r).informative_sites[k] for r in range(world))
+        assert abs(wc.sum_a[k] - sum(wc_of(r).sum_a[k] for r in range(world))) <= 1e-12
+        assert abs(wc.sum_b[k] - sum(wc_of(r).sum_b[k] for r in range(world))) <= 1e-12
+    assert wc.sites_attempted == sum(1200 * (r + 1) for r in range(world)) and wc.sum_a[slots] == 0.0
+    for p in range(G):
+        assert pops[p].haplotype_capacity == 20 + p  # a per-rank constant, not a sum
+        assert pops[p].segregating_sites == sum(300 * (r + 1) + p for r in range(world))
+        assert pops[p].uncallable_sites == sum(7 * r + p for r in range(world))
+        assert abs(pops[p].pi_sum - sum(11.25 * (r + 1) + 0.5 * p for r in range(world))) <= 1e-12
     if rank == 0:
         whole = totals_of(0, S)
         for k, _ in _abi.HudsonTotals._fields_:

@@ -94,3 +94,47 @@ def test_no_dot4_result_is_read_too_early():
     res = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert " 0 hazard(s)" in res.stdout
+
+
+def test_no_kernel_spills_to_scratch(lib):
+    """Every kernel of the shipped library, from the gfx950 code objects' metadata: no scratch memory (.private_segment_fixed_size)
+    and no spilled VGPRs.  Round 1 shipped eleven 8-group multi-allelic instantiations that spilled up to 464 VGPRs; no parity
+    test notices that."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(ROOT, "tools", "kernel_resources.py")
+    res = subprocess.run([sys.executable, tool, "--spills-only"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    m = re.search(r"(\d+) kernels, 0 with scratch", res.stdout)
+    assert m and int(m.group(1)) >= 150, res.stdout[-500:]
+
+
+def test_comm_and_packing_entry_points_without_a_gpu(lib):
+    """The packing halves are host arithmetic (no device); the communicator itself refuses loudly without a GPU."""
+    import torch
+
+    from ferromic_amd import _abi
+
+    t = _abi.WcTotals()
+    t.sum_a[0], t.sum_b[2], t.informative_sites[1], t.sites_attempted = 1.5, 2.5, 7, 100
+    f, u = (C.c_double * 8)(), (C.c_uint64 * 5)()
+    assert lib.fmh_wc_totals_pack(C.byref(t), 3, f, u) == 0
+    assert list(f) == [1.5, 0, 0, 0, 0, 0, 2.5, 0] and list(u) == [0, 7, 0, 0, 100]
+    back = _abi.WcTotals()
+    assert lib.fmh_wc_totals_unpack(C.byref(back), 3, f, u) == 0
+    assert back.sum_a[0] == 1.5 and back.sum_b[2] == 2.5 and back.informative_sites[1] == 7 and back.sites_attempted == 100
+    assert lib.fmh_wc_totals_pack(C.byref(t), 9, f, u) == _abi.FMH_ERR_INVALID
+    pt = (_abi.PopTotals * 2)()
+    pt[0].pi_sum, pt[1].segregating_sites, pt[0].haplotype_capacity = 0.75, 9, 30
+    pf, pu = (C.c_double * 2)(), (C.c_uint64 * 7)()
+    assert lib.fmh_pop_totals_pack(pt, 2, pf, pu) == 0 and pu[6] == 1
+    doubled = (C.c_uint64 * 7)(*[2 * x for x in pu])
+    out = (_abi.PopTotals * 2)()
+    assert lib.fmh_pop_totals_unpack(out, 2, (C.c_double * 2)(*[2 * x for x in pf]), doubled) == 0
+    assert out[0].pi_sum == 1.5 and out[1].segregating_sites == 18 and out[0].haplotype_capacity == 30
+    if not torch.cuda.is_available():
+        buf = (C.c_char * 128)()
+        assert lib.fmh_comm_get_unique_id(buf) == _abi.FMH_ERR_NO_DEVICE
+        h = C.c_void_p()
+        assert lib.fmh_comm_init_all((C.c_int * 2)(0, 0), 2, (C.c_void_p * 2)()) != 0

@@ -1,0 +1,104 @@
+"""The run_vcf output surface against the reference's committed exemplars:
+tests/golden/format_exemplars.json holds the header lines, a few rows and the FALSTA record shapes of
+data/output.csv, data/FST_data.tsv and data/per_site_diversity_output.falsta.gz (transcribed by
+tools/make_format_exemplars.py; the inputs behind those files are not in the reference tree, so they pin format, not
+numbers).  `run_vcf --print_formats` emits the binary's header lines and the records its writers produce for a tiny
+made-up region - no GPU, no inputs."""
+
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exemplars():
+    with open(os.path.join(ROOT, "tests", "golden", "format_exemplars.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="module")
+def printed():
+    binary = os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")
+    if not os.path.exists(binary):
+        import __graft_entry__ as ge
+
+        ge.build()
+    res = subprocess.run([binary, "--print_formats"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stderr
+    files = {}
+    for line in res.stdout.splitlines():
+        if "\t" in line and line.split("\t", 1)[0].endswith((".csv", ".tsv", ".falsta")):
+            name, rest = line.split("\t", 1)
+            files.setdefault(name, []).append(rest)
+        else:  # the token line of the FALSTA record just opened
+            files[name].append(line)
+    return files
+
+
+def shape(tok):
+    if re.fullmatch(r"-?\d+\.\d{6}", tok):
+        return "d.dddddd"
+    if re.fullmatch(r"-?\d+", tok):
+        return "0" if tok == "0" else "int"
+    return tok
+
+
+def test_csv_and_tsv_headers_equal_the_reference_files(exemplars, printed):
+    assert exemplars["output_csv"]["columns"] == 34
+    assert printed["output.csv"] == [exemplars["output_csv"]["header"]]
+    assert exemplars["hudson_tsv"]["columns"] == 12
+    assert printed["hudson_fst_results.tsv"] == [exemplars["hudson_tsv"]["header"]]
+    assert printed["wc_fst_results.tsv"][0].split("\t")[:3] == ["chr", "region_start_1based", "region_end_1based"]
+
+
+def test_oracle_headers_equal_the_reference_files(exemplars):
+    from oracle import run_vcf_ref as O
+
+    assert ",".join(O.CSV_HEADER) == exemplars["output_csv"]["header"]
+    assert "\t".join(O.HUDSON_TSV_HEADER) == exemplars["hudson_tsv"]["header"]
+    # the cell formatters produce exactly the token shapes the reference files hold: {:.6}, NA, NaN, integers
+    assert O.fmt6(0.0013634) == "0.001363" and O.fmt6(float("nan")) == "NaN" and O.format_optional_float(None) == "NA"
+    for row in exemplars["output_csv"]["rows"]:
+        cells = row.split(",")
+        assert len(cells) == 34
+        for c, cell in enumerate(cells):
+            assert shape(cell) in exemplars["output_csv"]["cell_shapes_by_column"][c]
+    floats = {9, 10, 11, 12, 15, 16, 17, 18}
+    for c, shapes in enumerate(exemplars["output_csv"]["cell_shapes_by_column"]):
+        if c in floats:
+            assert set(shapes) <= {"d.dddddd", "NaN"}
+    for c in (7, 8, 9, 10):
+        assert set(exemplars["hudson_tsv"]["cell_shapes_by_column"][c]) == {"d.dddddd"}
+    assert set(exemplars["hudson_tsv"]["cell_shapes_by_column"][11]) <= {"d.dddddd", "NA"}
+
+
+def test_falsta_records_have_the_reference_shape(exemplars, printed):
+    ref = exemplars["diversity_falsta"]
+    assert set(ref["token_shapes"]) == {"0", "NA", "d.dddddd"}
+    # record order inside one (region, group) of the reference file, and one dense line per record
+    assert [r["track"] for r in ref["records"][:4]] == ["unfiltered_pi", "unfiltered_theta", "filtered_pi", "filtered_theta"]
+    for r in ref["records"]:
+        assert r["tokens"] == r["span"]
+    recs = printed["per_site_diversity_output.falsta"]
+    heads, lines = recs[0::2], recs[1::2]
+    assert [re.fullmatch(r">(\w+?)_chr_1_start_5_end_12_group_(\d)", h).groups() for h in heads] == \
+           [(t, g) for g in "01" for t in ("unfiltered_pi", "unfiltered_theta", "filtered_pi", "filtered_theta")]
+    for h, line in zip(heads, lines):
+        pattern = re.sub(r"\d+", r"\\d+", re.escape(ref["records"][0]["header"]).replace("unfiltered_pi", r"\w+"))
+        assert re.fullmatch(pattern, h), (pattern, h)
+        toks = line.split(",")
+        assert len(toks) == 12 - 5 + 1 and {shape(t) for t in toks} <= set(ref["token_shapes"])
+    assert lines[0] == "0,0.289855,0,0,NA,0,0,0"  # default 0, masked site NA, a true zero stays 0 (process.rs:3786-3792)
+    fst = printed["per_site_fst_output.falsta"]
+    fheads, flines = fst[0::2], fst[1::2]
+    assert fheads[0] == ">haplotype_overall_fst_summary_chr_1_start_5_end_12" and fheads[6] == ">hudson_pairwise_fst_hap_0v1_chr_1_start_5_end_12"
+    assert len(fheads) == 9
+    for line in flines:
+        toks = line.split(",")
+        assert len(toks) == 8 and {shape(t) for t in toks} <= {"0", "NA", "d.dddddd", "Infinity", "-Infinity"}
+    assert flines[6] == "NA,1.000000,-0.500000,NA,NA,NA,NA,NA"  # FST tracks default to NA (process.rs:3842-3856)
