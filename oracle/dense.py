@@ -43,6 +43,8 @@ def load():
         lib.fo_hudson_sweep_threaded.argtypes = [vp, vp, sz, sz, vp, sz, vp, sz] + [vp] * 10 + [
             C.POINTER(PopTotals), C.POINTER(HudsonTotals), i]
         lib.fo_hudson_sweep_threaded.restype = None
+        lib.fo_wc_sites_threaded.argtypes = [vp, vp, sz, sz, vp, i, vp, vp, vp, vp, vp, vp, i]
+        lib.fo_wc_sites_threaded.restype = None
         _lib = lib
     return _lib
 
@@ -94,3 +96,28 @@ def hudson_sweep(data: np.ndarray, missing_words: Optional[np.ndarray], variants
     return SweepOut(alt, called, *tracks,
                     pop=[{k: getattr(pop[i], k) for k, _ in PopTotals._fields_} for i in range(2)],
                     totals={k: getattr(tot, k) for k, _ in HudsonTotals._fields_})
+
+
+@dataclass
+class WcOut:
+    a: np.ndarray       # [slots][S]; slot 0 = overall, then pairs (0,1), (0,2), ...
+    b: np.ndarray
+    state: np.ndarray   # 0 calculable, 1 indeterminate, 2 no variance, 3 insufficient
+    sum_a: np.ndarray
+    sum_b: np.ndarray
+    informative: np.ndarray
+
+
+def wc_sites(data: np.ndarray, missing_words: Optional[np.ndarray], variants: int, stride: int, group_of_column: np.ndarray,
+             n_groups: int, nthreads: int = 1) -> WcOut:
+    """fo_wc_sites_threaded: Weir & Cockerham per site + regional sums (stats.rs:1814-2032, 2145-2374) on a dense matrix."""
+    goc = np.ascontiguousarray(group_of_column, dtype=np.uint8)
+    assert goc.size == stride and 2 <= n_groups <= 16
+    slots = 1 + n_groups * (n_groups - 1) // 2
+    a = np.empty((slots, variants), dtype=np.float64)
+    b = np.empty((slots, variants), dtype=np.float64)
+    st = np.empty((slots, variants), dtype=np.uint8)
+    sa, sb, inf = np.zeros(slots), np.zeros(slots), np.zeros(slots, dtype=np.uint64)
+    load().fo_wc_sites_threaded(_p(data), _p(missing_words), variants, stride, _p(goc), n_groups, _p(a), _p(b), _p(st), _p(sa), _p(sb),
+                                _p(inf), nthreads)
+    return WcOut(a, b, st, sa, sb, inf)

@@ -325,3 +325,171 @@ void fo_hudson_sweep_threaded(const uint8_t* data, const uint64_t* missing, size
   free(th);
   free(jobs);
 }
+
+/* ================================================================================================
+ * Weir & Cockerham per site on a dense matrix (stats.rs:1814-2032, 2034-2127, 1781-1812) and the regional
+ * sums of calculate_overall_fst_wc (2145-2374), for the full-size C3 parity gate: the Python
+ * restatement (oracle/ferromic_ref.py) does ~100 sites per second, this does millions.
+ * Pinned to the Python half bit for bit by tests/test_oracle_dense_c.py.
+ *
+ * Dense model: column h of a row is one (sample, side) entry, called unless its missing bit is set;
+ * group_of_column[h] = group index or 0xFF (what SubpopulationMembership.left / right hold, 1104-1150).
+ * ================================================================================================ */
+
+/* calculate_variance_components, stats.rs:2034-2127; stats = (n_i, p_i) of the r groups with data */
+static void wc_variance_components(const size_t* n, const double* p, int r_i, double global_freq, double* a_out, double* b_out) {
+  const double r = (double)r_i;
+  *a_out = 0.0;
+  *b_out = 0.0;
+  if (r < 2.0) return;
+  size_t total_haplotypes = 0;
+  for (int i = 0; i < r_i; ++i) total_haplotypes += n[i];
+  const double n_bar = (double)total_haplotypes / r;
+  if ((n_bar - 1.0) < 1e-9) return;
+  const double global_p = global_freq;
+  double sum_sq_diff_n = 0.0;
+  for (int i = 0; i < r_i; ++i) {
+    const double diff = (double)n[i] - n_bar;
+    sum_sq_diff_n += diff * diff;
+  }
+  const double c_squared = (r > 0.0 && n_bar > 0.0) ? sum_sq_diff_n / (r * n_bar * n_bar) : 0.0;
+  double numerator_s_squared = 0.0;
+  for (int i = 0; i < r_i; ++i) {
+    const double diff_p = p[i] - global_p;
+    numerator_s_squared += (double)n[i] * diff_p * diff_p;
+  }
+  const double s_squared = ((r - 1.0) > 1e-9 && n_bar > 1e-9) ? numerator_s_squared / ((r - 1.0) * n_bar) : 0.0;
+  const double x_wc = global_p * (1.0 - global_p) - ((r - 1.0) / r) * s_squared;
+  const double a_numerator_term = s_squared - (x_wc / (n_bar - 1.0));
+  const double a_denominator_factor = 1.0 - (c_squared / (r - 1.0));
+  *a_out = a_numerator_term / a_denominator_factor;
+  *b_out = (n_bar / (n_bar - 1.0)) * x_wc;
+}
+
+/* fst_estimate_from_components, stats.rs:1781-1812 -> 0 calculable, 1 indeterminate, 2 no variance */
+static uint8_t wc_state(double a, double b) {
+  const double denominator = a + b;
+  if (denominator > FST_EPSILON) return 0;
+  if (denominator < -FST_EPSILON) return 1;
+  if (fabs(a) > FST_EPSILON) return 0;
+  return 2;
+}
+
+#define FO_WC_MAX_GROUPS 16
+typedef struct {
+  const uint8_t* data;
+  const uint64_t* missing;
+  size_t stride, s0, s1, variants;
+  const uint8_t* group_of_column;
+  int G;
+  double *a, *b; /* [slots][variants] */
+  uint8_t* state;
+} wc_job;
+
+static void* wc_worker(void* pv) {
+  wc_job* j = (wc_job*)pv;
+  const int G = j->G;
+  const int slots = 1 + G * (G - 1) / 2;
+  for (size_t s = j->s0; s < j->s1; ++s) {
+    const size_t base = s * j->stride;
+    /* alleles present among ALL called entries (1826-1837), ascending (BTreeSet) */
+    uint8_t present[256];
+    memset(present, 0, sizeof present);
+    for (size_t h = 0; h < j->stride; ++h)
+      if (!j->missing || !dense_missing(j->missing, base + h)) present[j->data[base + h]] = 1;
+    double sum_a = 0.0, sum_b = 0.0, pa[FO_WC_MAX_GROUPS * FO_WC_MAX_GROUPS], pb[FO_WC_MAX_GROUPS * FO_WC_MAX_GROUPS];
+    uint8_t pseen[FO_WC_MAX_GROUPS * FO_WC_MAX_GROUPS];
+    memset(pseen, 0, sizeof pseen);
+    for (int k = 0; k < slots; ++k) { pa[k] = 0.0; pb[k] = 0.0; }
+    int populated = 0;
+    for (int target = 0; target < 256; ++target) {
+      if (!present[target]) continue;
+      size_t total_counts[FO_WC_MAX_GROUPS], alt_counts[FO_WC_MAX_GROUPS];
+      for (int g = 0; g < G; ++g) { total_counts[g] = 0; alt_counts[g] = 0; }
+      for (size_t h = 0; h < j->stride; ++h) {
+        if (j->missing && dense_missing(j->missing, base + h)) continue;
+        const uint8_t g = j->group_of_column[h];
+        if (g == 0xFF) continue;
+        total_counts[g] += 1;
+        if (j->data[base + h] == (uint8_t)target) alt_counts[g] += 1;
+      }
+      size_t total_called = 0, total_target = 0, ns[FO_WC_MAX_GROUPS];
+      double ps[FO_WC_MAX_GROUPS];
+      int valid = 0;
+      for (int g = 0; g < G; ++g) {
+        if (total_counts[g] == 0) continue;
+        ns[valid] = total_counts[g];
+        ps[valid] = (double)alt_counts[g] / (double)total_counts[g];
+        ++valid;
+        total_called += total_counts[g];
+        total_target += alt_counts[g];
+      }
+      populated = 1; /* pop_sizes_populated (1987): an allele was iterated */
+      if (valid < 2) continue;
+      const double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
+      double ca, cb;
+      wc_variance_components(ns, ps, valid, global_freq, &ca, &cb);
+      sum_a += ca;
+      sum_b += cb;
+      int k = 1;
+      for (int x = 0; x < G; ++x)
+        for (int y = x + 1; y < G; ++y, ++k) {
+          const size_t ta = total_counts[x], tb = total_counts[y];
+          if (ta == 0 || tb == 0) continue;
+          const size_t pn[2] = {ta, tb};
+          const double pp[2] = {(double)alt_counts[x] / (double)ta, (double)alt_counts[y] / (double)tb};
+          const size_t pair_total = ta + tb;
+          const double pair_global = pair_total > 0 ? (double)(alt_counts[x] + alt_counts[y]) / (double)pair_total : 0.0;
+          double qa, qb;
+          wc_variance_components(pn, pp, 2, pair_global, &qa, &qb);
+          pa[k] += qa;
+          pb[k] += qb;
+          pseen[k] = 1;
+        }
+    }
+    if (!populated) { /* InsufficientData everywhere (1987-2003) */
+      for (int k = 0; k < slots; ++k) { j->a[(size_t)k * j->variants + s] = 0.0; j->b[(size_t)k * j->variants + s] = 0.0; j->state[(size_t)k * j->variants + s] = 3; }
+      continue;
+    }
+    j->a[s] = sum_a;
+    j->b[s] = sum_b;
+    j->state[s] = wc_state(sum_a, sum_b);
+    for (int k = 1; k < slots; ++k) {
+      const size_t o = (size_t)k * j->variants + s;
+      if (pseen[k]) { j->a[o] = pa[k]; j->b[o] = pb[k]; j->state[o] = wc_state(pa[k], pb[k]); }
+      else { j->a[o] = 0.0; j->b[o] = 0.0; j->state[o] = 3; }
+    }
+  }
+  return NULL;
+}
+
+/* Per-site a, b, state for every slot (0 = overall, then pairs (0,1),(0,2),...) and the regional sums over the sites whose
+ * state is not insufficient, accumulated SERIALLY in site order as the reference does (2222-2229). */
+void fo_wc_sites_threaded(const uint8_t* data, const uint64_t* missing, size_t variants, size_t stride, const uint8_t* group_of_column,
+                          int G, double* a, double* b, uint8_t* state, double* sum_a, double* sum_b, uint64_t* informative, int nthreads) {
+  if (G < 2 || G > FO_WC_MAX_GROUPS) return;
+  if (nthreads < 1) nthreads = 1;
+  if ((size_t)nthreads > variants) nthreads = variants ? (int)variants : 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+  wc_job* jobs = (wc_job*)malloc(sizeof(wc_job) * (size_t)nthreads);
+  for (int t = 0; t < nthreads; ++t) {
+    wc_job j = {data, missing, stride, variants * (size_t)t / (size_t)nthreads, variants * (size_t)(t + 1) / (size_t)nthreads, variants, group_of_column, G, a, b, state};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, wc_worker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
+  const int slots = 1 + G * (G - 1) / 2;
+  for (int k = 0; k < slots; ++k) {
+    double sa = 0.0, sb = 0.0;
+    uint64_t n = 0;
+    for (size_t s = 0; s < variants; ++s) {
+      const size_t o = (size_t)k * variants + s;
+      if (state[o] != 3) { sa += a[o]; sb += b[o]; ++n; }
+    }
+    sum_a[k] = sa;
+    sum_b[k] = sb;
+    informative[k] = n;
+  }
+}

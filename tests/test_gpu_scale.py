@@ -191,3 +191,129 @@ def test_c3_wc_sampled_sites_against_oracle(dev, layout):
         for k, (i, j) in enumerate(pairs, start=1):
             assert (float(w.a[k][r]), float(w.b[k][r])) == pair_components[f"{i}_vs_{j}"], (r, i, j)
         assert dev.WC_STATES[w.state[0][r]] == overall.state
+
+
+def test_c3_full_size(dev):
+    """BASELINE config C3 at its full size - 5 M sites x 2 500 haplotypes, 4 populations, fused W&C sweep on the resident
+    (bit-packed) layout - against the C oracle (oracle/dense_oracle.c fo_wc_sites_threaded, pinned bit for bit to the Python
+    restatement of stats.rs:1814-2032) on the SAME cohort regenerated on the host: a, b and state of the overall slot and of
+    all six pairs at EVERY site bit for bit (SURVEY 8(d) asks for 1 %), informative-site counts exact, regional sums 1e-9
+    (the reference sums serially in site order, the GPU per lane / block / grid)."""
+    S, N, P = 5_000_000, 1250, 4
+    seed = 5_001_250
+    base = thresholds(S, seed)
+    thr = np.stack([base[p % 2] for p in range(P)])
+    pop_of_sample = np.minimum(np.arange(N) * P // N, P - 1).astype(np.uint8)
+    poc = np.repeat(pop_of_sample, 2)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
+    dm.generate(seed, 0, thr, poc, 0)
+    settle(dm, "packed")
+    masks = np.stack([poc == p for p in range(P)]).astype(np.uint8)
+    w = dev.wc_sweep(dm, dev.Groups(dm, masks))
+    hdata, _ = D.generate(S, 2 * N, seed, 0, thr, poc, 0, 16)
+    exp = D.wc_sites(hdata, None, S, 2 * N, poc, P, 16)
+    del hdata
+    slots = 1 + P * (P - 1) // 2
+    assert w.a.shape == (slots, S)
+    assert np.array_equal(w.state, exp.state)
+    assert np.array_equal(w.a.view(np.uint64), exp.a.view(np.uint64))   # bit for bit, 35 M values each
+    assert np.array_equal(w.b.view(np.uint64), exp.b.view(np.uint64))
+    assert (w.group_called == np.array([int((poc == p).sum()) for p in range(P)], dtype=np.uint32)[:, None]).all()
+    for k in range(slots):
+        assert int(w.informative_sites[k]) == int(exp.informative[k]) == S
+        assert H.rel_close(float(w.sum_a[k]), float(exp.sum_a[k])), k
+        assert H.rel_close(float(w.sum_b[k]), float(exp.sum_b[k])), k
+    assert w.sites_attempted == S
+    # the regional F_ST the API reports
+    assert H.rel_close(float(w.sum_a[0] / (w.sum_a[0] + w.sum_b[0])), float(exp.sum_a[0] / (exp.sum_a[0] + exp.sum_b[0])))
+
+
+def test_c5_full_size(dev, monkeypatch):
+    """BASELINE config C5 at its full size - 2 M sites x 10 000 haplotypes, 2 populations, pi + Hudson - through all three counting
+    routes: int8 MFMA contraction on u8 rows (the route the config names), v_dot4 on u8 rows, popcounts on the packed planes; each
+    against the C oracle on the same cohort regenerated on the host: counts and all six f64 tracks bit for bit at every site,
+    integer totals exact, f64 totals 1e-9; plus additivity over uneven slabs on the MFMA route."""
+    S, N = 2_000_000, 5000
+    seed = 2_005_000
+    thr = thresholds(S, seed)
+    poc, masks = two_pops(N)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
+    dm.generate(seed, 0, thr, poc, 0)
+    g = dev.Groups(dm, masks)
+    hdata, _ = D.generate(S, 2 * N, seed, 0, thr, poc, 0, 16)
+    exp = D.hudson_sweep(hdata, None, S, 2 * N, np.nonzero(poc == 0)[0], np.nonzero(poc == 1)[0], 16)
+    del hdata
+
+    def check(got, what):
+        assert np.array_equal(got.sites["alt"], exp.alt), what
+        assert np.array_equal(got.sites["called"], exp.called), what
+        for name in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+            H.assert_bits_equal(got.sites[name], getattr(exp, name), f"{name} {what}")
+        for p in range(2):
+            assert got.pop[p]["segregating_sites"] == exp.pop[p]["segregating_sites"], what
+            assert got.pop[p]["uncallable_sites"] == exp.pop[p]["uncallable_sites"], what
+            assert H.rel_close(got.pop[p]["pi_sum"], exp.pop[p]["pi_sum"]), what
+        for k in ("numerator_sum", "denominator_sum", "pi1_sum", "pi2_sum", "dxy_sum_all", "site_num_sum", "site_den_sum"):
+            assert H.rel_close(got.totals[k], exp.totals[k]), (k, what)
+        assert got.totals["dxy_uncallable_sites"] == exp.totals["dxy_uncallable_sites"]
+        assert got.totals["sites_with_components"] == exp.totals["sites_with_components"]
+
+    monkeypatch.setenv("FMH_LAYOUT", "bytes")
+    monkeypatch.setenv("FMH_COUNTS_MFMA", "1")
+    mfma = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
+    check(mfma, "int8 MFMA route")
+    cuts = [0, 444_441, 1_500_007, S]
+    parts = [dev.hudson_sweep(dm, g, dev.FORMULA_DENSE, a, b - a, want_sites=False) for a, b in zip(cuts, cuts[1:])]
+    for k, v in mfma.totals.items():
+        tot = sum(p.totals[k] for p in parts)
+        assert (tot == v) if isinstance(v, int) else H.rel_close(tot, v), k
+    del mfma, parts
+    monkeypatch.delenv("FMH_COUNTS_MFMA")
+    check(dev.hudson_sweep(dm, g, dev.FORMULA_DENSE), "dot4 route")
+    monkeypatch.delenv("FMH_LAYOUT")
+    dm.pack(release_bytes=True)
+    check(dev.hudson_sweep(dm, g, dev.FORMULA_DENSE), "packed route")
+
+
+def test_c4_full_size(dev):
+    """BASELINE config C4 at its full size - 10 M sites x 5 000 haplotypes, 2 populations, the sweep bench.py times - on the resident
+    (bit-packed) layout: ONE sweep over the whole cohort, then every site's counts and f64 tracks bit for bit against the C oracle,
+    which regenerates the cohort on the host slab by slab (2 M sites = 10 GB at a time); integer totals exact, f64 totals 1e-9
+    against the oracle's slab totals summed in slab order."""
+    S, N = 10_000_000, 2500
+    seed = S + N
+    thr = thresholds(S, seed)
+    poc, masks = two_pops(N)
+    dm = dev.DeviceMatrix.alloc(S, N, 2, with_missing=False)
+    dm.generate(seed, 0, thr, poc, 0)
+    settle(dm, "packed")
+    got = dev.hudson_sweep(dm, dev.Groups(dm, masks), dev.FORMULA_DENSE)
+    off1, off2 = np.nonzero(poc == 0)[0], np.nonzero(poc == 1)[0]
+    sums = {k: 0.0 for k in ("numerator_sum", "denominator_sum", "pi1_sum", "pi2_sum", "dxy_sum_all", "site_num_sum", "site_den_sum")}
+    counts = {"dxy_uncallable_sites": 0, "sites_with_components": 0}
+    seg, unc, pis = [0, 0], [0, 0], [0.0, 0.0]
+    slab = 2_000_000
+    for b in range(0, S, slab):
+        e = min(S, b + slab)
+        hdata, _ = D.generate(e - b, 2 * N, seed, b, np.ascontiguousarray(thr[:, b:e]), poc, 0, 16)
+        exp = D.hudson_sweep(hdata, None, e - b, 2 * N, off1, off2, 16)
+        del hdata
+        assert np.array_equal(got.sites["alt"][:, b:e], exp.alt), b
+        assert np.array_equal(got.sites["called"][:, b:e], exp.called), b
+        for name in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+            H.assert_bits_equal(got.sites[name][b:e], getattr(exp, name), f"{name} slab {b}")
+        for k in sums:
+            sums[k] += exp.totals[k]
+        for k in counts:
+            counts[k] += exp.totals[k]
+        for p in range(2):
+            seg[p] += exp.pop[p]["segregating_sites"]
+            unc[p] += exp.pop[p]["uncallable_sites"]
+            pis[p] += exp.pop[p]["pi_sum"]
+    for k, v in sums.items():
+        assert H.rel_close(got.totals[k], v), k
+    for k, v in counts.items():
+        assert got.totals[k] == v, k
+    for p in range(2):
+        assert got.pop[p]["segregating_sites"] == seg[p] and got.pop[p]["uncallable_sites"] == unc[p]
+        assert H.rel_close(got.pop[p]["pi_sum"], pis[p])

@@ -54,3 +54,58 @@ def test_generator_is_deterministic_and_thread_independent():
     assert np.array_equal(c, c2.reshape(S, H_)[100:200].reshape(-1))
     frac = a.reshape(S, H_)[:, : H_ // 2].mean(axis=1)
     assert abs(np.corrcoef(frac, thr[0] / float(1 << 24))[0, 1]) > 0.8
+
+
+@pytest.mark.parametrize("sites,samples,G,max_allele,p_missing,ungrouped,threads", [
+    (160, 24, 2, 1, 0.0, 0, 1), (140, 31, 4, 1, 0.08, 3, 3), (120, 26, 3, 3, 0.15, 5, 2), (90, 18, 5, 2, 0.5, 2, 4), (40, 9, 2, 1, 0.97, 0, 1)])
+def test_c_wc_matches_python_oracle(sites, samples, G, max_allele, p_missing, ungrouped, threads):
+    """fo_wc_sites_threaded against calculate_fst_wc_at_site_with_membership / calculate_overall_fst_wc, bit for bit:
+    per-site a, b and state of the overall slot and of every pair, and the regional sums (serial, site order)."""
+    rng = np.random.default_rng(1000 * sites + samples + G)
+    m = H.random_dense_matrix(rng, sites, samples, 2, max_allele, p_missing)
+    data = np.frombuffer(m.data, dtype=np.uint8).reshape(sites, 2 * samples)
+    words = H.missing_words_np(m)
+    miss = np.zeros((sites, 2 * samples), dtype=bool) if words is None else \
+        np.unpackbits(words.view(np.uint8), bitorder="little")[: sites * 2 * samples].reshape(sites, 2 * samples).astype(bool)
+    # make the dense mask expressible in the sparse model the Python restatement takes: a genotype whose FIRST allele is missing
+    # is None as a whole (process.rs:479-496), one whose second allele is missing is a haploid call
+    miss[:, 1::2] |= miss[:, 0::2]
+    if words is not None:
+        bits = np.packbits(miss.reshape(-1), bitorder="little")
+        words = np.frombuffer(np.concatenate([bits, np.zeros((-len(bits)) % 8, np.uint8)]).tobytes(), dtype="<u8").copy()
+    group_of_sample = rng.integers(0, G, size=samples)
+    group_of_sample[:G] = np.arange(G)            # every group has a member
+    group_map = {(s, side): str(int(group_of_sample[s])) for s in range(samples - ungrouped) for side in (0, 1)}
+    membership = R.SubpopulationMembership.from_map(samples, group_map)
+    goc = np.full(2 * samples, 0xFF, dtype=np.uint8)
+    for (s, side), label in group_map.items():
+        goc[2 * s + side] = membership.labels.index(label)
+    n_groups = membership.group_count()
+    out = D.wc_sites(data.reshape(-1), words, sites, 2 * samples, goc, n_groups, threads)
+    pairs = [(i, j) for i in range(n_groups) for j in range(i + 1, n_groups)]
+    states = {"calculable": 0, "components_yield_indeterminate_ratio": 1, "no_inter_population_variance": 2, "insufficient_data_for_estimation": 3}
+    site_records = []
+    for s in range(sites):
+        genos = []
+        for smp in range(samples):
+            g = [int(data[s, 2 * smp + k]) for k in (0, 1)]
+            genos.append(None if miss[s, 2 * smp] else (g[:1] if miss[s, 2 * smp + 1] else g))
+        overall, pw, comps, sizes, pcomps = R.calculate_fst_wc_at_site_with_membership(R.make_variant(s, genos), membership)
+        site_records.append(R.SiteFstWc(s + 1, overall, pw, comps, sizes, pcomps))
+        assert (float(out.a[0][s]), float(out.b[0][s])) == comps, s
+        assert int(out.state[0][s]) == states[overall.state], s
+        for k, (i, j) in enumerate(pairs, start=1):
+            key = f"{membership.labels[i]}_vs_{membership.labels[j]}"
+            if overall.state == "insufficient_data_for_estimation":
+                assert int(out.state[k][s]) == 3
+                continue
+            assert (float(out.a[k][s]), float(out.b[k][s])) == pcomps[key], (s, key)
+            assert int(out.state[k][s]) == states[pw[key].state], (s, key)
+    overall, pw, agg = R.calculate_overall_fst_wc(site_records)
+    if overall.state != "insufficient_data_for_estimation":
+        assert (float(out.sum_a[0]), float(out.sum_b[0])) == (overall.sum_a, overall.sum_b) and int(out.informative[0]) == overall.sites
+    for k, (i, j) in enumerate(pairs, start=1):
+        key = f"{membership.labels[i]}_vs_{membership.labels[j]}"
+        if key in agg and pw[key].state != "insufficient_data_for_estimation":
+            assert (float(out.sum_a[k]), float(out.sum_b[k])) == agg[key], key
+            assert int(out.informative[k]) == pw[key].sites
