@@ -1067,13 +1067,49 @@ struct DevBuf {
 // DenseGenotypeMatrix::from_variants (stats.rs:339-500), uploaded.  When no genotype is called at all the
 // reference has no dense matrix; a one-allele all-missing matrix carries the same (empty) information for
 // the sparse formulas, and `has_dense` records which arm the reference would take.
-struct RegionMatrix {
+// One region's matrix, whole on one GPU or - a large region with --devices N - as N contiguous site slabs, one per GPU
+// (SURVEY.md 8e): per-site tracks are computed by the GPU that owns the sites, the regional accumulators are summed
+// through the library's communicator (RCCL; an in-process rendezvous when --devices lists a GPU twice).
+struct Slab {
   std::shared_ptr<DeviceMatrix> dm;
+  int device = 0;
+  size_t row0 = 0;
+  fmh_comm* comm = nullptr;  // null: the only slab
+};
+struct RegionMatrix {
+  std::shared_ptr<DeviceMatrix> dm;  // slab 0 (the whole matrix when not sharded): geometry queries
+  vector<Slab> slabs;
+  size_t variants = 0;               // over all slabs
   bool has_dense = false;
   size_t ploidy = 0;
 };
 
-RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, int device) {
+// --devices N: the communicators of the run (one per listed device) and when a region is worth splitting
+struct ShardState {
+  vector<int> devices;
+  vector<fmh_comm*> comms;
+  size_t min_bytes = (size_t)256 << 20;  // FERROMIC_SHARD_MIN_BYTES: matrices smaller than this stay whole
+  std::mutex region_mutex;               // one sharded region at a time (the communicators are shared)
+} g_shard;
+
+bool want_shard(size_t rows, size_t n_samples) {
+  if (g_shard.comms.size() < 2) return false;
+  return rows >= 64 * g_shard.comms.size() && rows * n_samples * 2 >= g_shard.min_bytes;
+}
+
+// runs fn(slab, k) for every slab: inline for one slab, one thread per slab otherwise (the collectives inside need every
+// slab to take part at the same time); the first error is rethrown after all threads have ended
+template <class F> void on_slabs(const RegionMatrix& rm, F fn) {
+  if (rm.slabs.size() <= 1) { if (!rm.slabs.empty()) fn(rm.slabs[0], (size_t)0); return; }
+  vector<std::exception_ptr> errs(rm.slabs.size());
+  vector<std::thread> pool;
+  for (size_t k = 0; k < rm.slabs.size(); ++k)
+    pool.emplace_back([&, k]() { try { fn(rm.slabs[k], k); } catch (...) { errs[k] = std::current_exception(); } });
+  for (auto& t : pool) t.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
+
+RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, int device, bool shard = false) {
   RegionMatrix out;
   if (vs.empty()) return out;
   size_t max_ploidy = 0;
@@ -1081,6 +1117,7 @@ RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, in
   out.has_dense = max_ploidy > 0;
   const size_t P = std::max<size_t>(max_ploidy, 1);
   out.ploidy = P;
+  out.variants = vs.size();
   const size_t stride = n_samples * P, total = vs.size() * stride;
   vector<uint8_t> data(total, 0);
   vector<uint64_t> missing((total + 63) / 64, 0);
@@ -1117,9 +1154,26 @@ RegionMatrix build_matrix(const vector<const Variant*>& vs, size_t n_samples, in
   bool any_missing = false;
   uint8_t max_allele = 0;
   for (unsigned t = 0; t < T; ++t) { any_missing |= t_missing[t] != 0; max_allele = std::max(max_allele, t_max[t]); }
-  out.dm.reset(new DeviceMatrix());
-  out.dm->variants = vs.size(); out.dm->samples = n_samples; out.dm->ploidy = P;
-  fmh_check(fmh_matrix_create(data.data(), any_missing ? missing.data() : nullptr, vs.size(), n_samples, P, max_allele, device, &out.dm->h), "matrix upload");
+  // Slabs start at multiples of 64 rows (a slab's slice of the missing bitset then starts on a word boundary) and every slab is
+  // created with the REGION's ploidy, max_allele and mask presence: the reference picks its formula arms from the region-wide
+  // matrix (stats.rs:3191 / 3218, 4454 / 4485), so a slab without missing calls must still take the masked arms if the region has any
+  const size_t D = shard ? g_shard.comms.size() : 1;
+  for (size_t k = 0; k < D; ++k) {
+    Slab sl;
+    sl.row0 = D == 1 ? 0 : std::min(vs.size(), (runs * k / D) * 64);
+    sl.device = D == 1 ? device : g_shard.devices[k];
+    sl.comm = D == 1 ? nullptr : g_shard.comms[k];
+    out.slabs.push_back(sl);
+  }
+  on_slabs(out, [&](const Slab& csl, size_t k) {
+    Slab& sl = out.slabs[k];
+    const size_t r1 = k + 1 < D ? out.slabs[k + 1].row0 : vs.size();
+    sl.dm.reset(new DeviceMatrix());
+    sl.dm->variants = r1 - csl.row0; sl.dm->samples = n_samples; sl.dm->ploidy = P;
+    fmh_check(fmh_matrix_create(data.data() + csl.row0 * stride, any_missing ? missing.data() + (csl.row0 * stride) / 64 : nullptr, r1 - csl.row0, n_samples, P,
+                                max_allele, sl.device, &sl.dm->h), "matrix upload");
+  });
+  out.dm = out.slabs[0].dm;
   return out;
 }
 
@@ -1151,6 +1205,120 @@ struct Groups {
   }
   ~Groups() { if (h) fmh_groups_destroy(h); }
 };
+
+// ---- sweeps over a (possibly sharded) region matrix -------------------------------------------------------------
+// Each returns what the single-matrix C-ABI call returns: per-site tracks assembled in site order from the slabs, totals summed
+// over the slabs through the communicator (fmh_*_totals_pack -> fmh_allreduce_totals -> unpack; every slab ends with the sums).
+vector<fmh_pop_totals> sharded_summaries(const RegionMatrix& rm, const vector<vector<uint8_t>>& masks, int formula, vector<uint32_t>* called0 = nullptr) {
+  const size_t G = masks.size();
+  vector<vector<fmh_pop_totals>> per(rm.slabs.size(), vector<fmh_pop_totals>(G));
+  if (called0) called0->assign(rm.variants, 0);
+  on_slabs(rm, [&](const Slab& sl, size_t k) {
+    const size_t rows = sl.dm->variants;
+    Groups grp(*sl.dm, masks);
+    std::unique_ptr<DevBuf> dcalled;
+    if (called0) dcalled.reset(new DevBuf(sl.device, 4 * G * std::max<size_t>(rows, 1)));
+    fmh_check(fmh_population_summaries(sl.dm->h, grp.h, 0, rows, formula, nullptr, dcalled ? (uint32_t*)dcalled->p : nullptr, per[k].data(), nullptr), "summaries");
+    if (called0 && rows) { vector<uint32_t> c = dcalled->fetch<uint32_t>(rows); std::copy(c.begin(), c.end(), called0->begin() + (ptrdiff_t)sl.row0); }
+    if (sl.comm) {
+      vector<double> f(FMH_POP_PACK_F64(G));
+      vector<uint64_t> u(FMH_POP_PACK_U64(G));
+      fmh_check(fmh_pop_totals_pack(per[k].data(), (int)G, f.data(), u.data()), "pack");
+      fmh_check(fmh_allreduce_totals(sl.comm, f.data(), f.size(), u.data(), u.size()), "all-reduce of the population totals");
+      fmh_check(fmh_pop_totals_unpack(per[k].data(), (int)G, f.data(), u.data()), "unpack");
+    }
+  });
+  return per[0];
+}
+
+void sharded_diversity(const RegionMatrix& rm, const vector<uint8_t>& mask, vector<double>& pi_v, vector<double>& th_v) {
+  pi_v.assign(rm.variants, 0.0);
+  th_v.assign(rm.variants, 0.0);
+  on_slabs(rm, [&](const Slab& sl, size_t) {
+    const size_t rows = sl.dm->variants;
+    if (!rows) return;
+    Groups one(*sl.dm, {mask});
+    DevBuf dpi(sl.device, 8 * rows), dth(sl.device, 8 * rows);
+    fmh_check(fmh_diversity_sites(sl.dm->h, one.h, 0, rows, (double*)dpi.p, (double*)dth.p, nullptr, nullptr, nullptr, nullptr), "diversity");
+    vector<double> a = dpi.fetch<double>(rows), b = dth.fetch<double>(rows);
+    std::copy(a.begin(), a.end(), pi_v.begin() + (ptrdiff_t)sl.row0);
+    std::copy(b.begin(), b.end(), th_v.begin() + (ptrdiff_t)sl.row0);
+  });
+}
+
+// fused W&C sweep (2..8 groups); tracks [nw][S] when wanted
+fmh_wc_totals sharded_wc(const RegionMatrix& rm, const vector<vector<uint8_t>>& masks, vector<double>* a, vector<double>* b, vector<uint8_t>* st) {
+  const size_t G = masks.size(), nw = 1 + G * (G - 1) / 2, S = rm.variants;
+  if (a) { a->assign(nw * S, 0.0); b->assign(nw * S, 0.0); st->assign(nw * S, 0); }
+  vector<fmh_wc_totals> per(rm.slabs.size());
+  on_slabs(rm, [&](const Slab& sl, size_t k) {
+    const size_t rows = sl.dm->variants;
+    Groups grp(*sl.dm, masks);
+    std::unique_ptr<DevBuf> da, db, ds;
+    if (a && rows) { da.reset(new DevBuf(sl.device, 8 * nw * rows)); db.reset(new DevBuf(sl.device, 8 * nw * rows)); ds.reset(new DevBuf(sl.device, nw * rows)); }
+    fmh_check(fmh_wc_sweep(sl.dm->h, grp.h, 0, rows, da ? (double*)da->p : nullptr, db ? (double*)db->p : nullptr, ds ? (uint8_t*)ds->p : nullptr, nullptr, &per[k], nullptr), "wc sweep");
+    if (da) {
+      vector<double> ha = da->fetch<double>(nw * rows), hb = db->fetch<double>(nw * rows);
+      vector<uint8_t> hs = ds->fetch<uint8_t>(nw * rows);
+      for (size_t w = 0; w < nw; ++w) {
+        std::copy(ha.begin() + (ptrdiff_t)(w * rows), ha.begin() + (ptrdiff_t)((w + 1) * rows), a->begin() + (ptrdiff_t)(w * S + sl.row0));
+        std::copy(hb.begin() + (ptrdiff_t)(w * rows), hb.begin() + (ptrdiff_t)((w + 1) * rows), b->begin() + (ptrdiff_t)(w * S + sl.row0));
+        std::copy(hs.begin() + (ptrdiff_t)(w * rows), hs.begin() + (ptrdiff_t)((w + 1) * rows), st->begin() + (ptrdiff_t)(w * S + sl.row0));
+      }
+    }
+    if (sl.comm) {
+      vector<double> f(FMH_WC_PACK_F64(nw));
+      vector<uint64_t> u(FMH_WC_PACK_U64(nw));
+      fmh_check(fmh_wc_totals_pack(&per[k], (int)G, f.data(), u.data()), "pack");
+      fmh_check(fmh_allreduce_totals(sl.comm, f.data(), f.size(), u.data(), u.size()), "all-reduce of the W&C totals");
+      fmh_check(fmh_wc_totals_unpack(&per[k], (int)G, f.data(), u.data()), "unpack");
+    }
+  });
+  return per[0];
+}
+
+// more than 8 groups: counting sweeps in batches + the counts kernel; regional sums only
+void sharded_wc_many(const RegionMatrix& rm, const vector<uint8_t>& flat_masks, size_t G, vector<double>& sum_a, vector<double>& sum_b, vector<uint64_t>& informative) {
+  const size_t nw = 1 + G * (G - 1) / 2;
+  vector<vector<double>> fa(rm.slabs.size(), vector<double>(2 * nw, 0.0));
+  vector<vector<uint64_t>> ui(rm.slabs.size(), vector<uint64_t>(nw, 0));
+  on_slabs(rm, [&](const Slab& sl, size_t k) {
+    fmh_check(fmh_wc_sweep_many(sl.dm->h, flat_masks.data(), (int)G, 0, sl.dm->variants, nullptr, nullptr, nullptr, nullptr, fa[k].data(), fa[k].data() + nw,
+                                ui[k].data(), nullptr), "wc sweep (many groups)");
+    if (sl.comm) {  // slot vectors beyond the communicator's per-call limit go in pieces
+      for (size_t off = 0; off < 2 * nw; off += FMH_COMM_MAX_VALUES)
+        fmh_check(fmh_allreduce_totals(sl.comm, fa[k].data() + off, std::min<size_t>(FMH_COMM_MAX_VALUES, 2 * nw - off), nullptr, 0), "all-reduce of the W&C sums");
+      for (size_t off = 0; off < nw; off += FMH_COMM_MAX_VALUES)
+        fmh_check(fmh_allreduce_totals(sl.comm, nullptr, 0, ui[k].data() + off, std::min<size_t>(FMH_COMM_MAX_VALUES, nw - off)), "all-reduce of the W&C site counts");
+    }
+  });
+  sum_a.assign(fa[0].begin(), fa[0].begin() + (ptrdiff_t)nw);
+  sum_b.assign(fa[0].begin() + (ptrdiff_t)nw, fa[0].end());
+  informative = ui[0];
+}
+
+// Hudson pair sweep: the library's own sharded entry point (sweep, device-side finalise, RCCL reduce, one synchronisation)
+fmh_hudson_totals sharded_hudson(const RegionMatrix& rm, const vector<uint8_t>& m0, const vector<uint8_t>& m1, int formula, vector<double>& fst,
+                                 vector<double>& num, vector<double>& den) {
+  const size_t S = rm.variants;
+  fst.assign(S, 0.0); num.assign(S, 0.0); den.assign(S, 0.0);
+  vector<fmh_hudson_totals> per(rm.slabs.size());
+  on_slabs(rm, [&](const Slab& sl, size_t k) {
+    const size_t rows = sl.dm->variants;
+    Groups grp(*sl.dm, {m0, m1});
+    DevBuf dfst(sl.device, 8 * std::max<size_t>(rows, 1)), dnum(sl.device, 8 * std::max<size_t>(rows, 1)), dden(sl.device, 8 * std::max<size_t>(rows, 1));
+    fmh_hudson_sites sites{};
+    sites.d_fst = (double*)dfst.p; sites.d_num = (double*)dnum.p; sites.d_den = (double*)dden.p;
+    if (sl.comm) fmh_check(fmh_hudson_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, formula, &sites, &per[k], nullptr), "sharded hudson sweep");
+    else fmh_check(fmh_hudson_sweep(sl.dm->h, grp.h, 0, rows, formula, &sites, &per[k], nullptr), "hudson sweep");
+    if (!rows) return;
+    vector<double> a = dfst.fetch<double>(rows), b = dnum.fetch<double>(rows), c = dden.fetch<double>(rows);
+    std::copy(a.begin(), a.end(), fst.begin() + (ptrdiff_t)sl.row0);
+    std::copy(b.begin(), b.end(), num.begin() + (ptrdiff_t)sl.row0);
+    std::copy(c.begin(), c.end(), den.begin() + (ptrdiff_t)sl.row0);
+  });
+  return per[0];
+}
 
 // ---- statistics (host scalars are literal restatements; genotype work is on the GPU) ------------------
 double harmonic(size_t n) { double s = 0.0; for (size_t k = 1; k <= n; ++k) s += 1.0 / (double)k; return s; }  // stats.rs:4234
@@ -1242,16 +1410,12 @@ void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix&
   }
   if (vs.empty() || (!out[0].present && !out[1].present)) return;
   const DeviceMatrix& dm = *rm.dm;
-  const size_t S = dm.variants;
+  const size_t S = rm.variants;
   // one pass: segregating sites + pi of both groups.  calculate_pi_for_population picks calculate_pi_dense
   // only for a diploid dense matrix (stats.rs:4603-4608), calculate_pi otherwise.
   const bool dense_arm = rm.has_dense && rm.ploidy == 2;
   vector<vector<uint8_t>> masks = {mask_of(haps[0], N, dm.ploidy, true), mask_of(haps[1], N, dm.ploidy, true)};
-  fmh_pop_totals tot[2];
-  {
-    Groups grp(dm, masks);
-    fmh_check(fmh_population_summaries(dm.h, grp.h, 0, S, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE, nullptr, nullptr, tot, nullptr), "summaries");
-  }
+  const vector<fmh_pop_totals> tot = sharded_summaries(rm, masks, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE);
   for (int g = 0; g < 2; ++g) {
     if (!out[g].present) continue;
     out[g].segsites = (size_t)tot[g].segregating_sites;
@@ -1259,10 +1423,8 @@ void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix&
     out[g].pi = pi_from_totals(rm, haps[g], masks[g], N, L, tot[g]);
     // calculate_per_site_diversity (stats.rs:4628-4806): needs >= 2 listed haplotypes
     if (haps[g].size() < 2 || hal_len(interval) <= 0) continue;
-    Groups one(dm, {masks[g]});
-    DevBuf dpi(device, 8 * S), dth(device, 8 * S);
-    fmh_check(fmh_diversity_sites(dm.h, one.h, 0, S, (double*)dpi.p, (double*)dth.p, nullptr, nullptr, nullptr, nullptr), "diversity");
-    vector<double> pi_v = dpi.fetch<double>(S), th_v = dth.fetch<double>(S);
+    vector<double> pi_v, th_v;
+    sharded_diversity(rm, masks[g], pi_v, th_v);
     for (size_t i = 0; i < S; ++i) {
       const int64_t pos0 = vs[i]->position;
       if (!hal_contains(interval, pos0)) continue;
@@ -1310,7 +1472,7 @@ WcRegion wc_haplotype_groups(const vector<const Variant*>& vs, const RegionMatri
   const size_t G = labels.size();
   if (vs.empty()) { out.value = std::nullopt; out.sites = 0; return out; }  // InsufficientData { sites_attempted: 0 }
   const DeviceMatrix& dm = *rm.dm;
-  const size_t S = dm.variants, P = dm.ploidy;
+  const size_t S = rm.variants, P = dm.ploidy;
   vector<vector<uint8_t>> masks(std::max<size_t>(G, 1), vector<uint8_t>(N * P, 0));
   for (auto& kv : hap_to_group) {
     if (kv.first.first >= N || (size_t)kv.first.second >= P) continue;
@@ -1321,11 +1483,8 @@ WcRegion wc_haplotype_groups(const vector<const Variant*>& vs, const RegionMatri
   if (G < 2) {
     // fewer than two groups: a site with any called allele is NoInterPopulationVariance (0, 0), a site with none is
     // InsufficientData (stats.rs:1925-1930, 1987-2003); "any called" comes from an all-columns summary sweep
-    Groups all(dm, {vector<uint8_t>(N * P, 1)});
-    DevBuf dcalled(device, 4 * S);
-    fmh_pop_totals t;
-    fmh_check(fmh_population_summaries(dm.h, all.h, 0, S, FMH_FORMULA_SPARSE, nullptr, (uint32_t*)dcalled.p, &t, nullptr), "summaries");
-    vector<uint32_t> called = dcalled.fetch<uint32_t>(S);
+    vector<uint32_t> called;
+    sharded_summaries(rm, {vector<uint8_t>(N * P, 1)}, FMH_FORMULA_SPARSE, &called);
     size_t informative = 0;
     for (size_t i = 0; i < S; ++i) {
       informative += called[i] != 0;
@@ -1336,13 +1495,9 @@ WcRegion wc_haplotype_groups(const vector<const Variant*>& vs, const RegionMatri
     return out;
   }
   if (G > FMH_MAX_GROUPS) throw Error("more than 8 haplotype groups");
-  const size_t nw = 1 + G * (G - 1) / 2;
-  Groups grp(dm, masks);
-  DevBuf da(device, 8 * nw * S), db(device, 8 * nw * S), ds(device, nw * S);
-  fmh_wc_totals tot;
-  fmh_check(fmh_wc_sweep(dm.h, grp.h, 0, S, (double*)da.p, (double*)db.p, (uint8_t*)ds.p, nullptr, &tot, nullptr), "wc sweep");
-  vector<double> a = da.fetch<double>(nw * S), b = db.fetch<double>(nw * S);
-  vector<uint8_t> st = ds.fetch<uint8_t>(nw * S);
+  vector<double> a, b;
+  vector<uint8_t> st;
+  const fmh_wc_totals tot = sharded_wc(rm, masks, &a, &b, &st);
   for (size_t i = 0; i < S; ++i) {
     WcSite w{vs[i]->position + 1, NAN, 0.0, 0.0, NAN, NAN, NAN};
     if (st[i] != FMH_WC_INSUFFICIENT) {
@@ -1422,15 +1577,13 @@ vector<vector<string>> wc_csv_population_rows(const vector<const Variant*>& vs, 
   WcEstimate insufficient;
   if (vs.empty()) { rows.push_back(row("overall", "ALL", "ALL", insufficient)); return rows; }  // sites_attempted 0, no pair keys
   const DeviceMatrix& dm = *rm.dm;
-  const size_t S = dm.variants, P = dm.ploidy;
+  const size_t S = rm.variants, P = dm.ploidy;
   if (G > FMH_MAX_GROUPS_MANY) throw Error("--fst_populations: more than 256 populations");
   if (G < 2) {
-    Groups all(dm, {vector<uint8_t>(N * P, 1)});
-    DevBuf dcalled(device, 4 * S);
-    fmh_pop_totals t;
-    fmh_check(fmh_population_summaries(dm.h, all.h, 0, S, FMH_FORMULA_SPARSE, nullptr, (uint32_t*)dcalled.p, &t, nullptr), "summaries");
+    vector<uint32_t> called;
+    sharded_summaries(rm, {vector<uint8_t>(N * P, 1)}, FMH_FORMULA_SPARSE, &called);
     size_t informative = 0;
-    for (uint32_t c : dcalled.fetch<uint32_t>(S)) informative += c != 0;
+    for (uint32_t c : called) informative += c != 0;
     WcEstimate e;
     if (informative) { e = wc_estimate(0.0, 0.0, informative); } else { e.sites = S; }
     rows.push_back(row("overall", "ALL", "ALL", e));
@@ -1447,15 +1600,12 @@ vector<vector<string>> wc_csv_population_rows(const vector<const Variant*>& vs, 
   const size_t nslots = 1 + G * (G - 1) / 2;
   tot.sum_a.assign(nslots, 0.0); tot.sum_b.assign(nslots, 0.0); tot.informative_sites.assign(nslots, 0);
   if (G <= FMH_MAX_GROUPS) {
-    Groups grp(dm, masks);
-    fmh_wc_totals t8;
-    fmh_check(fmh_wc_sweep(dm.h, grp.h, 0, S, nullptr, nullptr, nullptr, nullptr, &t8, nullptr), "wc sweep");
+    const fmh_wc_totals t8 = sharded_wc(rm, masks, nullptr, nullptr, nullptr);
     for (size_t k2 = 0; k2 < nslots; ++k2) { tot.sum_a[k2] = t8.sum_a[k2]; tot.sum_b[k2] = t8.sum_b[k2]; tot.informative_sites[k2] = t8.informative_sites[k2]; }
   } else {
     vector<uint8_t> flat;
     for (auto& m2 : masks) flat.insert(flat.end(), m2.begin(), m2.end());
-    fmh_check(fmh_wc_sweep_many(dm.h, flat.data(), (int)G, 0, S, nullptr, nullptr, nullptr, nullptr, tot.sum_a.data(), tot.sum_b.data(),
-                                tot.informative_sites.data(), nullptr), "wc sweep (many groups)");
+    sharded_wc_many(rm, flat, G, tot.sum_a, tot.sum_b, tot.informative_sites);
   }
   WcEstimate overall;
   if (tot.informative_sites[0] == 0) overall.sites = S; else overall = wc_estimate(tot.sum_a[0], tot.sum_b[0], (size_t)tot.informative_sites[0]);
@@ -1498,14 +1648,9 @@ HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix&
   const size_t N = sample_names.size();
   if (!vs.empty()) {
     const DeviceMatrix& dm = *rm.dm;
-    const size_t S = dm.variants;
-    Groups grp(dm, {mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false)});
-    DevBuf dfst(device, 8 * S), dnum(device, 8 * S), dden(device, 8 * S);
-    fmh_hudson_sites sites{};
-    sites.d_fst = (double*)dfst.p; sites.d_num = (double*)dnum.p; sites.d_den = (double*)dden.p;
-    fmh_hudson_totals tot;
-    fmh_check(fmh_hudson_sweep(dm.h, grp.h, 0, S, FMH_FORMULA_SPARSE, &sites, &tot, nullptr), "hudson sweep");
-    vector<double> fst = dfst.fetch<double>(S), num = dnum.fetch<double>(S), den = dden.fetch<double>(S);
+    const size_t S = rm.variants;
+    vector<double> fst, num, den;
+    const fmh_hudson_totals tot = sharded_hudson(rm, mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false), FMH_FORMULA_SPARSE, fst, num, den);
     num_sum = tot.site_num_sum; den_sum = tot.site_den_sum; dxy_sum = tot.site_dxy_sum; dxy_skipped = tot.site_dxy_skipped;
     size_t informative = 0;
     for (size_t i = 0; i < S; ++i) informative += (!std::isnan(den[i]) && std::isfinite(den[i]) && den[i] > 0.0);
@@ -1788,8 +1933,13 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
   const size_t N = vcf.sample_names.size();
   std::optional<StageTimer> tm;
   tm.emplace("  region:pack_and_upload_matrices");
-  RegionMatrix m_unf = build_matrix(unf, N, args.device);
-  RegionMatrix m_fil = fil == unf ? m_unf : build_matrix(fil, N, args.device);  // same variants -> one matrix in HBM
+  // a region large enough to be worth it is split into one site slab per --devices GPU; the communicators are shared, so only one
+  // such region is in flight at a time (small regions keep flowing through the other workers)
+  const bool shard = want_shard(std::max(unf.size(), fil.size()), N);
+  std::unique_lock<std::mutex> shard_lock(g_shard.region_mutex, std::defer_lock);
+  if (shard) shard_lock.lock();
+  RegionMatrix m_unf = build_matrix(unf, N, args.device, shard && want_shard(unf.size(), N));
+  RegionMatrix m_fil = fil == unf ? m_unf : build_matrix(fil, N, args.device, shard && want_shard(fil.size(), N));  // same variants -> one matrix in HBM
   tm.emplace("  region:gpu_sweeps_and_host_statistics");
 
   WcRegion wc;
@@ -1858,9 +2008,7 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
         const size_t cnt = std::min<size_t>(FMH_MAX_GROUPS, names.size() - b);
         vector<vector<uint8_t>> masks;
         for (size_t i = 0; i < cnt; ++i) masks.push_back(mask_of(pop_haps[names[b + i]], N, m_fil.dm->ploidy, true));
-        Groups grp(*m_fil.dm, masks);
-        fmh_pop_totals tot[FMH_MAX_GROUPS];
-        fmh_check(fmh_population_summaries(m_fil.dm->h, grp.h, 0, m_fil.dm->variants, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE, nullptr, nullptr, tot, nullptr), "summaries");
+        const vector<fmh_pop_totals> tot = sharded_summaries(m_fil, masks, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE);
         for (size_t i = 0; i < cnt; ++i) pop_pi[names[b + i]] = pi_from_totals(m_fil, pop_haps[names[b + i]], masks[i], N, fil_adj, tot[i]);
       }
     } else {
@@ -1924,7 +2072,28 @@ void erase_excluded(SampleMap& m, const std::set<string>& ex) {
   m.erase(std::remove_if(m.begin(), m.end(), [&](const auto& kv) { return ex.count(kv.first) > 0; }), m.end());
 }
 
+// --devices with more than one entry: one communicator per listed GPU (fmh_comm_init_all: RCCL over xGMI; the in-process host
+// rendezvous when a GPU is listed twice), released when run() ends
+struct ShardSetup {
+  explicit ShardSetup(const Args& args) {
+    if (args.devices.size() < 2 || args.ingest_only) return;
+    if (const char* e = getenv("FERROMIC_SHARD_MIN_BYTES")) g_shard.min_bytes = (size_t)strtoull(e, nullptr, 10);
+    g_shard.devices = args.devices;
+    g_shard.comms.assign(args.devices.size(), nullptr);
+    const int rc = fmh_comm_init_all(g_shard.devices.data(), (int)g_shard.devices.size(), g_shard.comms.data());
+    if (rc != FMH_OK) {  // no RCCL on this host: regions stay whole (the worker queue still spreads them over the GPUs)
+      logmsg("WARN", string("large regions will not be split across --devices: ") + fmh_last_error());
+      g_shard.comms.clear();
+    }
+  }
+  ~ShardSetup() {
+    for (fmh_comm* c : g_shard.comms) fmh_comm_destroy(c);
+    g_shard.comms.clear();
+  }
+};
+
 int run(const Args& args) {
+  ShardSetup shard_setup(args);
   std::optional<RegionMap> mask_regions, allow_regions;
   if (!args.mask_file.empty()) mask_regions = parse_regions_file(args.mask_file);
   if (!args.allow_file.empty()) allow_regions = parse_regions_file(args.allow_file);
