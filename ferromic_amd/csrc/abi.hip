@@ -200,6 +200,7 @@ extern "C" int fmh_stream_synchronize(int device, void* stream) {
 // LDS the sweep needs for P (padded) groups of an `nvec`-vector row, masks as bytes (fast) or as bits (8x the width);
 // the kernels take at most 150 KiB.  sweep_lds_bytes() > limit means "does not fit in LDS in either form".
 static const size_t kSweepLdsLimit = 150 * 1024;
+static size_t sweep_lds_limit(int padded, int mode) { (void)padded; (void)mode; return kSweepLdsLimit; }
 static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 2; }
 
 static int check_dims(size_t variants, size_t samples, size_t ploidy) {
@@ -779,6 +780,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   size_t smem = (size_t)P * a.nvec_pad * 16;
   int mask_mode = kMaskLdsBytes;
   int lpr = 16;
+  const size_t lds_limit = sweep_lds_limit(P, mode);
   if (packed) {
     // 128 columns per vector.  Rows of up to 32 vectors (4 096 columns) are shared by FOUR lanes (no idle vector slots
     // on short rows, a two-step reduction: C2 0.081 -> 0.042 ms, C3 0.94 -> 0.63 ms), wider ones by the sixteen lanes of a
@@ -788,8 +790,8 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;  // read per call: tests flip them
     const int env_lpr = getenv("FMH_PACKED_LPR") ? atoi(getenv("FMH_PACKED_LPR")) : 0;
     lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
-    // eight groups on the multi-allelic path: only the shallow batches are built (deeper ones spilled to scratch)
-    const bool shallow = general && P == 8;
+    // eight groups: only the shallow batches are built (deeper ones kept P x U mask vectors live and spilled)
+    const bool shallow = P == 8;
     const int us4[4] = {1, 2, 3, 5}, us16[3] = {2, 3, 4};
     const int* us = lpr != 16 ? us4 : us16;
     const int nus = shallow ? (lpr != 16 ? 2 : 1) : (lpr != 16 ? 4 : 3);
@@ -805,12 +807,12 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH");
     smem = (size_t)P * a.nvec_pad * 16;
     mask_mode = kMaskPacked;
-    if (smem > kSweepLdsLimit)
+    if (smem > lds_limit)
       return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep fewer groups at a time on rows this wide", P, m->columns);
-  } else if (smem > kSweepLdsLimit) {  // byte masks do not fit LDS: bits in LDS if those fit, else bytes in global memory (L2)
+  } else if (smem > lds_limit) {  // byte masks do not fit LDS: bits in LDS if those fit, else bytes in global memory (L2)
     smem = (size_t)P * a.nvec_pad * 2;
     mask_mode = kMaskLdsBits;
-    if (smem > kSweepLdsLimit) { smem = 0; mask_mode = kMaskGlobalBytes; }
+    if (smem > lds_limit) { smem = 0; mask_mode = kMaskGlobalBytes; }
   }
   // BASELINE config C5: the counts as an int8 matrix-core contraction (sweep_mfma_kernels.hpp), for u8 rows that are biallelic with
   // nothing missing and at most four (padded) groups.  An alternative route: the contraction has <= 4 output rows and stays HBM-bound,
@@ -819,7 +821,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   const int mfma_unroll = env_mfma && atoi(env_mfma) == 2 ? 2 : 4;
   // (rows whose byte masks do not fit LDS stay on the dot4 routes)
   const bool mfma = !packed && env_mfma && atoi(env_mfma) != 0 && !missing && !general && P <= 4 &&
-                    (size_t)P * mfma_mask_stride(m->nvec, mfma_unroll) * 16 <= kSweepLdsLimit;
+                    (size_t)P * mfma_mask_stride(m->nvec, mfma_unroll) * 16 <= lds_limit;
   if (mfma) {
     a.unroll = mfma_unroll;
     a.nvec_pad = mfma_mask_stride(m->nvec, a.unroll);
@@ -1040,7 +1042,7 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   }
   // the fused kernel for 5..8 groups keeps the counts of alleles 0..3 per site; cohorts with alleles beyond 3 take the counts route
   const bool many_alleles8 = m && g && g->padded == 8 && m->max_allele > 3;
-  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit)) {
+  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(g->padded, kModeWc))) {
     // (or: rows too wide for all groups' masks to sit in LDS at once) count in smaller batches, components from the count tables
     const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
     std::vector<double> sa(nslots), sb(nslots);

@@ -260,12 +260,77 @@ __host__ __device__ __forceinline__ WcShape wc_shape(const uint32_t (&n)[R], con
   return s;
 }
 
-// numerator_s_squared = sum n_i (p_i - p)^2 is accumulated by the caller; this finishes a and b.
-__device__ __forceinline__ void wc_apply(const WcShape& s, double numerator_s_squared, double global_p, double& a, double& b) {
-  double s_squared = s.s2_ok ? numerator_s_squared / s.s2_den : 0.0;
+// ---- divisions that share a denominator ---------------------------------------------------------------------------------------
+// Without missing data every W&C division of a site divides by a LAUNCH constant (group sizes, their sums, the WcShape terms):
+// 64 divisions per biallelic four-group site, and the C3 sweep is VALU-bound on them (profiles/r02: VALU busy 0.82 per SIMD).
+// An IEEE f64 division on gfx950 is hipcc's sequence  r = refine(v_rcp_f64(d));  q0 = n * r;  e = fma(-d, q0, n);
+// q = fma(e, r, q0)  wrapped in v_div_scale / v_div_fmas / v_div_fixup, which only act on operands near the exponent limits,
+// zero or non-finite denominators.  The reciprocal part depends on d alone, so it is computed ONCE per workgroup for every
+// denominator of the launch (wc_rcp_init, into LDS) and a division is the last three operations (div_shared): the same
+// instructions on the same operands as the full sequence, hence the same correctly rounded quotient bit for bit - for the
+// operands this path sees (counts, frequencies, their variances: |exponent| < 200, denominators >= 1e-9).  The parity suite
+// holds every per-site a, b against the oracle bit for bit (35 M values at C3's full size).
+__device__ __forceinline__ double refined_rcp(double d) {
+  const double r0 = __builtin_amdgcn_rcp(d);
+  const double e0 = __builtin_fma(-d, r0, 1.0);
+  const double r1 = __builtin_fma(r0, e0, r0);
+  const double e1 = __builtin_fma(-d, r1, 1.0);
+  return __builtin_fma(r1, e1, r1);
+}
+__device__ __forceinline__ double div_shared(double n, double d, double r) {
+  const double q0 = n * r;
+  const double e = __builtin_fma(-d, q0, n);
+  return __builtin_fma(e, r, q0);
+}
+// the workgroup's table of refined reciprocals: [0, P) group sizes | [P] their sum | [P + 1 + 3 k + {0, 1, 2}] s2_den, nbar_m1, a_den
+// of slot k | then the pair totals n_i + n_j in pair order
+__device__ __forceinline__ double* wc_rcp_table() {
+  __shared__ double table[8 + 1 + 3 * kMaxWcSlots + kMaxWcSlots];
+  return table;
+}
+template <int P>
+__device__ __forceinline__ void wc_rcp_init(const SweepArgs& A) {  // every thread of the block, before a __syncthreads()
+  constexpr int NW = 1 + (P * (P - 1)) / 2;
+  double* table = wc_rcp_table();
+  // Wave w fills the entries I = w (mod 4): all its lanes write the same value to the same word.  The wave index is made provably
+  // uniform and every index into the kernel arguments is a compile-time constant of a fully unrolled loop, so each entry is a scalar
+  // branch around scalar loads (a lane-dependent or runtime index made hipcc copy the 1.7 KB argument struct to scratch memory).
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned long long total = 0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    total += A.group_size[i];
+    if (wave == (i & 3)) table[i] = refined_rcp((double)A.group_size[i]);
+  }
+  if (wave == (P & 3)) table[P] = refined_rcp((double)total);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    if (wave == (k & 3)) {
+      table[P + 1 + 3 * k + 0] = refined_rcp(A.wc_shape[k].s2_den);
+      table[P + 1 + 3 * k + 1] = refined_rcp(A.wc_shape[k].nbar_m1);
+      table[P + 1 + 3 * k + 2] = refined_rcp(A.wc_shape[k].a_den);
+    }
+  }
+  int q = 0;
+#pragma unroll
+  for (int x = 0; x < P; ++x) {
+#pragma unroll
+    for (int y = x + 1; y < P; ++y) {
+      if (wave == (q & 3)) table[P + 1 + 3 * NW + q] = refined_rcp((double)((unsigned long long)A.group_size[x] + A.group_size[y]));
+      ++q;
+    }
+  }
+}
+
+// numerator_s_squared = sum n_i (p_i - p)^2 is accumulated by the caller; this finishes a and b.  rcp3 = the slot's three shared
+// reciprocals (PRE) or null.
+template <bool PRE>
+__device__ __forceinline__ void wc_apply(const WcShape& s, double numerator_s_squared, double global_p, double& a, double& b, const double* rcp3) {
+  double s_squared = 0.0;
+  if (s.s2_ok) s_squared = PRE ? div_shared(numerator_s_squared, s.s2_den, rcp3[0]) : numerator_s_squared / s.s2_den;
   double x_wc = global_p * (1.0 - global_p) - s.rm1_over_r * s_squared;
-  double a_numerator_term = s_squared - (x_wc / s.nbar_m1);
-  a = a_numerator_term / s.a_den;
+  double a_numerator_term = s_squared - (PRE ? div_shared(x_wc, s.nbar_m1, rcp3[1]) : x_wc / s.nbar_m1);
+  a = PRE ? div_shared(a_numerator_term, s.a_den, rcp3[2]) : a_numerator_term / s.a_den;
   b = s.b_fac * x_wc;
 }
 __device__ __forceinline__ uint8_t wc_classify(double a, double b) {
@@ -305,6 +370,8 @@ struct WcSite {
 // (has_data always; (0, 0) when fewer than two groups have data), k >= 1 pairs (has_data = both groups have data).
 template <int P, int NA, bool PRE, class Emit>
 __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint32_t (&n)[P], const uint32_t (&c)[NA][P], Emit&& emit) {
+  constexpr int NWS = 1 + (P * (P - 1)) / 2;
+  const double* rcp = PRE ? wc_rcp_table() : nullptr;  // PRE: every denominator below is a launch constant (wc_rcp_init)
   bool use[P];
   double nd[P], freq[NA][P];
   int valid = 0;
@@ -315,7 +382,11 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
     nd[i] = (double)n[i];
     if (use[i]) { ++valid; total_called += n[i]; }
 #pragma unroll
-    for (int al = 0; al < NA; ++al) freq[al][i] = use[i] ? (double)c[al][i] / nd[i] : 0.0;
+    for (int al = 0; al < NA; ++al) {
+      double f = 0.0;
+      if (use[i]) f = PRE ? div_shared((double)c[al][i], nd[i], rcp[i]) : (double)c[al][i] / nd[i];
+      freq[al][i] = f;
+    }
   }
   {
     double wa = 0.0, wb = 0.0;
@@ -328,12 +399,13 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
           unsigned long long total_target = 0;
 #pragma unroll
           for (int i = 0; i < P; ++i) if (use[i]) total_target += c[al][i];
-          double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
+          double global_freq = 0.0;
+          if (total_called > 0) global_freq = PRE ? div_shared((double)total_target, (double)total_called, rcp[P]) : (double)total_target / (double)total_called;
           double num = 0.0;
 #pragma unroll
           for (int i = 0; i < P; ++i) if (use[i]) { double diff_p = freq[al][i] - global_freq; num += nd[i] * diff_p * diff_p; }
           double ca, cb;
-          wc_apply(sh, num, global_freq, ca, cb);
+          wc_apply<PRE>(sh, num, global_freq, ca, cb, PRE ? rcp + P + 1 : nullptr);
           wa += ca;
           wb += cb;
         }
@@ -361,12 +433,16 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
           unsigned long long pair_total = (unsigned long long)n[i] + n[j];
 #pragma unroll
           for (int al = 0; al < NA; ++al) {
-            double pair_global = pair_total > 0 ? (double)((unsigned long long)c[al][i] + c[al][j]) / (double)pair_total : 0.0;
+            double pair_global = 0.0;
+            if (pair_total > 0) {
+              const double pair_target = (double)((unsigned long long)c[al][i] + c[al][j]);
+              pair_global = PRE ? div_shared(pair_target, (double)pair_total, rcp[P + 1 + 3 * NWS + (k - 1)]) : pair_target / (double)pair_total;
+            }
             double num = 0.0;
             { double diff_p = freq[al][i] - pair_global; num += nd[i] * diff_p * diff_p; }
             { double diff_p = freq[al][j] - pair_global; num += nd[j] * diff_p * diff_p; }
             double pa, pb;
-            wc_apply(sh, num, pair_global, pa, pb);
+            wc_apply<PRE>(sh, num, pair_global, pa, pb, PRE ? rcp + P + 1 + 3 * k : nullptr);
             wa += pa;
             wb += pb;
           }
@@ -577,15 +653,20 @@ __device__ __forceinline__ uint32_t allele_count_from_planes(uint32_t a, uint32_
 // batch of U loads per lane covers (C4: 40 vectors, 16 lanes x 3).  Then (1) a lane's mask vectors are the same for every
 // row, so they are read from LDS once per tile into registers, and (2) the loads of row s + 1 are issued before the
 // popcounts and the reduction of row s, so a wave always has two rows of loads in flight instead of one.
+// (With many groups or a deep batch the mask vectors would take P x U x 4 registers - 80 for four groups on C3's 20-vector rows, which
+// held that kernel at two waves per SIMD - so beyond 12 vectors they stay in LDS and are re-read per row: MREG = false.)
 template <int P, int U, int LPR>
 __device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, const MatrixView& mv, const uint4* __restrict__ lds_mask,
                                                           uint32_t nvec_pad, size_t tile_row0, int grp, int gl, uint32_t (&alt_mine)[P]) {
+  constexpr bool MREG = P * U <= 12;
   const uint32_t last = mv.nvec - 1;
-  uint4 m[P][U];
+  uint4 m[MREG ? P : 1][MREG ? U : 1];
+  if constexpr (MREG) {
 #pragma unroll
-  for (int p = 0; p < P; ++p)
+    for (int p = 0; p < P; ++p)
 #pragma unroll
-    for (int u = 0; u < U; ++u) m[p][u] = lds_mask[(uint32_t)p * nvec_pad + (uint32_t)gl + LPR * u];  // zero beyond the row
+      for (int u = 0; u < U; ++u) m[p][u] = lds_mask[(uint32_t)p * nvec_pad + (uint32_t)gl + LPR * u];  // zero beyond the row
+  }
   auto load_row = [&](uint4 (&dst)[U], int s) {
     const size_t rel = tile_row0 + (size_t)grp * LPR + s;
     const size_t row = A.row_begin + (rel < A.row_count ? rel : A.row_count - 1);  // rows past the end re-read the last one
@@ -597,12 +678,17 @@ __device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, co
     }
   };
   auto count_row = [&](const uint4 (&x)[U], int s) {
+    // masks in LDS: keep their reads inside the row (hoisted out of the row loop they would be the P x U register image again)
+    if constexpr (!MREG) asm volatile("" ::: "memory");
     uint32_t alt[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       alt[p] = 0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) alt[p] = popc128(and128(x[u], m[p][u]), alt[p]);
+      for (int u = 0; u < U; ++u) {
+        if constexpr (MREG) alt[p] = popc128(and128(x[u], m[p][u]), alt[p]);
+        else alt[p] = popc128(and128(x[u], lds_mask[(uint32_t)p * nvec_pad + (uint32_t)gl + LPR * u]), alt[p]);
+      }
       alt[p] = group_sum<LPR>(alt[p]);
     }
     if (gl == s) {
@@ -738,9 +824,10 @@ struct LaneTotals {
   // W&C regional sums per slot; for P = 8 (29 slots = 174 registers of accumulators) they are NOT kept per lane: the
   // host sums the per-site tracks with wc_slot_reduce_kernel instead (kWcLaneTotals)
   static constexpr bool kWcLaneTotals = (MODE & kModeWc) != 0 && P < 8;
-  double wc_a[kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1];
-  double wc_b[kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1];
-  unsigned long long wc_inf[kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1];
+  static constexpr int kWcRegSlots = kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1;
+  double wc_a[kWcRegSlots];
+  double wc_b[kWcRegSlots];
+  unsigned long long wc_inf[kWcRegSlots];
 
   __device__ __forceinline__ void clear() {
 #pragma unroll
@@ -749,9 +836,8 @@ struct LaneTotals {
     for (int i = 0; i < kHudF64; ++i) hud[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < kHudU64; ++i) hud_u[i] = 0;
-    constexpr int NW = kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { wc_a[i] = 0.0; wc_b[i] = 0.0; wc_inf[i] = 0; }
+    for (int i = 0; i < kWcRegSlots; ++i) { wc_a[i] = 0.0; wc_b[i] = 0.0; wc_inf[i] = 0; }
   }
 };
 
@@ -1045,6 +1131,10 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
     lds_mask = staged;
   }
 
+  if constexpr ((MODE & kModeWc) != 0 && !MISSING) {
+    wc_rcp_init<P>(A);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int grp = lane / LPR;   // the wave's 64 / LPR groups take LPR rows of the tile each, one row per step
@@ -1055,8 +1145,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   T.clear();
 
   const size_t ntiles = (A.row_count + kTileRows - 1) / kTileRows;
-  for (size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles;
-       tile += (size_t)gridDim.x * kWavesPerBlock) {
+  const size_t tile_stride = (size_t)gridDim.x * kWavesPerBlock;
+  for (size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += tile_stride) {
     const size_t tile_row0 = tile * kTileRows;  // relative to row_begin
     SiteTally<P> mine;
     WcSite<P> wc;
@@ -1077,7 +1167,10 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         uint32_t alt_mine[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) alt_mine[p] = 0;
-        if constexpr (LPR != 16) {
+        if constexpr (P == 8) {  // eight groups: the shallow batches only (see kShallow below)
+          if (LPR != 16 && A.unroll == 1) tile_rows_packed_prefetch<P, 1, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+          else tile_rows_packed_prefetch<P, 2, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+        } else if constexpr (LPR != 16) {
           if (A.unroll == 5) tile_rows_packed_prefetch<P, 5, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
           else if (A.unroll == 3) tile_rows_packed_prefetch<P, 3, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
           else if (A.unroll == 2) tile_rows_packed_prefetch<P, 2, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
@@ -1104,7 +1197,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       for (int k = 0; k < NS; ++k) my_s[p][k] = 0;
     // packed cores: the batch depth U is the launch's (A.unroll); with eight groups on the general path only the shallow batches are
     // built - deeper ones kept P x U mask vectors live and spilled to scratch
-    constexpr bool kShallow = GENERAL && P == 8;
+    constexpr bool kShallow = P == 8;
     for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;

@@ -28,7 +28,7 @@ int launch_mfma(const SweepArgs& args, size_t smem, hipStream_t st, const Launch
   const size_t ntiles = (args.row_count + kTileRows - 1) / kTileRows;
   size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
   const size_t cap = (size_t)ctx.cus * cached_occ[dev];
-  if (blocks > cap) blocks = cap;
+  if (blocks > cap) blocks = cap;  // persistent grid (equalising the tile rounds per workgroup was measured: fewer resident waves, slower)
   if (blocks > (size_t)ctx.max_grid) blocks = ctx.max_grid;
   if (blocks < 1) blocks = 1;
   if (ctx.timing) HIP_TRY(hipEventRecord(ctx.ev0, st));

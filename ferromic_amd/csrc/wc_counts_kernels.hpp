@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_allele
             num += nd * diff_p * diff_p;
           }
           double ca, cb;
-          wc_apply(ms.sh, num, global_freq, ca, cb);
+          wc_apply<false>(ms.sh, num, global_freq, ca, cb, nullptr);
           wa += ca;
           wb += cb;
         }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_allele
           { const double diff_p = (double)ci / ndi - pair_global; num += ndi * diff_p * diff_p; }
           { const double diff_p = (double)cj / ndj - pair_global; num += ndj * diff_p * diff_p; }
           double pa, pb;
-          wc_apply(ms.sh, num, pair_global, pa, pb);
+          wc_apply<false>(ms.sh, num, pair_global, pa, pb, nullptr);
           wa += pa;
           wb += pb;
         }
