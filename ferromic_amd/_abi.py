@@ -112,6 +112,7 @@ SYMBOLS = {
     "fmh_device_zero": (_i, [_i, _vp, _sz, _vp]),
     "fmh_stream_synchronize": (_i, [_i, _vp]),
     "fmh_matrix_create": (_i, [_vp, _vp, _sz, _sz, _sz, _u8, _i, _P(_vp)]),
+    "fmh_matrix_create_packed": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _u8, _i, _P(_vp)]),
     "fmh_matrix_alloc": (_i, [_sz, _sz, _sz, _i, _u8, _i, _P(_vp)]),
     "fmh_matrix_wrap": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _sz, _u8, _i, _P(_vp)]),
     "fmh_matrix_destroy": (_i, [_vp]),

@@ -342,42 +342,10 @@ extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missin
     auto bail = [&](int code) { fmh_matrix_destroy(m); return code; };
     if (alloc_planes(m) != FMH_OK) return bail(FMH_ERR_HIP);
     if (variants == 0) { *out = m; return FMH_OK; }
-    hipError_t e = hipSuccess;
-    if (h_missing) {
-      const size_t words = (variants * (size_t)m->columns + 63) / 64;
-      unsigned long long* d_words = nullptr;
-      e = pool_malloc(device, (void**)&d_words, words * 8);
-      if (e == hipSuccess) e = hipMemcpy(d_words, h_missing, words * 8, hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemset(m->pc, 0, variants * m->plane_pitch);
-      if (e == hipSuccess) {
-        const size_t total = variants * m->plane_pitch;
-        const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
-        hipLaunchKernelGGL(missing_to_called_rows, dim3(blocks), dim3(256), 0, 0, d_words, variants, m->columns, m->pc, m->plane_pitch);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-      }
-      pool_free(device, d_words);
-      if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "missing-mask upload failed: %s", hipGetErrorString(e)));
-    }
-    const size_t slab_rows = std::max<size_t>(1, std::min<size_t>(variants, ((size_t)256 << 20) / m->pitch));
-    uint8_t* d_slab = nullptr;
-    unsigned int* d_overflow = nullptr;
-    unsigned int overflow = 0;
-    e = pool_malloc(device, (void**)&d_slab, slab_rows * m->pitch);
-    if (e == hipSuccess) e = hipMemset(d_slab, 0, slab_rows * m->pitch);  // padding columns stay zero
-    if (e == hipSuccess) e = pool_malloc(device, (void**)&d_overflow, 4);
-    if (e == hipSuccess) e = hipMemset(d_overflow, 0, 4);
-    for (size_t r0 = 0; r0 < variants && e == hipSuccess; r0 += slab_rows) {
-      const size_t rows = std::min(slab_rows, variants - r0);
-      e = hipMemcpy2D(d_slab, m->pitch, h_data + r0 * m->columns, m->columns, m->columns, rows, hipMemcpyHostToDevice);
-      // the called plane (already built from the missing bitset) tells the packer which entries count for the max_allele check
-      if (e == hipSuccess) e = pack_rows(m, d_slab, m->pitch, m->pc ? m->pc + r0 * m->plane_pitch : nullptr, m->plane_pitch, r0, rows, 0, d_overflow);
-      if (e == hipSuccess) e = hipDeviceSynchronize();
-    }
-    if (e == hipSuccess) e = hipMemcpy(&overflow, d_overflow, 4, hipMemcpyDeviceToHost);
-    pool_free(device, d_slab);
-    pool_free(device, d_overflow);
-    if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "matrix upload failed: %s", hipGetErrorString(e)));
+    // packed on the host (threads + SSE2) into pinned staging, ceil(H / 8) bytes per site and plane over PCIe (upload.hip)
+    bool overflow = false;
+    const int rc = upload_planes_from_bytes(m, h_data, h_missing, &overflow);
+    if (rc != FMH_OK) return bail(rc);
     if (overflow) return bail(fail(FMH_ERR_INVALID, "a called entry holds an allele above max_allele = %u: the packed layout cannot represent it", (unsigned)max_allele));
     *out = m;
     return FMH_OK;
@@ -407,6 +375,34 @@ extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missin
     pool_free(device, d_words);
     if (e != hipSuccess) return bail(fail(FMH_ERR_HIP, "missing-mask upload failed: %s", hipGetErrorString(e)));
   }
+  return FMH_OK;
+}
+
+extern "C" int fmh_matrix_create_packed(const uint8_t* h_plane0, const uint8_t* h_plane1, const uint8_t* h_plane2, const uint8_t* h_called,
+                                        size_t h_pitch, size_t variants, size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMH_TRY(check_dims(variants, samples, ploidy));
+  const uint32_t columns = (uint32_t)(samples * ploidy);
+  if (!packable(max_allele, columns)) return fail(FMH_ERR_UNSUPPORTED, "the packed layout holds alleles 0..7 on rows of at most %u columns", kPackMaxColumns);
+  if (!h_plane0 && variants) return fail(FMH_ERR_INVALID, "h_plane0 is NULL");
+  if ((max_allele >= 2) != (h_plane1 != nullptr) || (max_allele >= 4) != (h_plane2 != nullptr))
+    return fail(FMH_ERR_INVALID, "max_allele %u needs %d allele plane(s)", (unsigned)max_allele, max_allele >= 4 ? 3 : (max_allele >= 2 ? 2 : 1));
+  if (variants && h_pitch < ((size_t)columns + 7) / 8) return fail(FMH_ERR_INVALID, "h_pitch %zu is smaller than a row of %u columns", h_pitch, columns);
+  FMH_TRY(use_device(device));
+  fmh_matrix* m = new fmh_matrix();
+  m->device = device;
+  m->variants = variants; m->samples = samples; m->ploidy = ploidy;
+  m->columns = columns;
+  m->pitch = round_up(columns, 16);
+  m->nvec = (uint32_t)(m->pitch / 16);
+  m->max_allele = max_allele;
+  m->has_missing = h_called != nullptr;
+  if (alloc_planes(m) != FMH_OK) { fmh_matrix_destroy(m); return FMH_ERR_HIP; }
+  const uint8_t* planes[4] = {h_plane0, h_plane1, h_plane2, h_called};
+  const int rc = upload_planes_from_planes(m, planes, h_pitch);
+  if (rc != FMH_OK) { fmh_matrix_destroy(m); return rc; }
+  *out = m;
   return FMH_OK;
 }
 
@@ -1185,5 +1181,6 @@ extern "C" int fmh_device_release_scratch(int device) {
   w->pd_planes = nullptr;
   w->pd_planes_bytes = 0;
   pool_trim(device);
+  upload_release(device);
   return FMH_OK;
 }

@@ -116,6 +116,11 @@ struct SweepBuffers {
 struct fmh_matrix;
 struct fmh_groups;
 namespace fmhi {
+// host buffers -> the (already allocated) planes of a packed matrix (upload.hip): packed on the host into pinned staging, copied
+// asynchronously; *overflow = a called entry carries an allele above max_allele
+int upload_planes_from_bytes(fmh_matrix* m, const uint8_t* h_data, const uint64_t* h_missing, bool* overflow);
+int upload_planes_from_planes(fmh_matrix* m, const uint8_t* const h_planes[4], size_t h_pitch);
+void upload_release(int device);
 // planes rows [row0, row0 + rows) of a packed matrix -> byte rows of `pitch` bytes (abi.hip)
 hipError_t unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* data, size_t pitch, hipStream_t st);
 // sweep + finalize enqueued on `st`, no synchronisation (abi.hip)

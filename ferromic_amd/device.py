@@ -77,6 +77,21 @@ class DeviceMatrix:
         return cls(h.value)
 
     @classmethod
+    def from_host_planes(cls, planes: Sequence[np.ndarray], called: Optional[np.ndarray], variants: int, samples: int, ploidy: int,
+                         max_allele: int, device: int = 0) -> "DeviceMatrix":
+        """fmh_matrix_create_packed: host bit planes [variants][pitch] uint8 (column c = bit c & 7 of byte c >> 3), plane k = bit k of
+        the allele value; `called` the same shape with 1 bits for called entries, or None."""
+        planes = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+        pitch = planes[0].shape[1] if variants else 0
+        ptrs = [_ptr(p) for p in planes] + [None] * (3 - len(planes))
+        if called is not None:
+            called = np.ascontiguousarray(called, dtype=np.uint8)
+        h = C.c_void_p()
+        _abi.check(_abi.load().fmh_matrix_create_packed(ptrs[0], ptrs[1], ptrs[2], _ptr(called), pitch, variants, samples, ploidy,
+                                                        int(max_allele), device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
     def alloc(cls, variants: int, samples: int, ploidy: int, with_missing: bool, max_allele: int = 1,
               device: int = 0) -> "DeviceMatrix":
         h = C.c_void_p()

@@ -84,16 +84,26 @@ int fmh_device_release_scratch(int device);
  * Upload a site-major matrix in the reference's host layout: data[site*stride + sample*ploidy + side],
  * stride = samples*ploidy (stats.rs:293); optional missing bitset, one bit per linear entry,
  * LSB-first in u64 words (stats.rs:1298-1302; lib.rs:1188-1189).
- * Resident layout: with max_allele <= 3 (every biallelic and every SNP cohort) the matrix is kept BIT-PACKED - one bit
- * plane per allele bit plus one "called" plane, 128 columns per 16-byte vector - and the sweeps read 1/8 (1/4 with
- * alleles 2..3) of the bytes the u8 layout would cost; the bytes only pass through a staging slab.  Other matrices
- * (max_allele > 3, rows beyond 600 000 columns, FMH_LAYOUT=bytes) keep the u8 rows, padded to a 16-byte pitch, with the
+ * Resident layout: with max_allele <= 7 (every biallelic and every SNP cohort) the matrix is kept BIT-PACKED - one bit
+ * plane per allele bit (1, 2 or 3) plus one "called" plane, 128 columns per 16-byte vector - and the sweeps read 1/8 (1/4 with
+ * alleles 2..3, 3/8 with 4..7) of the bytes the u8 layout would cost; the rows are packed on the host (threads, SSE2) into pinned
+ * staging, so that only the planes cross PCIe.  Other matrices
+ * (max_allele > 7, rows beyond 600 000 columns, FMH_LAYOUT=bytes) keep the u8 rows, padded to a 16-byte pitch, with the
  * missing bitset re-laid as one "called" bit-row per site.  A called value above max_allele is a caller error: the packed
  * layout would lose its high bits, so fmh_matrix_create / fmh_matrix_pack detect it on the device and return
  * FMH_ERR_INVALID (the u8 layout keeps the bytes as they are and only uses max_allele as a loop bound).
  */
 int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing_or_null, size_t variants,
                       size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out);
+/*
+ * The same for a host that already holds BIT PLANES (run_vcf after ingest, a cohort stored packed): plane k = bit k of the allele
+ * value (h_plane1 iff max_allele >= 2, h_plane2 iff max_allele >= 4), h_called_or_null = 1 bits for called entries; a row is
+ * h_pitch bytes, column c is bit (c & 7) of byte (c >> 3), bits past the last column zero.  Pitched copies, no conversion:
+ * ceil(H / 8) bytes per site and plane cross PCIe.  The planes are taken at their word (no max_allele check is possible).
+ */
+int fmh_matrix_create_packed(const uint8_t* h_plane0, const uint8_t* h_plane1_or_null, const uint8_t* h_plane2_or_null,
+                             const uint8_t* h_called_or_null, size_t h_pitch, size_t variants, size_t samples, size_t ploidy,
+                             uint8_t max_allele, int device, fmh_matrix** out);
 /* Allocate an uninitialised device matrix (filled by fmh_matrix_generate or by the caller). */
 int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, int with_missing, uint8_t max_allele,
                      int device, fmh_matrix** out);
@@ -105,7 +115,7 @@ int fmh_matrix_wrap(void* d_data, size_t pitch, void* d_called_bits_or_null, siz
                     fmh_matrix** out);
 /* Build the bit-packed image of a matrix that holds u8 rows (fmh_matrix_alloc + fmh_matrix_generate, fmh_matrix_wrap);
  * the sweeps use it from then on.  release_bytes != 0 frees the u8 rows of a matrix the library owns (a wrapped matrix
- * keeps the caller's memory).  FMH_ERR_UNSUPPORTED when max_allele > 3 or the rows are too wide; a no-op when the
+ * keeps the caller's memory).  FMH_ERR_UNSUPPORTED when max_allele > 7 or the rows are too wide; a no-op when the
  * matrix is already packed and holds no bytes. */
 int fmh_matrix_pack(fmh_matrix* m, int release_bytes);
 int fmh_matrix_destroy(fmh_matrix* m);

@@ -575,3 +575,54 @@ def test_pack_api_contract(dev):
     miss = np.unpackbits(np.asarray(before[1]).view(np.uint8), bitorder="little")[:40 * 50].reshape(40, 50).astype(bool)
     assert np.array_equal(s.called[0], (~miss).sum(axis=1).astype(np.uint32))
     assert np.array_equal(s.alt[0], ((data == 1) & ~miss).sum(axis=1).astype(np.uint32))
+
+
+@pytest.mark.parametrize("S,N,max_allele,p_missing", [(300, 333, 1, 0.0), (257, 100, 1, 0.07), (130, 700, 3, 0.02), (97, 45, 6, 0.1), (1, 3, 2, 0.0),
+                                                       (40_000, 640, 1, 0.01)])
+def test_upload_routes_agree(dev, S, N, max_allele, p_missing):
+    """Three ways into the same resident image: fmh_matrix_create (u8 rows packed on the HOST into pinned staging - threads, SSE2, ragged
+    tails, the linear missing bitset at arbitrary bit offsets; the last shape spans several staging slabs and threads), fmh_matrix_create_packed
+    (host bit planes, pitched copies) and the device-side packer (u8 rows uploaded with FMH_LAYOUT=bytes, then fmh_matrix_pack).  Downloads
+    and sweeps must be identical."""
+    import os
+
+    rng = np.random.default_rng(S + N)
+    m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
+    cols = 2 * N
+    data = np.frombuffer(m.data, dtype=np.uint8).reshape(S, cols)
+    words = H.missing_words_np(m)
+    a = upload(dev, m)                                     # host-packed
+    os.environ["FMH_LAYOUT"] = "bytes"
+    try:
+        b = upload(dev, m)                                 # u8 rows on the device ...
+    finally:
+        del os.environ["FMH_LAYOUT"]
+    b.pack(release_bytes=True)                             # ... packed there
+    nplanes = 1 if m.max_allele <= 1 else (2 if m.max_allele <= 3 else 3)
+    pitch = (cols + 7) // 8 + 5                            # a host pitch of its own
+    planes = []
+    for k in range(nplanes):
+        bits = np.packbits((data >> k) & 1, axis=1, bitorder="little")
+        planes.append(np.pad(bits, ((0, 0), (0, pitch - bits.shape[1]))))
+    called = None
+    if words is not None:
+        miss = np.unpackbits(words.view(np.uint8), bitorder="little")[:S * cols].reshape(S, cols)
+        cb = np.packbits(1 - miss, axis=1, bitorder="little")
+        called = np.pad(cb, ((0, 0), (0, pitch - cb.shape[1])))
+    c = dev.DeviceMatrix.from_host_planes(planes, called, S, N, 2, m.max_allele)
+    ref = a.download()
+    for other in (b, c):
+        got = other.download()
+        assert np.array_equal(got[0], ref[0])
+        assert (got[1] is None) == (ref[1] is None) and (ref[1] is None or np.array_equal(got[1], ref[1]))
+    assert np.array_equal(ref[0].reshape(S, cols), data)
+    if N >= 3:
+        lists = [H.haps_for_samples(range(0, N // 3)), H.haps_for_samples(range(N // 3, N))]
+        base = dev.hudson_sweep(a, dev.Groups.from_haplotype_lists(a, lists), dev.FORMULA_SPARSE)
+        for other in (b, c):
+            got = dev.hudson_sweep(other, dev.Groups.from_haplotype_lists(other, lists), dev.FORMULA_SPARSE)
+            for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+                H.assert_bits_equal(got.sites[k], base.sites[k], k)
+            assert got.totals == base.totals and got.pop == base.pop
+    with pytest.raises(Exception, match="allele plane"):
+        dev.DeviceMatrix.from_host_planes(planes[:1], called, S, N, 2, 3)
