@@ -650,14 +650,6 @@ int fmhi::workspace(int device, Workspace** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     w.cus = prop.multiProcessorCount;
     w.max_grid = w.cus * 8;
-    HIP_TRY(hipMalloc((void**)&w.part_f64, (size_t)w.max_grid * kMaxF64 * 8));
-    HIP_TRY(hipMalloc((void**)&w.part_u64, (size_t)w.max_grid * kMaxU64 * 8));
-    HIP_TRY(hipMalloc((void**)&w.out_f64, kMaxF64 * 8));
-    HIP_TRY(hipMalloc((void**)&w.out_u64, kMaxU64 * 8));
-    HIP_TRY(hipHostMalloc((void**)&w.h_f64, kMaxF64 * 8, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&w.h_u64, kMaxU64 * 8, hipHostMallocDefault));
-    HIP_TRY(hipEventCreate(&w.ev0));
-    HIP_TRY(hipEventCreate(&w.ev1));
     w.ready = true;
   }
   *out = &w;
@@ -674,14 +666,42 @@ static int ensure_harmonic(Workspace* w, size_t max_k, hipStream_t st) {
     sum += 1.0 / (double)k;
     table[k] = sum;
   }
-  if (w->harmonic) HIP_TRY(hipFree(w->harmonic));
-  w->harmonic = nullptr;
-  HIP_TRY(hipMalloc((void**)&w->harmonic, table.size() * 8));
-  HIP_TRY(hipMemcpyAsync(w->harmonic, table.data(), table.size() * 8, hipMemcpyHostToDevice, st));
+  double* fresh = nullptr;
+  HIP_TRY(hipMalloc((void**)&fresh, table.size() * 8));
+  HIP_TRY(hipMemcpyAsync(fresh, table.data(), table.size() * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (w->harmonic) w->retired_harmonic.push_back(w->harmonic);  // another thread's sweep may still be reading it
+  w->harmonic = fresh;
   w->harmonic_len = table.size();
   return FMH_OK;
 }
+
+// one sweep's buffers, taken from / returned to the device's pool
+static int lease_acquire(Workspace* w, SweepLease** out) {
+  {
+    std::lock_guard<std::mutex> lock(w->lease_mu);
+    if (!w->idle_leases.empty()) { *out = w->idle_leases.back(); w->idle_leases.pop_back(); return FMH_OK; }
+  }
+  SweepLease* l = new SweepLease();
+  HIP_TRY(hipMalloc((void**)&l->part_f64, (size_t)w->max_grid * kMaxF64 * 8));
+  HIP_TRY(hipMalloc((void**)&l->part_u64, (size_t)w->max_grid * kMaxU64 * 8));
+  HIP_TRY(hipMalloc((void**)&l->out_f64, kMaxF64 * 8));
+  HIP_TRY(hipMalloc((void**)&l->out_u64, kMaxU64 * 8));
+  HIP_TRY(hipHostMalloc((void**)&l->h_f64, kMaxF64 * 8, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&l->h_u64, kMaxU64 * 8, hipHostMallocDefault));
+  HIP_TRY(hipEventCreate(&l->ev0));
+  HIP_TRY(hipEventCreate(&l->ev1));
+  HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+  *out = l;
+  return FMH_OK;
+}
+struct LeaseHolder {
+  Workspace* w = nullptr;
+  SweepLease* l = nullptr;
+  ~LeaseHolder() {
+    if (w && l) { std::lock_guard<std::mutex> lock(w->lease_mu); w->idle_leases.push_back(l); }
+  }
+};
 
 extern "C" int fmh_timing_enable(int on) { g_timing = on != 0; return FMH_OK; }
 extern "C" int fmh_timing_reset(void) {
@@ -866,24 +886,35 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   FMH_TRY(use_device(m->device));
   Workspace* w = nullptr;
   FMH_TRY(workspace(m->device, &w));
-  std::lock_guard<std::mutex> busy(w->in_use);
-  hipStream_t st = (hipStream_t)stream;
+  LeaseHolder hold;
+  hold.w = w;
+  FMH_TRY(lease_acquire(w, &hold.l));
+  SweepLease* l = hold.l;
+  // The caller's stream, or - for the NULL stream - the lease's own: the inputs of a sweep were made by synchronous calls and its outputs
+  // are read after this call has synchronised, so nothing orders it against the legacy default stream, and sweeps of different host
+  // threads (run_vcf's region workers) overlap on the device.
+  hipStream_t st = stream ? (hipStream_t)stream : l->stream;
   const bool timing = g_timing.load();  // one snapshot per sweep: another thread may flip the switch while this one runs
-  if (mode & kModeDiversity) FMH_TRY(ensure_harmonic(w, m->columns + 1, st));
+  const double* harmonic = nullptr;
+  if (mode & kModeDiversity) {
+    std::lock_guard<std::mutex> grow(w->in_use);
+    FMH_TRY(ensure_harmonic(w, m->columns + 1, st));
+    harmonic = w->harmonic;
+  }
   memset(res, 0, sizeof *res);
-  const LaunchCtx ctx{w->cus, w->max_grid, w->ev0, w->ev1, timing};
-  const SweepBuffers bufs{w->part_f64, w->part_u64, w->out_f64, w->out_u64};
+  const LaunchCtx ctx{w->cus, w->max_grid, l->ev0, l->ev1, timing};
+  const SweepBuffers bufs{l->part_f64, l->part_u64, l->out_f64, l->out_u64};
   bool launched = false;
-  FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, w->harmonic, &launched));
+  FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, harmonic, &launched));
   if (!launched) return FMH_OK;
-  HIP_TRY(hipMemcpyAsync(w->h_f64, w->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(w->h_u64, w->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(l->h_f64, l->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(l->h_u64, l->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  memcpy(res->f64, w->h_f64, sizeof res->f64);
-  memcpy(res->u64, w->h_u64, sizeof res->u64);
+  memcpy(res->f64, l->h_f64, sizeof res->f64);
+  memcpy(res->u64, l->h_u64, sizeof res->u64);
   if (timing) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, w->ev0, w->ev1) == hipSuccess) timing_add(ms);  // a timing failure never fails a sweep that has its results
+    if (hipEventElapsedTime(&ms, l->ev0, l->ev1) == hipSuccess) timing_add(ms);  // a timing failure never fails a sweep that has its results
     else (void)hipGetLastError();
   }
   return FMH_OK;
@@ -1121,6 +1152,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   if (general) {
     FMH_TRY(scratch.get(&acounts, (size_t)n_alleles * G * row_count));
     HIP_TRY(hipMemsetAsync(acounts, 0, (size_t)n_alleles * G * row_count * sizeof(uint32_t), st));
+    HIP_TRY(hipStreamSynchronize(st));  // the counting sweeps may run on another stream (run_sweep's lease): the zeros must be in place first
   } else {
     FMH_TRY(scratch.get(&alt, G * row_count));
   }

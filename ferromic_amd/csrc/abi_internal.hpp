@@ -73,23 +73,32 @@ struct DeviceScratch {
   }
 };
 
-// ---- per-device workspace: block partials, totals, harmonic table, timing events ------------------------------------
-struct Workspace {
-  bool ready = false;
-  int cus = 0;
-  int max_grid = 0;
+// ---- per-device workspace: sweep leases, harmonic table, pairwise scratch -----------------------------------------------
+// What ONE sweep in flight needs: block partials, the finalised totals, their pinned host copy, timing events, and a stream of its own
+// (used when the caller passes the NULL stream, so that sweeps issued by different host threads overlap on the device instead of
+// queueing behind each other on the legacy default stream).  Leases are pooled per device: run_vcf's region workers each take one.
+struct SweepLease {
   double* part_f64 = nullptr;
   unsigned long long* part_u64 = nullptr;
   double* out_f64 = nullptr;
   unsigned long long* out_u64 = nullptr;
   double* h_f64 = nullptr;  // pinned
   unsigned long long* h_u64 = nullptr;
-  double* harmonic = nullptr;
-  size_t harmonic_len = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t stream = nullptr;
+};
+struct Workspace {
+  bool ready = false;
+  int cus = 0;
+  int max_grid = 0;
+  std::mutex lease_mu;
+  std::vector<SweepLease*> idle_leases;
+  double* harmonic = nullptr;  // grows only; superseded tables stay alive (a sweep in flight may still read them)
+  size_t harmonic_len = 0;
+  std::vector<double*> retired_harmonic;
   uint8_t* pd_planes = nullptr;  // pairwise-differences planes, kept between calls (fmh_device_release_scratch frees them)
   size_t pd_planes_bytes = 0;
-  std::mutex in_use;  // one sweep at a time per device: concurrent callers share the partials and the pinned staging
+  std::mutex in_use;  // the harmonic table's growth and the pairwise scratch: one holder at a time per device
 };
 int workspace(int device, Workspace** out);
 
