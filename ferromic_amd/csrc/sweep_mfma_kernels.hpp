@@ -79,6 +79,8 @@ __global__ __launch_bounds__(kBlock) void sweep_mfma_kernel(const SweepArgs A) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[u][t] = load_stream(rp[t] + off);
       }
+      // all 4 U loads of the batch are issued before the first MFMA (left alone, hipcc sinks them between the MFMAs and keeps four in flight)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint4 m = my_mask[(k0 + u) * 4];  // zero beyond the row (the image is padded to a multiple of 4 U vectors)

@@ -1,44 +1,86 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the measurements and rocprofv3 passes whose summaries are kept under profiles/.
-# Usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>/)
+# Runs on the GPU box (via gpurun): the measurements and rocprofv3 passes whose summaries are kept under profiles/<round>/.
+# Usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>/; copy what is to be judged into profiles/<tag>/)
+# Counter passes (--pmc) are separate runs from the kernel trace, as MI355X_MICROARCH.md prescribes; the profiled program is always
+# `python3 <script>` itself (no env / shell hop between rocprofv3 and the process that touches the GPU).
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r01}
+TAG=${1:-r02}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp
 export TMPDIR=/tmp
-echo "[1/8] bench.py (C4)"; python3 $R/bench.py --steps 20 --warmup 3 > $O/c4_bench.json
-echo "[2/8] kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -o c4 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/c4_bench_under_rocprof.json 2> $O/c4_trace.log
+step() { echo "[$(date +%H:%M:%S)] $*"; }
+
+step "bench.py (C4, N = 1)"; python3 $R/bench.py --steps 20 --warmup 3 2> $O/c4_bench.err | grep '^{' > $O/c4_bench.json
+step "kernel trace of the same command"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -o c4 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline 2> $O/c4_trace.log | grep '^{' > $O/c4_bench_under_rocprof.json
 python3 $R/tools/summarize_rocprof.py trace $O/c4_trace $O/c4_kernel_stats.csv
-echo "[3/8] pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_fetch.log
+step "pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_fetch.log
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch $O/c4_pmc_fetch_summary.csv
-echo "[4/8] pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write.log
+step "pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write.log
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_write $O/c4_pmc_write_summary.csv
-python3 - "$O" <<'PY'
+step "the u8-row layout: bench, FETCH_SIZE, WRITE_SIZE"
+python3 $R/bench.py --steps 10 --warmup 2 --layout bytes --no-cpu-baseline 2>/dev/null | grep '^{' > $O/c4_bench_u8_layout.json
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_pmc_fetch8 -o f -- python3 $R/bench.py --steps 3 --warmup 1 --layout bytes --no-cpu-baseline > /dev/null 2> $O/c4_pmc_fetch8.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch8 $O/c4_pmc_fetch_summary_u8_layout.csv
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write8 -o w -- python3 $R/bench.py --steps 3 --warmup 1 --layout bytes --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write8.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_write8 $O/c4_pmc_write_summary_u8_layout.csv
+python3 - "$O" "$R" "$TAG" <<'PY'
 import csv, json, sys
-o = sys.argv[1]
-def sweep_mean(path):
-    # the packed sweep (mask mode 3) - the run also holds the five u8-row reference sweeps (mask mode 0) of bench.py
-    rows = [r for r in csv.DictReader(open(path)) if "sweep_kernel" in r["kernel"]]
-    packed = [r for r in rows if r["kernel"].rstrip('"').rstrip().endswith(", 3, 16>")]
-    if not packed:
-        raise SystemExit("no packed sweep kernel in " + path)
-    return float(packed[0]["mean"])
-fetch, write = sweep_mean(o + "/c4_pmc_fetch_summary.csv"), sweep_mean(o + "/c4_pmc_write_summary.csv")
-json.dump({"10000000x5000:packed": {
-    "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_size_kb": fetch, "write_size_kb": write,
-    "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (gfx950 FETCH_SIZE halves wide coalesced reads); separate --pmc passes",
-    "source": "c4_pmc_fetch_summary.csv, c4_pmc_write_summary.csv of the same collection",
-    "algorithmic_bytes": 681 * 10_000_000}}, open(o + "/pmc_traffic_packed.json", "w"), indent=1)
+o, root, tag = sys.argv[1:4]
+sys.path.insert(0, root)
+import bench
+def sweep_mean(path, mask_mode):
+    rows = [r for r in csv.DictReader(open(path)) if "sweep_kernel<2, 3, false, false, %d, 16" % mask_mode in r["kernel"]]
+    if not rows:
+        raise SystemExit("no Hudson sweep kernel with mask mode %d in %s" % (mask_mode, path))
+    return float(rows[0]["mean"])
+out = {}
+for layout, suffix, mode, b_site in (("packed", "", 3, 681), ("bytes", "_u8_layout", 0, 5056)):
+    fetch, write = sweep_mean(o + "/c4_pmc_fetch_summary%s.csv" % suffix, mode), sweep_mean(o + "/c4_pmc_write_summary%s.csv" % suffix, mode)
+    out["10000000x5000:" + layout] = {
+        "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_size_kb": fetch, "write_size_kb": write,
+        "correction": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md HBM section (gfx950 FETCH_SIZE halves wide coalesced reads); separate --pmc passes",
+        "source": "profiles/%s/c4_pmc_fetch_summary%s.csv, c4_pmc_write_summary%s.csv" % (tag, suffix, suffix),
+        "kernel_source_sha": bench.kernel_source_sha(),
+        "algorithmic_bytes": b_site * 10_000_000}
+json.dump(out, open(o + "/pmc_traffic.json", "w"), indent=1)
 PY
-echo "[4b/8] the u8-row layout for comparison"; python3 $R/bench.py --steps 10 --warmup 2 --layout bytes --no-cpu-baseline > $O/c4_bench_u8_layout.json
-echo "[5/8] other configs"; python3 $R/tools/measure_configs.py C2 C3 C4m C5 C3h WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
-MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C2 C3 C4m C5 C3h WIDE 2>/dev/null | grep '^{' > $O/other_configs_u8_layout.jsonl
-echo "[6/8] multi-allelic path"; python3 $R/tools/measure_general.py 2>/dev/null | grep '^{' | grep hudson > $O/general_path.jsonl
-echo "[7/8] pairwise"; python3 $R/tools/measure_pairwise.py 1000000x2500 200000x500 2>/dev/null | grep '^{' > $O/pairwise.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/pd_trace -o pd -- python3 $R/tools/measure_pairwise.py 1000000x2500 > /dev/null 2> $O/pd_trace.log
-python3 $R/tools/summarize_rocprof.py trace $O/pd_trace $O/pairwise_kernel_stats.csv
-echo "[8/8] run_vcf at reduced C4 scale"; python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 2>/dev/null | tail -1 > $O/run_vcf_scale_200k_x_2500.json
-rm -rf $O/c4_trace $O/c4_pmc_fetch $O/c4_pmc_write $O/pd_trace
+step "strong-scaling step sizes on one GPU (the per-rank slab of 1, 2, 4, 8 GPUs): plain sweep and the sharded path with a one-rank RCCL group"
+for s in 10000000 5000000 2500000 1250000; do
+  python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_plain.jsonl
+  python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --force-collective 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_sharded_path.jsonl
+done
+step "other configs"; python3 $R/tools/measure_configs.py C2 C2x10 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
+MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs_u8_layout.jsonl
+step "C5 counting routes on u8 rows: v_dot4 / int8 MFMA (4 and 2 K steps in flight)"
+for v in 0 1 2; do FMH_COUNTS_MFMA=$v MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C5 2>/dev/null | grep '^{' | sed "s/^{/{\"FMH_COUNTS_MFMA\": $v, /" >> $O/c5_counting_routes_u8.jsonl; done
+export MEASURE_LAYOUT=bytes
+export FMH_COUNTS_MFMA=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_trace -o c5 -- python3 $R/tools/measure_configs.py C5 > /dev/null 2> $O/c5_trace.log
+python3 $R/tools/summarize_rocprof.py trace $O/c5_trace $O/c5_mfma_kernel_stats.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/c5_pmc -o c5 -- python3 $R/tools/measure_configs.py C5 > /dev/null 2> $O/c5_pmc.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c5_pmc $O/c5_mfma_pmc_summary.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c5_pmc_fetch -o c5 -- python3 $R/tools/measure_configs.py C5 > /dev/null 2> $O/c5_pmc_fetch.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c5_pmc_fetch $O/c5_mfma_pmc_fetch_summary.csv
+unset FMH_COUNTS_MFMA
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/c5_pmc_dot4 -o c5 -- python3 $R/tools/measure_configs.py C5 > /dev/null 2> $O/c5_pmc_dot4.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c5_pmc_dot4 $O/c5_dot4_pmc_summary.csv
+unset MEASURE_LAYOUT
+step "issue / wait counters of the C2, C3, C3-summaries and C4 kernels (two passes of 8 SQ counters)"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/cfg_pmc1 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 > /dev/null 2> $O/cfg_pmc1.log
+python3 $R/tools/summarize_rocprof.py pmc $O/cfg_pmc1 $O/c2_c3_c4_pmc_issue_wait_summary.csv
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT --output-format csv -d $O/cfg_pmc2 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 > /dev/null 2> $O/cfg_pmc2.log
+python3 $R/tools/summarize_rocprof.py pmc $O/cfg_pmc2 $O/c2_c3_c4_pmc_inst_mix_summary.csv
+step "multi-allelic paths"; python3 $R/tools/measure_general.py 2>/dev/null | grep '^{' | grep hudson > $O/general_path.jsonl
+MEASURE_ALLELE7=1 python3 $R/tools/measure_wc_general.py 2>/dev/null | grep '^{' > $O/wc_general_5_8_groups.jsonl
+python3 $R/tools/measure_wc_groups.py 2 4 5 8 12 26 2>/dev/null | grep '^{' > $O/wc_groups.jsonl
+step "pairwise"; python3 $R/tools/measure_pairwise.py 1000000x2500 200000x500 2>/dev/null | grep '^{' > $O/pairwise.jsonl
+step "upload, API, run_vcf"
+python3 $R/tools/measure_h2d.py 2>/dev/null | grep '^{' > $O/h2d.json
+python3 $R/tools/measure_api_c2.py 2>/dev/null | grep '^{' > $O/api_c2.json
+python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 2>/dev/null | tail -1 > $O/run_vcf_scale_200k_x_2500.json
+python3 $R/tools/run_vcf_many_regions.py 2>/dev/null | tail -1 > $O/run_vcf_500_regions.json
+rm -rf $O/c4_trace $O/c4_pmc_fetch $O/c4_pmc_write $O/c4_pmc_fetch8 $O/c4_pmc_write8 $O/c5_trace $O/c5_pmc $O/c5_pmc_fetch $O/c5_pmc_dot4 $O/cfg_pmc1 $O/cfg_pmc2
 ls -la $O

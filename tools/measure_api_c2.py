@@ -29,6 +29,13 @@ def main():
         out[name + "_s"] = round(time.perf_counter() - t0, 4)
         return r
 
+    # HIP start-up (runtime initialisation, code-object load, first allocations) on a throw-away 8-site population, so that the C2 numbers
+    # below are the path itself
+    def warm():
+        tiny = fm.Population.from_numpy("warm", g[:8].copy(), pos[:8].copy(), haps, int(pos[7] - pos[0] + 1))
+        return tiny.segregating_sites()
+
+    timed("hip_startup_and_first_tiny_statistic", warm)
     pop = timed("from_numpy", lambda: fm.Population.from_numpy("all", g, pos, haps, L))
     p1 = pop.with_haplotypes("p1", haps[:N])
     p2 = pop.with_haplotypes("p2", haps[N:])
