@@ -242,8 +242,32 @@ def main() -> int:
     masks = np.stack([(poc == 0), (poc == 1)]).astype(np.uint8)
     sharded = world > 1 or args.force_collective
     comm = None
+    transport_note = None
     if sharded and args.transport == "rccl":
-        comm = sharding.Comm.from_torch_distributed(dist, local_rank) if world > 1 else sharding.Comm.single(local_rank)
+        # the library's own communicator; creating it is a collective, so the ranks agree on the outcome before anyone uses it - if RCCL
+        # cannot come up on this host the run falls back to torch.distributed for the reduce (slower, same numbers) and says so
+        try:
+            comm = sharding.Comm.from_torch_distributed(dist, local_rank) if world > 1 else sharding.Comm.single(local_rank)
+            failure = None
+        except Exception as exc:  # noqa: BLE001 - any failure takes the fallback
+            comm, failure = None, f"{type(exc).__name__}: {exc}"
+        if world > 1:
+            ok = torch.tensor([0 if failure else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                failure = failure or "another rank could not create its communicator"
+        if comm is None:
+            if world == 1 and not args.force_collective:
+                sharded = False
+            else:
+                if dist is None:
+                    raise SystemExit(f"the RCCL communicator could not be created: {failure}")
+                args.transport = "torch"
+            transport_note = f"libferromic_hip's RCCL communicator could not be created ({failure}); accumulators summed through torch.distributed ({args.backend})"
+            print("bench.py: " + transport_note, file=sys.stderr)
 
     def barrier():
         if dist is not None and world > 1:
@@ -413,6 +437,7 @@ def main() -> int:
             "generate_s": first["gen_s"],
             "pack_s": first["pack_s"],
             "layout": args.layout,
+            **({"transport_fallback": transport_note} if transport_note else {}),
         },
         "roofline": {
             "bound": "hbm",
