@@ -691,7 +691,10 @@ static int lease_acquire(Workspace* w, SweepLease** out) {
   HIP_TRY(hipHostMalloc((void**)&l->h_u64, kMaxU64 * 8, hipHostMallocDefault));
   HIP_TRY(hipEventCreate(&l->ev0));
   HIP_TRY(hipEventCreate(&l->ev1));
-  HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+  // a BLOCKING stream: it still orders itself against the legacy default stream (work a caller queued there on the sweep's inputs or
+  // outputs - a torch kernel on a wrapped tensor, fmh_device_zero - is seen, as it was when sweeps ran on the NULL stream itself), while
+  // the leases' streams do not order against each other
+  HIP_TRY(hipStreamCreate(&l->stream));
   *out = l;
   return FMH_OK;
 }
@@ -890,9 +893,8 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   hold.w = w;
   FMH_TRY(lease_acquire(w, &hold.l));
   SweepLease* l = hold.l;
-  // The caller's stream, or - for the NULL stream - the lease's own: the inputs of a sweep were made by synchronous calls and its outputs
-  // are read after this call has synchronised, so nothing orders it against the legacy default stream, and sweeps of different host
-  // threads (run_vcf's region workers) overlap on the device.
+  // The caller's stream, or - for the NULL stream - the lease's own (blocking: ordered against the legacy default stream like the NULL
+  // stream itself, but not against the other leases), so that sweeps of different host threads (run_vcf's region workers) overlap on the device.
   hipStream_t st = stream ? (hipStream_t)stream : l->stream;
   const bool timing = g_timing.load();  // one snapshot per sweep: another thread may flip the switch while this one runs
   const double* harmonic = nullptr;
