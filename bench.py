@@ -5,7 +5,8 @@ A step = one pass of the hot path (per-site allele counts for both populations, 
 regional accumulators summed over all ranks and back on the host) over the synthetic cohort already resident in HBM.
 Workload = BASELINE config C4: 10 M sites x 5 000 haplotypes, 2 populations.
 
-  N = 1   the whole cohort on one GPU, fmh_hudson_sweep.
+  N = 1   the whole cohort on one GPU; the same begin / end calls on a local one-rank communicator (no RCCL, nothing to exchange), i.e. the
+          next sweep is enqueued while the previous one's totals travel to the host (--sync-steps: one blocking fmh_hudson_sweep per step).
   N > 1   region sharding: rank r owns one contiguous slab and only that slab; the regional accumulators are
           summed by RCCL inside libferromic_hip.so (fmh_hudson_sweep_sharded_begin/_end: finalise on the device, ncclAllReduce
           on the communicator's stream, pipelined one step deep so the reduce of step k overlaps the sweep of step k + 1).
@@ -188,6 +189,8 @@ def parse_args():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded path (communicator, device-side reduce, pipelining) even with one rank: measures its "
                          "software cost on a one-GPU box")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="N = 1: one blocking fmh_hudson_sweep per step instead of the pipelined begin / end pair on a local communicator")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
                     help="all ranks share cuda:0 (needs --transport torch --backend gloo): exercises the sharded code path on a one-GPU box")
     return ap.parse_args()
@@ -260,14 +263,16 @@ def main() -> int:
                     comm = None
                 failure = failure or "another rank could not create its communicator"
         if comm is None:
-            if world == 1 and not args.force_collective:
-                sharded = False
-            else:
-                if dist is None:
-                    raise SystemExit(f"the RCCL communicator could not be created: {failure}")
-                args.transport = "torch"
+            if dist is None:
+                raise SystemExit(f"the RCCL communicator could not be created: {failure}")
+            args.transport = "torch"
             transport_note = f"libferromic_hip's RCCL communicator could not be created ({failure}); accumulators summed through torch.distributed ({args.backend})"
             print("bench.py: " + transport_note, file=sys.stderr)
+
+    if not sharded and not args.sync_steps:
+        # one GPU, nothing to exchange: the same pipelined begin / end calls on a local one-rank communicator (no RCCL), so that N = 1 and
+        # N > 1 run the same step structure - the next sweep is enqueued while the previous one's totals travel to the host
+        comm = sharding.Comm.local(local_rank)
 
     def barrier():
         if dist is not None and world > 1:
@@ -432,7 +437,9 @@ def main() -> int:
             "haplotypes": H,
             "populations": 2,
             "parallelism": (f"region-sharded x{world}: one contiguous slab per GPU, per-site tracks stay on the owning GPU, the 128 regional "
-                            f"accumulators summed by {reduce_name}, pipelined one step deep") if sharded else "one GPU, no collective",
+                            f"accumulators summed by {reduce_name}, pipelined one step deep") if sharded else
+                           ("one GPU, no collective; sweeps pipelined two deep (fmh_hudson_sweep_sharded_begin / _end on a local one-rank communicator)"
+                            if comm is not None else "one GPU, no collective, one blocking fmh_hudson_sweep per step"),
             "seed": first["seed"],
             "generate_s": first["gen_s"],
             "pack_s": first["pack_s"],

@@ -140,6 +140,7 @@ SYMBOLS = {
     "fmh_comm_get_unique_id": (_i, [_vp]),
     "fmh_comm_init_rank": (_i, [_vp, _i, _i, _i, _P(_vp)]),
     "fmh_comm_init_all": (_i, [_P(_i), _i, _P(_vp)]),
+    "fmh_comm_init_local": (_i, [_i, _P(_vp)]),
     "fmh_comm_destroy": (_i, [_vp]),
     "fmh_comm_info": (_i, [_vp, _P(_i), _P(_i), _P(_i), _P(_i)]),
     "fmh_allreduce_totals": (_i, [_vp, _P(_d), _sz, _P(_u64), _sz]),

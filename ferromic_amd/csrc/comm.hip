@@ -296,6 +296,20 @@ extern "C" int fmh_comm_init_all(const int* h_devices, int n, fmh_comm** h_out) 
   return FMH_OK;
 }
 
+// One rank, no transport at all (the sum over one rank is the identity): the pipelined begin / end calls for a single GPU that scans
+// many windows - the next window's sweep is enqueued while the previous one's totals travel to the host.
+extern "C" int fmh_comm_init_local(int device, fmh_comm** out) {
+  if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  FMH_TRY(use_device(device));
+  fmh_comm* c = new fmh_comm();
+  c->world = 1; c->rank = 0; c->device = device; c->transport = 2;
+  const int rc = comm_alloc(c);
+  if (rc != FMH_OK) { comm_free(c); return rc; }
+  *out = c;
+  return FMH_OK;
+}
+
 extern "C" int fmh_comm_destroy(fmh_comm* c) {
   if (c) comm_free(c);
   return FMH_OK;
@@ -340,7 +354,7 @@ extern "C" int fmh_allreduce_totals_end(fmh_comm* c, double* h_f64, uint64_t* h_
   if (c->transport == 0) {
     FMH_TRY(use_device(c->device));
     HIP_TRY(hipEventSynchronize(c->done));
-  } else {
+  } else if (c->transport == 1) {
     FMH_TRY(c->host->allreduce(c->rank, c->h_f64, c->pend_nf, reinterpret_cast<uint64_t*>(c->h_u64), c->pend_nu));
   }
   memcpy(h_f64, c->h_f64, c->pend_nf * 8);
@@ -403,6 +417,7 @@ extern "C" int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* t) {
   s.busy = false;
   HIP_TRY(hipEventSynchronize(s.reduced));
   if (c->transport == 1) FMH_TRY(c->host->allreduce(c->rank, s.h_f64, kMaxF64, reinterpret_cast<uint64_t*>(s.h_u64), kMaxU64));
+  // (transport 2, a local one-rank communicator: nothing to add)
   if (s.timed && s.launched) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) timing_add(ms); else (void)hipGetLastError();

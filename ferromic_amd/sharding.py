@@ -29,7 +29,7 @@ class Comm:
         lib = _abi.load()
         w, r, d, t = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _abi.check(lib.fmh_comm_info(handle, C.byref(w), C.byref(r), C.byref(d), C.byref(t)))
-        self.world, self.rank, self.device, self.transport = w.value, r.value, d.value, ("rccl", "host")[t.value]
+        self.world, self.rank, self.device, self.transport = w.value, r.value, d.value, ("rccl", "host", "local")[t.value]
 
     @classmethod
     def from_unique_id(cls, uid: bytes, world: int, rank: int, device: int) -> "Comm":
@@ -50,6 +50,13 @@ class Comm:
     def single(cls, device: int = 0) -> "Comm":
         """A one-rank communicator (the collective is then an identity, but runs through RCCL all the same)."""
         return cls.from_unique_id(cls.unique_id(), 1, 0, device)
+
+    @classmethod
+    def local(cls, device: int = 0) -> "Comm":
+        """One rank without any transport (no RCCL): the pipelined begin / end sweeps of a single GPU."""
+        h = C.c_void_p()
+        _abi.check(_abi.load().fmh_comm_init_local(device, C.byref(h)))
+        return cls(h.value)
 
     @classmethod
     def from_torch_distributed(cls, dist, device: int) -> "Comm":

@@ -302,8 +302,11 @@ typedef struct fmh_comm fmh_comm;
 int fmh_comm_get_unique_id(void* h_id /*[FMH_COMM_ID_BYTES]*/);
 int fmh_comm_init_rank(const void* h_id, int world, int rank, int device, fmh_comm** out);
 int fmh_comm_init_all(const int* h_devices, int n, fmh_comm** h_out /*[n]*/);
+/* A communicator of ONE rank that needs no transport (and no RCCL): what a single GPU uses for the pipelined
+ * fmh_hudson_sweep_sharded_begin / _end calls when it scans many windows. */
+int fmh_comm_init_local(int device, fmh_comm** out);
 int fmh_comm_destroy(fmh_comm* c);
-/* transport: 0 = RCCL, 1 = in-process host rendezvous */
+/* transport: 0 = RCCL, 1 = in-process host rendezvous, 2 = local (one rank, nothing to exchange) */
 int fmh_comm_info(const fmh_comm* c, int* world, int* rank, int* device, int* transport);
 
 /* Element-wise sum over all ranks, in place, blocking (collective: every rank calls it with the same lengths;

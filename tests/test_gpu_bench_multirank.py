@@ -61,8 +61,10 @@ def test_rccl_collective_path_with_one_rank():
     common = ["--steps", "4", "--warmup", "1", "--sites", "250000", "--haplotypes", "1000", "--no-cpu-baseline"]
     plain = run([sys.executable, "bench.py"] + common)
     coll = run([sys.executable, "bench.py", "--force-collective"] + common)
-    assert "RCCL" in coll["config"]["parallelism"] and "no collective" in plain["config"]["parallelism"]
+    assert "RCCL" in coll["config"]["parallelism"] and "no collective" in plain["config"]["parallelism"] and "pipelined" in plain["config"]["parallelism"]
     assert coll["results"] == plain["results"]
+    blocking = run([sys.executable, "bench.py", "--sync-steps"] + common)
+    assert "blocking" in blocking["config"]["parallelism"] and blocking["results"] == plain["results"]
     assert coll["roofline"]["kernel_ms_avg"] > 0  # HIP events of the pipelined launches
     for d in (plain, coll):
         r = d["roofline"]

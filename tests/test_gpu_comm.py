@@ -71,6 +71,15 @@ def test_rccl_one_rank_allreduce_and_sharded_sweep():
     assert a.sites_with_components + b.sites_with_components == plain.sites_with_components
     assert a.pop[0].segregating_sites + b.pop[0].segregating_sites == plain.pop[0].segregating_sites
     assert a.numerator_sum + b.numerator_sum == pytest.approx(plain.numerator_sum, rel=1e-12)
+    # a local communicator (no RCCL at all) runs the same pipelined calls
+    loc = sharding.Comm.local(0)
+    assert (loc.world, loc.transport) == (1, "local")
+    l2 = _abi.HudsonTotals()
+    _abi.check(lib.fmh_hudson_sweep_sharded(loc._h, dm._h, g._h, 0, S, _abi.FORMULA_DENSE, None, C.byref(l2), None))
+    _totals_equal(l2, plain, 0.0)
+    f2, u2 = loc.allreduce([0.5, 2.0], [9])
+    assert f2 == [0.5, 2.0] and u2 == [9]
+    loc.close()
     # an empty window is a valid collective participant
     _abi.check(lib.fmh_hudson_sweep_sharded(comm._h, dm._h, g._h, 10, 0, _abi.FORMULA_DENSE, None, C.byref(a), None))
     assert a.sites_with_components == 0 and a.numerator_sum == 0.0 and a.pop[1].haplotype_capacity == N
