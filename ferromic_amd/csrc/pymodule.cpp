@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/ferromic_hip.h"
+#include "host_cpus.hpp"
 
 namespace py = pybind11;
 using std::optional;
@@ -397,8 +398,8 @@ struct ByteBuf {
 template <class F>
 void parallel_ranges(size_t total, F fn) {
   const size_t grain = (size_t)4 << 20;
-  unsigned hw = std::thread::hardware_concurrency();
-  size_t workers = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (total + grain - 1) / grain);
+  const unsigned hw = fmh_host::usable_cpus();
+  size_t workers = std::min<size_t>(std::min<size_t>(hw, 16), (total + grain - 1) / grain);
   if (workers <= 1) { fn((size_t)0, total, (size_t)0); return; }
   vector<std::thread> pool;
   const size_t step = (total + workers - 1) / workers;

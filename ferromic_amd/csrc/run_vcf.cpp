@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/ferromic_hip.h"
+#include "host_cpus.hpp"
 
 namespace {
 
@@ -74,8 +75,7 @@ void fmh_check(int status, const char* what) {
 unsigned worker_threads() {
   static const unsigned n = [] {
     if (const char* e = getenv("FERROMIC_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 256); }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(hw ? hw : 1u, 64u));
+    return std::max(1u, std::min(fmh_host::usable_cpus(), 64u));  // the process's CPU share, not the machine (host_cpus.hpp)
   }();
   return n;
 }
@@ -756,6 +756,47 @@ bool process_variant(sv line, const string& chr, const vector<Interval>& regions
   scr.vals.clear();
   bool low_gq = false, missing = false;
   size_t max_len = 0;
+  // Whole-line fast path: every kept cell is "a|b:GQ[:...]" with one-digit alleles, GQ second, and no sample column is skipped.  The
+  // alleles go straight into the packed row, nothing else is recorded per cell; the first cell that looks different sends the whole
+  // line through the general walk below (same acceptance rules as its per-cell shortcut, so the outcome is the same).
+  if (gq_index == 1 && n && more && kept[0] == 9 && kept[n - 1] == 8 + n) {
+    scr.vals.resize(2 * n);
+    uint8_t* dst = scr.vals.data();
+    const char* p = cur;
+    size_t i = 0;
+    bool low = false;
+    for (; i < n; ++i) {
+      if (lend - p < 5) break;
+      const unsigned a = (unsigned)(p[0] - '0'), b = (unsigned)(p[2] - '0');
+      if (a > 9u || b > 9u || p[3] != ':' || (p[1] != '|' && p[1] != '/')) break;
+      const char* q = p + 4;
+      unsigned v = 0;
+      while (q < lend && (unsigned)(*q - '0') < 10u && v < 100000u) { v = v * 10 + (unsigned)(*q - '0'); ++q; }
+      if (q == p + 4 || v > 65535u) break;
+      if (q < lend && *q == ':') { const char* t = (const char*)memchr(q, '\t', (size_t)(lend - q)); q = t ? t : lend; }
+      else if (q < lend && *q == '\n' && q + 1 == lend) q = lend;
+      else if (q < lend && *q != '\t') break;
+      dst[2 * i] = (uint8_t)a;
+      dst[2 * i + 1] = (uint8_t)b;
+      low |= v < min_gq;
+      if (q == lend) { ++i; break; }  // the line ends with this cell
+      p = q + 1;
+    }
+    if (i == n) {
+      // all n cells were taken (a line that ends early leaves i < n and is reported by the general walk)
+      if (low) flags |= FLAG_LOW_GQ;
+      if (indel) return false;
+      out->position = pos0;
+      out->num_samples = n;
+      out->stride = 2;
+      out->max_len = 2;
+      out->data.swap(scr.vals);
+      scr.vals.clear();
+      *out_flags = flags;
+      return true;
+    }
+    scr.vals.clear();
+  }
   size_t col = 9;  // column index of the field that starts at `cur` (valid while `more`)
   for (size_t i = 0; i < n; ++i) {
     // skip to column kept[i] (ascending: the header is read left to right)
@@ -2173,8 +2214,37 @@ struct ShardSetup {
   }
 };
 
+// HIP start-up (context, code objects of the library, pinned staging of the upload path, the first sweep's buffers) costs 0.15-0.2 s per
+// process; a helper thread pays it with a throw-away 64-site matrix per GPU while the main thread reads the VCF text, and is joined before
+// the first region touches a GPU.  Failures are left for the real calls to report.
+struct DeviceWarmup {
+  std::thread t;
+  explicit DeviceWarmup(const Args& args) {
+    if (args.ingest_only || getenv("FERROMIC_NO_WARMUP")) return;
+    vector<int> devices = args.devices.empty() ? vector<int>{args.device} : args.devices;
+    std::sort(devices.begin(), devices.end());
+    devices.erase(std::unique(devices.begin(), devices.end()), devices.end());
+    t = std::thread([devices] {
+      StageTimer tw("  (helper thread) hip_start_up");
+      const vector<uint8_t> rows(64 * 4, 1), mask(4, 1);
+      for (int d : devices) {
+        fmh_matrix* m = nullptr;
+        fmh_groups* g = nullptr;
+        fmh_pop_totals totals;
+        if (fmh_matrix_create(rows.data(), nullptr, 64, 2, 2, 1, d, &m) == FMH_OK && fmh_groups_create(m, mask.data(), 1, &g) == FMH_OK)
+          (void)fmh_population_summaries(m, g, 0, 64, 0, nullptr, nullptr, &totals, nullptr);
+        if (g) fmh_groups_destroy(g);
+        if (m) fmh_matrix_destroy(m);
+      }
+    });
+  }
+  void join() { if (t.joinable()) t.join(); }
+  ~DeviceWarmup() { join(); }
+};
+
 int run(const Args& args) {
   ShardSetup shard_setup(args);
+  DeviceWarmup warmup(args);
   std::optional<RegionMap> mask_regions, allow_regions;
   if (!args.mask_file.empty()) mask_regions = parse_regions_file(args.mask_file);
   if (!args.allow_file.empty()) allow_regions = parse_regions_file(args.allow_file);
@@ -2265,6 +2335,7 @@ int run(const Args& args) {
                (unsigned long long)h);
         continue;
       }
+      warmup.join();
       tm.emplace("regions_statistics_and_writers");
       // Regions are independent units: one worker per GPU pulls the next config entry; rows and
       // tracks are emitted in config order whatever the completion order, so the files match a 1-GPU run.

@@ -17,6 +17,7 @@
 #include <thread>
 
 #include "abi_internal.hpp"
+#include "host_cpus.hpp"
 
 using namespace fmhi;
 
@@ -53,9 +54,7 @@ int staging(int device, Staging** out) {
 
 unsigned host_threads(size_t bytes) {
   if (bytes < ((size_t)2 << 20)) return 1;  // small matrices (run_vcf's many small regions): no thread start-up
-  cpu_set_t set;
-  unsigned n = std::thread::hardware_concurrency();
-  if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+  unsigned n = fmh_host::usable_cpus();
   if (const char* e = getenv("FMH_UPLOAD_THREADS")) n = (unsigned)atoi(e);
   return std::max(1u, std::min(n, 16u));
 }

@@ -41,7 +41,30 @@ def weird_cell(rng, n_alts):
     return f"{a()}|{a()}:{gq}"
 
 
-def weird_line(rng, chrom, pos, n_samples):
+def near_clean_cell(rng, n_alts, dirt):
+    """The cell the binary's whole-line fast path takes ("a|b:GQ", one-digit alleles), with a small chance of one of its border cases."""
+    a = lambda: str(rng.randint(0, min(n_alts, 9)))  # noqa: E731
+    if rng.random() >= dirt:
+        return f"{a()}{rng.choice('||||/')}{a()}:{rng.choice(['99', '60', '31', '30', '29', '5', '0', '100', '65535'])}"
+    return rng.choice([f"{a()}|{a()}:65536", f"{a()}|{a()}:100000", f"{a()}|{a()}:0000031", f"{a()}|{a()}:", f"{a()}|{a()}:.", f"{a()}|{a()}:3x",
+                       f"{a()}|{a()}:40:7,1", f"{a()}|{a()}:12:", f"10|{a()}:50", f"{a()}|10:50", f"{a()}:50", f"{a()}|{a()}", f"{a()}|{a()}|{a()}:50",
+                       f"{a()}|{a()};50", f".|.:50", f"{a()}|{a()}:50 ", f" {a()}|{a()}:50", ""])
+
+
+def weird_line(rng, chrom, pos, n_samples, clean=0.0):
+    if rng.random() < clean:
+        fmt = rng.choice(["GT:GQ"] * 8 + ["GT:GQ:AD", "GT:GQ:PL:DP"])
+        dirt = rng.choice([0.0, 0.0, 0.0, 0.02, 0.2])
+        cells = [near_clean_cell(rng, 3, dirt) for _ in range(n_samples)]
+        if fmt != "GT:GQ":
+            cells = [c + ":1,2" if rng.random() < 0.9 else c for c in cells]
+        fields = [chrom, str(pos), ".", rng.choice("ACGT"), rng.choice(["A", "C", "A,C", "A,C,G", "GG"]), ".", "PASS", ".", fmt] + cells
+        r = rng.random()
+        if r < 0.03:
+            fields = fields[:9 + rng.randint(0, n_samples - 1)]
+        elif r < 0.06:
+            fields.append("0|1:50")
+        return "\t".join(fields) + ("\r\n" if rng.random() < 0.03 else "\n")
     fmt = rng.choice(["GT:GQ"] * 6 + ["GT:AD:GQ", "GT:GQ:PL", "GQ:GT", "GT", "GT:DP", "GT:gq", "GT:GQ:GQ"])
     ref = rng.choice(["A", "C", "G", "T", "a", "N", "AT", "", "*"])
     alt = rng.choice(["A", "C", "G", "T", "t", "A,C", "A,C,G", "GG", "A,GG", "<DEL>", "*", ".", "", "A,", ",A"])
@@ -70,9 +93,9 @@ def weird_line(rng, chrom, pos, n_samples):
     return "\t".join(fields) + eol
 
 
-def build(tmp, seed):
+def build(tmp, seed, clean=0.0, max_samples=9):
     rng = random.Random(seed)
-    n_samples = rng.randint(1, 9)
+    n_samples = rng.randint(1, max_samples)
     names = [f"S{i:03d}" for i in range(n_samples)]
     length = 3000
     seq = "".join(rng.choice("ACGT") for _ in range(length))
@@ -85,7 +108,7 @@ def build(tmp, seed):
     for _ in range(rng.randint(150, 400)):
         step = rng.choice([0, 1, 1, 2, 3, 5, 8, -2])          # duplicates and the odd step backwards
         pos = max(pos + step, 1)
-        text += weird_line(rng, "1", pos, n_samples)
+        text += weird_line(rng, "1", pos, n_samples, clean)
     if rng.random() < 0.5:
         text = text.rstrip("\n")                               # no newline at the end of the file
     (tmp / "vcfs" / "chr1.vcf").write_text(text, newline="")
@@ -97,18 +120,33 @@ def build(tmp, seed):
     return dict(vcf_folder=str(tmp / "vcfs"), reference=str(tmp / "ref.fa"), gtf=str(tmp / "ann.gtf"), config_file=str(tmp / "config.tsv"))
 
 
-@pytest.mark.parametrize("seed", range(CASES))
-def test_adversarial_vcf_text(tmp_path, seed):
-    if not os.path.exists(BIN):
-        pytest.skip("run_vcf binary not built")
-    kw = build(tmp_path, 5000 + seed)
+def run_and_compare(tmp_path, seed, kw, extra=()):
     min_gq = [30, 31, 0, 46][seed % 4]
     cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--config_file", kw["config_file"],
            "--output_file", str(tmp_path / "out" / "o.csv"), "--mask_file", str(tmp_path / "mask.bed"), "--allow_file", str(tmp_path / "allow.tsv"),
-           "--min_gq", str(min_gq), "--ingest_only"]
+           "--min_gq", str(min_gq), "--ingest_only", *extra]
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_THREADS=str(1 + seed % 3)), timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     got = {m.group(1): (int(m.group(2)), int(m.group(3)), m.group(4))
            for m in re.finditer(r"\[INGEST\] chr (\S+): (\d+) variants x (\d+) samples digest ([0-9a-f]{16})", res.stdout)}
     exp = oracle_digests(kw, min_gq=min_gq, mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"))
     assert got == exp
+    return got
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_adversarial_vcf_text(tmp_path, seed):
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    run_and_compare(tmp_path, seed, build(tmp_path, 5000 + seed))
+
+
+@pytest.mark.parametrize("seed", range(max(CASES, 60)))
+def test_mostly_clean_lines(tmp_path, seed):
+    """Lines made of the plain "a|b:GQ" cells the whole-line fast path of process_variant takes, with its border cases mixed in:
+    GQ at and beyond 65535, empty / dotted / padded GQ, extra FORMAT parts, two-digit alleles, haploid and triploid cells, short and long lines,
+    CR-LF, a file without a final newline."""
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    got = run_and_compare(tmp_path, seed, build(tmp_path, 9000 + seed, clean=0.85, max_samples=40))
+    assert got and all(v[0] > 0 for v in got.values())

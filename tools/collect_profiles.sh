@@ -47,9 +47,10 @@ for layout, suffix, mode, b_site in (("packed", "", 3, 681), ("bytes", "_u8_layo
         "algorithmic_bytes": b_site * 10_000_000}
 json.dump(out, open(o + "/pmc_traffic.json", "w"), indent=1)
 PY
-step "strong-scaling step sizes on one GPU (the per-rank slab of 1, 2, 4, 8 GPUs): plain sweep and the sharded path with a one-rank RCCL group"
+step "strong-scaling step sizes on one GPU (the per-rank slab of 1, 2, 4, 8 GPUs): blocking fmh_hudson_sweep, the pipelined begin / end path on a local communicator (bench's N = 1 default) and on a one-rank RCCL group"
 for s in 10000000 5000000 2500000 1250000; do
-  python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_plain.jsonl
+  python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --sync-steps 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_blocking.jsonl
+  python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_pipelined_local.jsonl
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --force-collective 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_sharded_path.jsonl
 done
 step "other configs"; python3 $R/tools/measure_configs.py C2 C2x10 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
