@@ -4,6 +4,7 @@
 // hudson_fst_results.tsv.gz).  Host C++ does text ingest (config TSV, BED/TSV regions, FASTA index,
 // VCF) and the writers; every statistic over genotype data is computed on the GPU through the
 // C-ABI of libferromic_hip.so.  PHYLIP / CDS export and PCA are outside the path.
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <emmintrin.h>
@@ -50,6 +51,19 @@ typedef std::pair<int64_t, int64_t> Interval;  // 0-based half-open unless said 
 struct Error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+
+// The GPU check (HIP start-up: 0.07-0.2 s) runs on a helper thread under the text ingest; its verdict is polled once per block of VCF text and
+// when the helper is joined.  Not an Error: the per-chromosome handlers must not swallow it.
+struct NoGpuError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct GpuCheck {
+  std::atomic<int> state{0};  // 0 = pending or checked up front, 1 = present, 2 = absent
+  string message;
+} g_gpu_check;
+void throw_if_no_gpu() {
+  if (g_gpu_check.state.load(std::memory_order_acquire) == 2) throw NoGpuError(g_gpu_check.message);
+}
 
 void logmsg(const char* level, const string& m) {
   static const bool quiet = getenv("FERROMIC_PROGRESS") && string(getenv("FERROMIC_PROGRESS")) == "0";
@@ -959,6 +973,7 @@ VcfData process_vcf(const string& path, const string& chr, const vector<Interval
     }
     vector<vector<std::pair<Variant, uint8_t>>> parts(T);
     vector<string> complaints(T);
+    throw_if_no_gpu();
     StageTimer tparse("    ingest:parse_block");
     parallel_for(T, [&](unsigned t) {
       VariantScratch scr;
@@ -2219,13 +2234,25 @@ struct ShardSetup {
 // the first region touches a GPU.  Failures are left for the real calls to report.
 struct DeviceWarmup {
   std::thread t;
+  static bool enabled(const Args& args) { return !args.ingest_only && !getenv("FERROMIC_NO_WARMUP"); }
+  static bool checks_gpu(const Args& args) { return enabled(args) && args.devices.size() < 2; }  // several GPUs: main() checks before the communicators
   explicit DeviceWarmup(const Args& args) {
-    if (args.ingest_only || getenv("FERROMIC_NO_WARMUP")) return;
+    if (!enabled(args)) return;
+    const bool check_first = checks_gpu(args);
     vector<int> devices = args.devices.empty() ? vector<int>{args.device} : args.devices;
     std::sort(devices.begin(), devices.end());
     devices.erase(std::unique(devices.begin(), devices.end()), devices.end());
-    t = std::thread([devices] {
+    t = std::thread([devices, check_first] {
       StageTimer tw("  (helper thread) hip_start_up");
+      if (check_first) {
+        int n = 0;
+        if (fmh_device_count(&n) != FMH_OK) {
+          g_gpu_check.message = string("GPU required (run_vcf has no CPU fallback): ") + fmh_last_error();
+          g_gpu_check.state.store(2, std::memory_order_release);
+          return;
+        }
+        g_gpu_check.state.store(1, std::memory_order_release);
+      }
       const vector<uint8_t> rows(64 * 4, 1), mask(4, 1);
       for (int d : devices) {
         fmh_matrix* m = nullptr;
@@ -2238,8 +2265,8 @@ struct DeviceWarmup {
       }
     });
   }
-  void join() { if (t.joinable()) t.join(); }
-  ~DeviceWarmup() { join(); }
+  void join() { if (t.joinable()) t.join(); throw_if_no_gpu(); }
+  ~DeviceWarmup() { if (t.joinable()) t.join(); }
 };
 
 int run(const Args& args) {
@@ -2390,6 +2417,7 @@ int run(const Args& args) {
       continue;
     }
   }
+  warmup.join();  // a run whose chromosomes were all skipped still reports a missing GPU
   csv.flush();
   if (args.enable_fst) {  // final rewrite with header (process.rs:1557-1625)
     remove(hudson_path.c_str());
@@ -2462,12 +2490,28 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
 }  // namespace
 
 int main(int argc, char** argv) {
+  // glibc's allocator hands freed heap tops back to the kernel and grows arenas in small steps; with sixteen parser threads allocating a 5-KB
+  // row per VCF line that is a stream of brk / mprotect / madvise calls which serialise on the process's address-space lock against every
+  // page fault of every other thread (measured on the 16-CPU GPU box: 2.4 s of system time and 0.33-0.36 s for the 3.5 GB ingest, against
+  // 0.4 s and 0.18 s with the two settings below).  The process lives for seconds; it keeps what it has touched.
+  mallopt(M_TOP_PAD, 256 << 20);
+  mallopt(M_TRIM_THRESHOLD, INT32_MAX);
   try {
     const Args args = parse_args(argc, argv);
     if (args.print_formats) return print_formats();
     int n = 0;
-    if (!args.ingest_only) fmh_check(fmh_device_count(&n), "GPU required (run_vcf has no CPU fallback)");
-    return run(args);
+    if (!args.ingest_only && !DeviceWarmup::checks_gpu(args)) fmh_check(fmh_device_count(&n), "GPU required (run_vcf has no CPU fallback)");
+    int rc;
+    {
+      StageTimer t("run");
+      rc = run(args);
+    }
+    // Every output file is closed by now.  Leaving through exit() would spend 0.1-0.2 s unloading the HIP runtime and running the static
+    // destructors of a process that is about to disappear (FERROMIC_FULL_TEARDOWN=1 keeps the long way, for leak checkers).
+    fflush(stdout);
+    fflush(stderr);
+    if (!getenv("FERROMIC_FULL_TEARDOWN")) _exit(rc);
+    return rc;
   } catch (const std::exception& e) {
     fprintf(stderr, "Error: %s\n", e.what());
     return 1;
