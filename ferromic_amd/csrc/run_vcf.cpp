@@ -1846,12 +1846,25 @@ void gz_append(const string& path, const string& text) {  // open_append_compres
 
 // A complete gzip member holding `text` (what one open_append_compressed + write + finish produces).
 string gzip_member(const string& text) {
-  z_stream z;
-  memset(&z, 0, sizeof z);
   // Level 1: the tracks are long runs of "0," / "NA," around sparse values; the default level spends ~1 ms per 40 kB of such
   // text searching for longer matches and gains a few hundred bytes.  Readers see the same text either way.
   static const int level = getenv("FERROMIC_GZIP_LEVEL") ? atoi(getenv("FERROMIC_GZIP_LEVEL")) : 1;
-  if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
+  // One deflate state per thread, reset per member: deflateInit2 allocates and clears ~270 kB (one block of it above the allocator's
+  // mmap threshold), which was half the cost of a 30-kB track and a map / unmap per track on the process's address space.
+  struct State {
+    z_stream z;
+    bool ready = false;
+    ~State() { if (ready) deflateEnd(&z); }
+  };
+  thread_local State st;
+  z_stream& z = st.z;
+  if (!st.ready) {
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
+    st.ready = true;
+  } else if (deflateReset(&z) != Z_OK) {
+    throw Error("deflateReset failed");
+  }
   string out;
   out.resize(deflateBound(&z, (uLong)std::min<size_t>(text.size(), (size_t)1 << 30)) + 64);
   size_t in_off = 0, out_off = 0;
@@ -1868,12 +1881,11 @@ string gzip_member(const string& text) {
       const size_t room = std::min<size_t>(out.size() - out_off, (size_t)1 << 30);
       z.avail_out = (uInt)room;
       rc = deflate(&z, flush);
-      if (rc == Z_STREAM_ERROR) { deflateEnd(&z); throw Error("deflate failed"); }
+      if (rc == Z_STREAM_ERROR) throw Error("deflate failed");
       out_off += room - z.avail_out;
     } while (z.avail_out == 0 || (flush == Z_FINISH && rc != Z_STREAM_END));
     if (flush == Z_FINISH) break;
   }
-  deflateEnd(&z);
   out.resize(out_off);
   return out;
 }
@@ -1882,32 +1894,37 @@ string gzip_member(const string& text) {
 // its own gzip member, in track order (the files are multi-member already: one member per region in the
 // reference; readers see the same decompressed text).
 typedef std::function<string()> TrackFn;
-// `files` = (path, tracks) pairs; all tracks of all files form one parallel batch
-void append_tracks(const vector<std::pair<string, vector<TrackFn>>>& files) {
+// `files` = one list of tracks per output file; returns, per file, the gzip members of its tracks in order (empty tracks dropped).
+// All tracks form one batch: formatted and deflated on the pool when they are large, inline when the whole region is small (hundreds of
+// small regions are compressed by their region workers side by side; waking the pool for 40-kB tracks cost more than deflating them).
+std::atomic<unsigned> g_region_workers{1};  // region workers running side by side (set by run())
+vector<vector<string>> compress_tracks(const vector<vector<TrackFn>>& files, size_t approx_tokens) {
   vector<std::pair<size_t, size_t>> jobs;  // (file, track)
-  for (size_t f = 0; f < files.size(); ++f) for (size_t t = 0; t < files[f].second.size(); ++t) jobs.push_back({f, t});
-  if (jobs.empty()) return;
+  for (size_t f = 0; f < files.size(); ++f) for (size_t t = 0; t < files[f].size(); ++t) jobs.push_back({f, t});
   vector<string> members(jobs.size());
   std::atomic<size_t> next{0};
-  parallel_for((unsigned)std::min<size_t>(worker_threads(), jobs.size()), [&](unsigned) {
+  auto work = [&](unsigned) {
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= jobs.size()) break;
-      const string text = files[jobs[i].first].second[jobs[i].second]();
+      const string text = files[jobs[i].first][jobs[i].second]();
       if (!text.empty()) members[i] = gzip_member(text);
     }
-  });
-  size_t i = 0;
-  for (size_t fi = 0; fi < files.size(); ++fi) {
-    FILE* f = nullptr;
-    for (size_t t = 0; t < files[fi].second.size(); ++t, ++i) {
-      const string& m = members[i];
-      if (m.empty()) continue;
-      if (!f && !(f = fopen(files[fi].first.c_str(), "ab"))) throw Error("cannot open " + files[fi].first);
-      if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); throw Error("write failed: " + files[fi].first); }
-    }
-    if (f) fclose(f);
-  }
+  };
+  // inline when the tracks are tiny, or when the region workers alone already occupy the CPUs (each deflating its own region's tracks)
+  if (approx_tokens * jobs.size() < ((size_t)1 << 16) || 2 * g_region_workers.load() >= worker_threads()) work(0u);
+  else parallel_for((unsigned)std::min<size_t>(worker_threads(), jobs.size()), work);
+  vector<vector<string>> out(files.size());
+  for (size_t i = 0; i < jobs.size(); ++i) if (!members[i].empty()) out[jobs[i].first].push_back(std::move(members[i]));
+  return out;
+}
+void append_members(const string& path, const vector<string>& members) {
+  if (members.empty()) return;
+  FILE* f = fopen(path.c_str(), "ab");
+  if (!f) throw Error("cannot open " + path);
+  for (const string& m : members)
+    if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); throw Error("write failed: " + path); }
+  fclose(f);
 }
 
 struct RegionOutput {
@@ -1919,13 +1936,55 @@ struct RegionOutput {
   vector<std::tuple<int64_t, double, double, double>> hudson_sites;
   vector<vector<string>> hudson_rows;
   vector<vector<string>> wc_rows;
+  vector<string> diversity_members, fst_members;  // the region's FALSTA tracks as gzip members, made by the region's worker
 };
 
 // One dense FALSTA line: `n` comma-joined tokens, `dflt` everywhere except at the positions present, where the
 // LAST record of a position wins (the reference assigns into a Vec in record order).
+// `tokens` default tokens, each followed by a comma, copied from a per-thread block of the repeated pattern
+inline void append_default_run(string& out, const char* dflt, size_t dl, size_t tokens) {
+  thread_local string pat, pat_of;
+  if (pat.empty() || pat_of != dflt) {
+    pat.clear();
+    while (pat.size() < 65536) { pat.append(dflt, dl); pat.push_back(','); }
+    pat_of = dflt;
+  }
+  const size_t unit = dl + 1, per_block = pat.size() / unit;
+  while (tokens) {
+    const size_t t = std::min(tokens, per_block);
+    out.append(pat.data(), t * unit);
+    tokens -= t;
+  }
+}
+
 template <class PosAt, class TokenAt>
 bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, PosAt pos_at, TokenAt token_at, const char* dflt,
                  vector<int32_t>& slot) {
+  const size_t dl0 = strlen(dflt);
+  // Records in ascending position order (the usual case: variants are sorted): the gaps between them are runs of the default token and are
+  // block-copied; equal positions are neighbours, so "the last record wins" is "skip a record whose successor has its position".
+  bool ascending = true;
+  for (size_t i = 1; i < count && ascending; ++i) ascending = pos_at(i - 1) <= pos_at(i);
+  if (ascending) {
+    out.reserve(out.size() + (size_t)n * (dl0 + 1) + 16 * count + 16);
+    bool any_rec = false;
+    int64_t next_k = 0;  // first position of the line not written yet
+    for (size_t i = 0; i < count; ++i) {
+      const int64_t p = pos_at(i) - 1;
+      if (!hal_contains(region, p)) continue;
+      any_rec = true;
+      if (i + 1 < count && pos_at(i + 1) - 1 == p) continue;
+      const int64_t k = p - region.first;
+      append_default_run(out, dflt, dl0, (size_t)(k - next_k));
+      out += token_at(i);
+      out.push_back(',');
+      next_k = k + 1;
+    }
+    if (n > next_k) append_default_run(out, dflt, dl0, (size_t)(n - next_k));
+    if (n > 0) out.back() = '\n';
+    else out.push_back('\n');
+    return any_rec;
+  }
   slot.assign((size_t)n, -1);
   bool any = false;
   for (size_t i = 0; i < count; ++i) {
@@ -2038,6 +2097,29 @@ int print_formats() {
   return 0;
 }
 
+// --bench_tracks (no GPU): formats and deflates the tracks of a made-up 15-kb region with 120 variants, 500 times on one thread;
+// what the writers cost per small region.
+int bench_tracks() {
+  RegionOutput r;
+  r.seqname = "1";
+  r.region_start1 = 1000;
+  r.region_end1 = 15999;
+  for (int g = 0; g < 2; ++g)
+    for (int f = 0; f < 2; ++f)
+      for (int i = 0; i < 120; ++i) r.diversity.push_back({1000 + 125 * i, 0.289855 + i * 1e-3, 0.267788, g, f != 0});
+  for (int i = 0; i < 120; ++i) {
+    r.wc_sites.push_back({1000 + 125 * i, 0.5, 0.25, 0.5, 0.5, 0.25, 0.5});
+    r.hudson_sites.push_back({1000 + 125 * i, 0.25, 0.125, 0.5});
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t bytes = 0, members = 0;
+  for (int rep = 0; rep < 500; ++rep)
+    for (auto& file : compress_tracks({diversity_tracks(r), fst_tracks(r)}, 15000)) for (auto& m : file) { bytes += m.size(); ++members; }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 500;
+  printf("tracks of one region: %.3f ms, %zu members, %zu bytes\n", ms, members / 500, bytes / 500);
+  return 0;
+}
+
 // ---- per-region driver (process.rs:2468-3653) ----------------------------------------------------------------
 struct Args {
   string vcf_folder, chr, region, config_file, output_file = "output.csv", mask_file, allow_file, reference, gtf, fst_populations;
@@ -2045,7 +2127,7 @@ struct Args {
   unsigned min_gq = 30;
   bool enable_fst = false, enable_pca = false;
   int device = 0;
-  int workers_per_device = 4;  // region workers per GPU: host-side packing, downloads and writers of one region overlap the sweeps of another
+  int workers_per_device = 0;  // region workers per GPU (0 = by the CPU share): host-side packing, downloads and track writers of one region overlap the sweeps of another
   bool print_formats = false;  // diagnostic: header lines + sample FALSTA records (needs no GPU, no inputs)
   bool ingest_only = false;  // diagnostic: parse the inputs, report counts, compute nothing (needs no GPU)
   vector<int> devices;  // --devices: one worker thread per entry, config regions dealt out dynamically
@@ -2061,8 +2143,12 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
   const vector<Interval>* mask_chr = nullptr;
   { auto it = mask.find(chr); if (it != mask.end()) mask_chr = &it->second; }
   vector<const Variant*> unf, fil;
-  for (size_t i = 0; i < vcf.variants.size(); ++i) {
+  // the variants are sorted by position (process_vcf): only the run inside the region is visited
+  const int64_t lo_pos = std::max(ext.first, entry.interval.first);
+  size_t first = (size_t)(std::lower_bound(vcf.variants.begin(), vcf.variants.end(), lo_pos, [](const Variant& v, int64_t p) { return v.position < p; }) - vcf.variants.begin());
+  for (size_t i = first; i < vcf.variants.size(); ++i) {
     const Variant& v = vcf.variants[i];
+    if ((uint64_t)v.position >= (uint64_t)ext.second || (uint64_t)v.position >= (uint64_t)entry.interval.second) break;  // hal_contains' unsigned order; positions ascend
     if (!hal_contains(ext, v.position) || !hal_contains(entry.interval, v.position)) continue;
     if ((!allow_chr || position_in_regions(v.position, *allow_chr)) && (!mask_chr || !position_in_regions(v.position, *mask_chr))) unf.push_back(&v);
     if (vcf.flags[i] == FLAG_PASS) fil.push_back(&v);
@@ -2377,7 +2463,8 @@ int run(const Args& args) {
           std::optional<RegionOutput>& res = done[emitted];
           if (res) {
             csv << join(res->csv_row, ',', true) << "\n";
-            append_tracks({{div_path, diversity_tracks(*res)}, {fst_path, fst_tracks(*res)}});
+            append_members(div_path, res->diversity_members);
+            append_members(fst_path, res->fst_members);
             for (auto& r : res->hudson_rows) hudson_rows.push_back(r);
             for (auto& r : res->wc_rows) wc_rows.push_back(r);
             res.reset();
@@ -2395,6 +2482,14 @@ int run(const Args& args) {
           try { res = process_single_config_entry(*todo[i], vcf, final_mask, allow_regions ? &*allow_regions : nullptr, chr_length, chr, mine,
                                                     csv_for_hudson ? &*csv_for_hudson : nullptr); }
           catch (const std::exception& err) { logmsg("ERROR", string("DROPPED: Error processing region: ") + err.what()); }
+          if (res) try {  // tracks are formatted and deflated here, outside the ordered emit: only the file appends are serial
+            vector<vector<string>> members = compress_tracks({diversity_tracks(*res), fst_tracks(*res)}, (size_t)std::max<int64_t>(res->region_end1 - res->region_start1 + 1, 1));
+            res->diversity_members = std::move(members[0]);
+            res->fst_members = std::move(members[1]);
+            res->diversity.clear(); res->diversity.shrink_to_fit();
+            res->wc_sites.clear(); res->wc_sites.shrink_to_fit();
+            res->hudson_sites.clear(); res->hudson_sites.shrink_to_fit();
+          } catch (const std::exception& err) { logmsg("ERROR", string("DROPPED: Error writing the tracks of a region: ") + err.what()); res.reset(); }
           std::lock_guard<std::mutex> lock(emit_mutex);
           done[i] = std::move(res);
           finished[i] = 1;
@@ -2402,9 +2497,14 @@ int run(const Args& args) {
         }
       };
       vector<int> worker_devices;
+      // Per region the host side (packing, track formatting and deflate: ~10 ms for a few thousand sites) outweighs the GPU side (~1 ms), so the
+      // default is as many workers as the process has CPUs, shared between the GPUs, at least 4 and at most 16 per GPU.
+      const int n_gpus = (int)std::max<size_t>(args.devices.size(), 1);
+      const int workers_per_device = args.workers_per_device > 0 ? args.workers_per_device : std::max(4, std::min(16, (int)fmh_host::usable_cpus() / n_gpus));
       for (int d : args.devices.empty() ? vector<int>{args.device} : args.devices)
-        for (int k = 0; k < std::max(1, args.workers_per_device); ++k) worker_devices.push_back(d);
+        for (int k = 0; k < workers_per_device; ++k) worker_devices.push_back(d);
       if (worker_devices.size() > todo.size()) worker_devices.resize(std::max<size_t>(todo.size(), 1));
+      g_region_workers.store((unsigned)std::max<size_t>(worker_devices.size(), 1));
       if (worker_devices.size() <= 1) {
         worker(worker_devices.empty() ? args.device : worker_devices[0]);
       } else {
@@ -2467,6 +2567,7 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--fst_populations") a.fst_populations = value();
     else if (k == "--ingest_only") a.ingest_only = true;
     else if (k == "--print_formats") { a.print_formats = true; return a; }
+    else if (k == "--bench_tracks") { exit(bench_tracks()); }
     else if (k == "--workers_per_device") a.workers_per_device = std::max(1, atoi(value().c_str()));
     else if (k == "--device") a.device = atoi(value().c_str());
     else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)
@@ -2478,7 +2579,7 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     }
     else if (k == "--help" || k == "-h") {
       printf("run_vcf --vcf_folder DIR --reference FA --gtf GTF [--config_file TSV | --chr C [--region S-E]] [--output_file CSV]\n"
-             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--fst_populations CSV] [--device N | --devices N|a,b,c] [--workers_per_device 4]\n");
+             "        [--min_gq 30] [--mask_file F] [--allow_file F] [--exclude a,b] [--fst] [--fst_populations CSV] [--device N | --devices N|a,b,c] [--workers_per_device N]\n");
       exit(0);
     } else throw Error("unexpected argument '" + k + "'");
   }
@@ -2496,6 +2597,23 @@ int main(int argc, char** argv) {
   // 0.4 s and 0.18 s with the two settings below).  The process lives for seconds; it keeps what it has touched.
   mallopt(M_TOP_PAD, 256 << 20);
   mallopt(M_TRIM_THRESHOLD, INT32_MAX);
+  if (getenv("FERROMIC_TIMING")) {  // how long the loader took: process start (/proc/self/stat field 22, 10-ms ticks since boot) to main()
+    if (FILE* f = fopen("/proc/self/stat", "r")) {
+      char buf[1024] = {0};
+      const size_t got = fread(buf, 1, sizeof buf - 1, f);
+      fclose(f);
+      const char* p = got ? strrchr(buf, ')') : nullptr;
+      unsigned long long start_ticks = 0;
+      if (p) {
+        int field = 2;
+        for (const char* q = p + 1; *q && field < 22; ++q) if (*q == ' ') { ++field; if (field == 22) start_ticks = strtoull(q + 1, nullptr, 10); }
+      }
+      struct timespec ts;
+      clock_gettime(CLOCK_BOOTTIME, &ts);
+      const double now = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, started = (double)start_ticks / (double)sysconf(_SC_CLK_TCK);
+      if (start_ticks) fprintf(stderr, "[TIMING] process_start_to_main %.3f\n", now - started);
+    }
+  }
   try {
     const Args args = parse_args(argc, argv);
     if (args.print_formats) return print_formats();

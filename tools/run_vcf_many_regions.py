@@ -33,6 +33,8 @@ def main():
     out_csv = os.path.join(tmp, "out", "results.csv")
     cmd = [RS.BIN, "--vcf_folder", os.path.join(tmp, "vcfs"), "--reference", os.path.join(tmp, "ref.fa"), "--gtf", os.path.join(tmp, "ann.gtf"),
            "--config_file", os.path.join(tmp, "config.tsv"), "--output_file", out_csv, "--fst"]
+    if os.environ.get("RUN_VCF_WORKERS"):
+        cmd += ["--workers_per_device", os.environ["RUN_VCF_WORKERS"]]
     if os.environ.get("RUN_VCF_DEVICES"):
         cmd += ["--devices", os.environ["RUN_VCF_DEVICES"]]
     t0 = time.perf_counter()
