@@ -53,6 +53,11 @@ for s in 10000000 5000000 2500000 1250000; do
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_pipelined_local.jsonl
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --force-collective 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_sharded_path.jsonl
 done
+step "what the per-site tracks cost next to the read stream: a do-nothing kernel with the sweep's access pattern (tools/microbench/store_bursts.hip)"
+mkdir -p $R/build/micro
+[ -x $R/build/micro/store_bursts ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/build/micro/store_bursts $R/tools/microbench/store_bursts.hip
+for wg in 3 4; do $R/build/micro/store_bursts 10000000 7 640 $wg >> $O/store_bursts_packed_row_width.jsonl; done
+$R/build/micro/store_bursts 10000000 7 5008 4 >> $O/store_bursts_u8_row_width.jsonl
 step "other configs"; python3 $R/tools/measure_configs.py C2 C2x10 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
 MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs_u8_layout.jsonl
 step "C5 counting routes on u8 rows: v_dot4 / int8 MFMA (4 and 2 K steps in flight)"
@@ -83,5 +88,6 @@ python3 $R/tools/measure_h2d.py 2>/dev/null | grep '^{' > $O/h2d.json
 python3 $R/tools/measure_api_c2.py 2>/dev/null | grep '^{' > $O/api_c2.json
 python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 2>/dev/null | tail -1 > $O/run_vcf_scale_200k_x_2500.json
 python3 $R/tools/run_vcf_many_regions.py 2>/dev/null | tail -1 > $O/run_vcf_500_regions.json
+for c in gzip bgzf; do python3 $R/tools/run_vcf_scale.py --sites 50000 --samples 2500 --compress $c 2>/dev/null | tail -1 >> $O/run_vcf_compressed_inputs.jsonl; done
 rm -rf $O/c4_trace $O/c4_pmc_fetch $O/c4_pmc_write $O/c4_pmc_fetch8 $O/c4_pmc_write8 $O/c5_trace $O/c5_pmc $O/c5_pmc_fetch $O/c5_pmc_dot4 $O/cfg_pmc1 $O/cfg_pmc2
 ls -la $O
