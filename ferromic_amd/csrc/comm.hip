@@ -3,7 +3,9 @@
 // Transport 0: RCCL (ncclAllReduce over xGMI), bound at run time with dlopen so that a single-GPU host never loads the
 // library and a process that already maps a copy (PyTorch's wheel bundles one) shares it.  Transport 1: an in-process
 // rendezvous that sums in rank order on the host, for one process whose "ranks" alias a device (RCCL refuses two ranks on
-// one GPU) - the rehearsal path of run_vcf --devices 0,0 and of the tests on a one-GPU box.
+// one GPU) - the rehearsal path of run_vcf --devices 0,0 and of the tests on a one-GPU box.  Transport 2: a local one-rank
+// communicator (fmh_comm_init_local): nothing to exchange, no RCCL - the pipelined begin / end calls for a single GPU that scans
+// many windows, and what bench.py runs at N = 1 so that every N has the same step structure.
 //
 // The reference has no counterpart file: its reduce is rayon's fold/reduce inside one address space
 // (stats.rs:1365-1461) and the serial sums of 1554-1623 / 2145-2374.
