@@ -830,6 +830,12 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     const bool long_launch = lpr == 16 && P <= 2 && a.row_count > (size_t)ctx.cus * 12 * kTileRows * 5;
     a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH") && (!long_launch || getenv("FMH_PACKED_PREFETCH"));
     smem = (size_t)P * a.nvec_pad * 16;
+    // the C4 shape defers its epilogues (sweep_kernel, kDefer): room for the parked counts of kDeferTiles tiles per wave
+    if (!general && !missing && P <= 2 && lpr == 16 && (mode & kModeWc) == 0) {
+      const char* e = getenv("FMH_DEFER_TILES");  // read per call: measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
+      a.defer_tiles = e && atoi(e) >= 1 && atoi(e) <= kDeferTiles ? atoi(e) : -1;
+      smem += (size_t)kWavesPerBlock * kDeferTiles * 64 * P * 4;
+    }
     mask_mode = kMaskPacked;
     if (smem > lds_limit)
       return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep fewer groups at a time on rows this wide", P, m->columns);

@@ -37,6 +37,7 @@ constexpr int kTileRows = 64;
 constexpr double kFstEps = 1e-12;  // FST_EPSILON, stats.rs:26
 
 enum Mode : int { kModeSummary = 1, kModeHudson = 2, kModeDiversity = 4, kModeWc = 8 };
+constexpr int kDeferTiles = 16;  // tiles whose epilogues a wave defers (SweepArgs.defer_tiles; 4 bytes of LDS per site and group)
 enum Formula : int { kFormulaSparse = 0, kFormulaDense = 1, kFormulaSummary = 2 };
 
 struct MatrixView {
@@ -74,6 +75,8 @@ struct SweepArgs {
   uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
   int unroll;             // vectors per lane issued back to back (4 or 8)
   int single_trip;        // packed cores: nvec_pad == lanes-per-row * unroll, i.e. one batch of loads covers a row
+  int defer_tiles;        // kDefer kernels: count this many of a wave's tiles, parking the counts in LDS, then run their epilogues and stores back to back
+                          // (1 = the undeferred order; -1 on the host side = let launch_one choose by the launch size)
   int n_groups;           // caller's group count (<= kernel P; padded groups are never reported)
   size_t row_begin;
   size_t row_count;
@@ -1089,6 +1092,11 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
 // ------------------------------------------------------------------------------------------------
 // MM = where the membership masks live (kMaskLdsBytes / kMaskGlobalBytes / kMaskLdsBits, see mask_vec).
 // NPL = bit planes of a packed multi-allelic matrix (2: alleles up to 3, 3: up to 7); ignored elsewhere.
+// kernels that defer their epilogues (kDefer below) are held to three waves per SIMD: left alone, the register allocator keeps the hoisted
+// invariants of the epilogue loop alive across the counting loop (233 VGPRs, two waves), and occupancy is worth more than that (2 -> 3 waves: 16 %)
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
+constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL && !MISSING && P <= 2 && LPR == 16 && (MODE & kModeWc) == 0) ? 3 : 1; }
+
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   static_assert(NPL == 2 || (NPL == 3 && GENERAL && MM == kMaskPacked), "a third plane exists on packed multi-allelic matrices only");
@@ -1146,6 +1154,78 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
 
   const size_t ntiles = (A.row_count + kTileRows - 1) / kTileRows;
   const size_t tile_stride = (size_t)gridDim.x * kWavesPerBlock;
+
+  // Deferred epilogues (biallelic, nothing missing, one or two groups, sixteen-lane rows - the C4 shape).  A wave counts kDeferTiles of its
+  // tiles in a row, parking the per-site counts in LDS (8 bytes per site), and only then runs their epilogues: its track stores leave in one
+  // burst of kDeferTiles x 7 instructions instead of 7 after every tile.  The tiles, their order per lane and every per-site operation are
+  // unchanged (same bits, same regional sums); only WHEN a wave writes changes.  Measured with the do-nothing kernel of
+  // tools/microbench/store_bursts.hip (modes 20 / 21: the sweep's reads with one row in flight per lane group, stores per tile vs per eight
+  // tiles): 1.256 -> 1.150 ms at 16 waves per CU, 1.415 -> 1.322 ms at 12.
+  constexpr bool kDefer = MM == kMaskPacked && !GENERAL && !MISSING && P <= 2 && LPR == 16 && (MODE & kModeWc) == 0;
+  if constexpr (kDefer) {
+    {
+      // (the only tile loop of these kernels: defer_tiles = 1 is the undeferred order, through the same code)
+      const int ch = A.defer_tiles < 1 ? 1 : (A.defer_tiles > kDeferTiles ? kDeferTiles : A.defer_tiles);
+      const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
+      uint32_t* park = reinterpret_cast<uint32_t*>(smem + (size_t)P * nvec_pad * 16) + (size_t)wave * kDeferTiles * 64 * P;
+      for (size_t tile0 = (size_t)blockIdx.x * kWavesPerBlock + wave; tile0 < ntiles; tile0 += tile_stride * ch) {
+#pragma unroll 1
+        for (int b = 0; b < ch; ++b) {  // counts
+          const size_t tile = tile0 + (size_t)b * tile_stride;
+          if (tile >= ntiles) break;
+          const size_t tile_row0 = tile * kTileRows;
+          uint32_t alt_mine[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) alt_mine[p] = 0;
+          {
+            for (int s = 0; s < LPR; ++s) {
+              const size_t rel = tile_row0 + (size_t)grp * LPR + s;
+              const size_t row = A.row_begin + (rel < A.row_count ? rel : A.row_count - 1);
+              const uint8_t* row_ptr = mv.data + row * mv.pitch;
+              uint32_t n[P], n_all, aor, sp[P][1];
+              if (A.unroll == 4) count_row_packed<P, false, false, 1, 4, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp);
+              else if (A.unroll == 3) count_row_packed<P, false, false, 1, 3, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp);
+              else count_row_packed<P, false, false, 1, 2, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp);
+              if (gl == s) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) alt_mine[p] = sp[p][0];
+              }
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < P; ++p) park[((size_t)b * 64 + lane) * P + p] = alt_mine[p];
+        }
+#pragma unroll 1
+        for (int b = 0; b < ch; ++b) {  // epilogues and stores of the same tiles, back to back
+          const size_t tile = tile0 + (size_t)b * tile_stride;
+          if (tile >= ntiles) break;
+          SiteTally<P> mine;
+          WcSite<P> wc;
+          double hud_dot = 0.0;
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            // the group size is re-read opaquely per tile: as a visible loop invariant, everything the epilogue derives from it (f64 reciprocals,
+            // products) is hoisted out of this loop AND kept alive across the counting loop above - 233 VGPRs instead of 160
+            uint32_t gs = A.group_size[p];
+            asm volatile("" : "+s"(gs));
+            mine.n[p] = gs;
+            mine.alt[p] = park[((size_t)b * 64 + lane) * P + p];
+            mine.distinct[p] = 0;
+            mine.ssq[p] = 0;
+          }
+          uint32_t cols = mv.columns;
+          asm volatile("" : "+s"(cols));
+          mine.n_all = cols;
+          finish_biallelic_site<P, MODE>(mine, hud_dot);
+          const size_t my_rel = tile * kTileRows + lane;
+          site_epilogue<P, MODE, MISSING, GENERAL>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T);
+        }
+      }
+      reduce_block_totals<P, MODE>(A, T);
+      return;
+    }
+  }
+
   for (size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += tile_stride) {
     const size_t tile_row0 = tile * kTileRows;  // relative to row_begin
     SiteTally<P> mine;
