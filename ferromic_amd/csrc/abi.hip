@@ -831,10 +831,10 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH") && (!long_launch || getenv("FMH_PACKED_PREFETCH"));
     smem = (size_t)P * a.nvec_pad * 16;
     // the C4 shape defers its epilogues (sweep_kernel, kDefer): room for the parked counts of kDeferTiles tiles per wave
-    if (!general && !missing && P <= 2 && lpr == 16 && (mode & kModeWc) == 0) {
+    if (!general && P <= 2 && (lpr == 16 || lpr == 4) && (mode & kModeWc) == 0) {
       const char* e = getenv("FMH_DEFER_TILES");  // read per call: measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
       a.defer_tiles = e && atoi(e) >= 1 && atoi(e) <= kDeferTiles ? atoi(e) : -1;
-      smem += (size_t)kWavesPerBlock * kDeferTiles * 64 * P * 4;
+      smem += defer_lds_bytes(P, mode, missing);
     }
     mask_mode = kMaskPacked;
     if (smem > lds_limit)

@@ -1097,6 +1097,20 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
 constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL && !MISSING && P <= 2 && LPR == 16 && (MODE & kModeWc) == 0) ? 3 : 1; }
 
+// Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
+// 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
+constexpr bool defer_kernel() { return MM == 3 /* kMaskPacked */ && !GENERAL && P <= 2 && (LPR == 16 || LPR == 4) && (MODE & kModeWc) == 0; }
+template <int P, int MODE, bool MISSING>
+constexpr int defer_values() { return MISSING ? 2 * P + ((MODE & kModeWc) != 0 ? 1 : 0) : P; }
+template <int P, int MODE, bool MISSING>
+constexpr int defer_depth() { return defer_values<P, MODE, MISSING>() <= 2 ? kDeferTiles : kDeferTiles / 2; }
+inline size_t defer_lds_bytes(int P, int mode, bool missing) {
+  const int k = missing ? 2 * P + ((mode & kModeWc) != 0 ? 1 : 0) : P;
+  const int d = k <= 2 ? kDeferTiles : kDeferTiles / 2;
+  return (size_t)kWavesPerBlock * d * 64 * k * 4;
+}
+
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   static_assert(NPL == 2 || (NPL == 3 && GENERAL && MM == kMaskPacked), "a third plane exists on packed multi-allelic matrices only");
@@ -1161,39 +1175,64 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   // unchanged (same bits, same regional sums); only WHEN a wave writes changes.  Measured with the do-nothing kernel of
   // tools/microbench/store_bursts.hip (modes 20 / 21: the sweep's reads with one row in flight per lane group, stores per tile vs per eight
   // tiles): 1.256 -> 1.150 ms at 16 waves per CU, 1.415 -> 1.322 ms at 12.
-  constexpr bool kDefer = MM == kMaskPacked && !GENERAL && !MISSING && P <= 2 && LPR == 16 && (MODE & kModeWc) == 0;
+  constexpr bool kDefer = defer_kernel<P, MODE, MISSING, GENERAL, MM, LPR>();
   if constexpr (kDefer) {
     {
       // (the only tile loop of these kernels: defer_tiles = 1 is the undeferred order, through the same code)
-      const int ch = A.defer_tiles < 1 ? 1 : (A.defer_tiles > kDeferTiles ? kDeferTiles : A.defer_tiles);
+      constexpr int K = defer_values<P, MODE, MISSING>();   // parked u32 per site: alt per group (+ called per group, + called in all, with missing calls)
+      constexpr int D = defer_depth<P, MODE, MISSING>();    // tiles a wave can park
+      const int ch = A.defer_tiles < 1 ? 1 : (A.defer_tiles > D ? D : A.defer_tiles);
       const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-      uint32_t* park = reinterpret_cast<uint32_t*>(smem + (size_t)P * nvec_pad * 16) + (size_t)wave * kDeferTiles * 64 * P;
+      uint32_t* park = reinterpret_cast<uint32_t*>(smem + (size_t)P * nvec_pad * 16) + (size_t)wave * D * 64 * K;
       for (size_t tile0 = (size_t)blockIdx.x * kWavesPerBlock + wave; tile0 < ntiles; tile0 += tile_stride * ch) {
 #pragma unroll 1
         for (int b = 0; b < ch; ++b) {  // counts
           const size_t tile = tile0 + (size_t)b * tile_stride;
           if (tile >= ntiles) break;
           const size_t tile_row0 = tile * kTileRows;
-          uint32_t alt_mine[P];
+          uint32_t alt_mine[P], n_mine[P], n_all_mine = 0;
 #pragma unroll
-          for (int p = 0; p < P; ++p) alt_mine[p] = 0;
-          {
+          for (int p = 0; p < P; ++p) { alt_mine[p] = 0; n_mine[p] = 0; }
+          bool counted = false;
+          if constexpr (!MISSING && LPR != 16) {
+            if (A.single_trip) {  // four-lane rows keep the prefetching row loop (level or 1-6 % ahead at every launch size)
+              if (A.unroll == 5) tile_rows_packed_prefetch<P, 5, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+              else if (A.unroll == 3) tile_rows_packed_prefetch<P, 3, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+              else if (A.unroll == 2) tile_rows_packed_prefetch<P, 2, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+              else tile_rows_packed_prefetch<P, 1, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
+              counted = true;
+            }
+          }
+          if (!counted) {
             for (int s = 0; s < LPR; ++s) {
               const size_t rel = tile_row0 + (size_t)grp * LPR + s;
               const size_t row = A.row_begin + (rel < A.row_count ? rel : A.row_count - 1);
               const uint8_t* row_ptr = mv.data + row * mv.pitch;
+              const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
               uint32_t n[P], n_all, aor, sp[P][1];
-              if (A.unroll == 4) count_row_packed<P, false, false, 1, 4, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp);
-              else if (A.unroll == 3) count_row_packed<P, false, false, 1, 3, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp);
-              else count_row_packed<P, false, false, 1, 2, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp);
+#define FMH_COUNT_DEFER(UV) count_row_packed<P, MISSING, NEED_ALL, 1, UV, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, bits_ptr, gl, n, n_all, aor, sp)
+              if constexpr (LPR != 16) {
+                if (A.unroll == 5) FMH_COUNT_DEFER(5);
+                else if (A.unroll == 3) FMH_COUNT_DEFER(3);
+                else if (A.unroll == 2) FMH_COUNT_DEFER(2);
+                else FMH_COUNT_DEFER(1);
+              } else {
+                if (A.unroll == 4) FMH_COUNT_DEFER(4);
+                else if (A.unroll == 3) FMH_COUNT_DEFER(3);
+                else FMH_COUNT_DEFER(2);
+              }
+#undef FMH_COUNT_DEFER
               if (gl == s) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) alt_mine[p] = sp[p][0];
+                for (int p = 0; p < P; ++p) { alt_mine[p] = sp[p][0]; if (MISSING) n_mine[p] = n[p]; }
+                if (MISSING && NEED_ALL) n_all_mine = n_all;
               }
             }
           }
+          uint32_t* slot = park + ((size_t)b * 64 + lane) * K;
 #pragma unroll
-          for (int p = 0; p < P; ++p) park[((size_t)b * 64 + lane) * P + p] = alt_mine[p];
+          for (int p = 0; p < P; ++p) { slot[p] = alt_mine[p]; if (MISSING) slot[P + p] = n_mine[p]; }
+          if (MISSING && NEED_ALL) slot[2 * P] = n_all_mine;
         }
 #pragma unroll 1
         for (int b = 0; b < ch; ++b) {  // epilogues and stores of the same tiles, back to back
@@ -1202,20 +1241,26 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
           SiteTally<P> mine;
           WcSite<P> wc;
           double hud_dot = 0.0;
+          const uint32_t* slot = park + ((size_t)b * 64 + lane) * K;
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             // the group size is re-read opaquely per tile: as a visible loop invariant, everything the epilogue derives from it (f64 reciprocals,
             // products) is hoisted out of this loop AND kept alive across the counting loop above - 233 VGPRs instead of 160
             uint32_t gs = A.group_size[p];
             asm volatile("" : "+s"(gs));
-            mine.n[p] = gs;
-            mine.alt[p] = park[((size_t)b * 64 + lane) * P + p];
+            mine.n[p] = MISSING ? slot[P + p] : gs;
+            mine.alt[p] = slot[p];
             mine.distinct[p] = 0;
             mine.ssq[p] = 0;
           }
           uint32_t cols = mv.columns;
           asm volatile("" : "+s"(cols));
-          mine.n_all = cols;
+          mine.n_all = MISSING ? (NEED_ALL ? slot[2 * P] : 0u) : cols;
+          if constexpr ((MODE & kModeWc) != 0) {
+            constexpr int NW = 1 + (P * (P - 1)) / 2;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { wc.a[k] = 0.0; wc.b[k] = 0.0; }
+          }
           finish_biallelic_site<P, MODE>(mine, hud_dot);
           const size_t my_rel = tile * kTileRows + lane;
           site_epilogue<P, MODE, MISSING, GENERAL>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T);

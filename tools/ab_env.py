@@ -28,15 +28,17 @@ def main():
     lib = _abi.load()
     cases = [(10_000_000, 2500, "packed"), (2_000_000, 5000, "packed"), (5_000_000, 1250, "packed"), (4_000_000, 500, "packed"), (2_000_000, 2500, "bytes")]
     if len(sys.argv) > 2:  # tools/ab_env.py VAR=value SITESxSAMPLES[:layout] ...
-        cases = [(int(c.split(":")[0].split("x")[0]), int(c.split(":")[0].split("x")[1]), c.split(":")[1] if ":" in c else "packed") for c in sys.argv[2:]]
+        cases = [(int(c.split(":")[0].split("x")[0]), int(c.split(":")[0].split("x")[1]), c.split(":", 1)[1] if ":" in c else "packed") for c in sys.argv[2:]]
     for S, N, layout in cases:
         H = 2 * N
         poc = np.zeros(H, dtype=np.uint8)
         poc[H // 2:] = 1
         masks = np.stack([(poc == 0), (poc == 1)]).astype(np.uint8)
         thr = bench.synthetic_thresholds(S, 0, S + N)
-        dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=False, max_allele=1, device=0)
-        dm.generate(S + N, 0, thr, poc, 0)
+        missing = layout.endswith(":m")  # SITESxSAMPLES:packed:m = 1 % missing calls
+        layout = layout.split(":")[0]
+        dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=missing, max_allele=1, device=0)
+        dm.generate(S + N, 0, thr, poc, int(0.01 * (1 << 24)) if missing else 0)
         if layout == "packed":
             dm.pack(release_bytes=True)
         groups = device.Groups(dm, masks)
@@ -63,7 +65,7 @@ def main():
                     res.setdefault(name, []).append(ms.value / max(n.value, 1))
             os.environ.pop(var, None)
             a, b = min(res["unset"]), min(res["set"])
-            print(json.dumps({"switch": sys.argv[1], "sites": rows, "haplotypes": H, "layout": layout, "unset_ms": round(a, 4), "set_ms": round(b, 4),
+            print(json.dumps({"switch": sys.argv[1], "sites": rows, "haplotypes": H, "layout": layout + (" +1% missing" if missing else ""), "unset_ms": round(a, 4), "set_ms": round(b, 4),
                               "set_over_unset": round(b / a, 4), "all_unset": [round(x, 4) for x in res["unset"]], "all_set": [round(x, 4) for x in res["set"]]}), flush=True)
         del bufs, groups, dm
 
