@@ -831,10 +831,15 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH") && (!long_launch || getenv("FMH_PACKED_PREFETCH"));
     smem = (size_t)P * a.nvec_pad * 16;
     // the C4 shape defers its epilogues (sweep_kernel, kDefer): room for the parked counts of kDeferTiles tiles per wave
-    if (!general && P <= 2 && (lpr == 16 || lpr == 4) && (mode & kModeWc) == 0) {
+    if (!general && (lpr == 16 || lpr == 4) && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing)) {  // == defer_kernel<...>()
       const char* e = getenv("FMH_DEFER_TILES");  // read per call: measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
       a.defer_tiles = e && atoi(e) >= 1 && atoi(e) <= kDeferTiles ? atoi(e) : -1;
-      smem += defer_lds_bytes(P, mode, missing);
+      // room for the parked counts, as deep as leaves three workgroups per CU their LDS (wide rows: the mask image takes it, and a tile of
+      // megabytes has nothing to gain from deferral anyway; measured: 200 000 columns fell from 3 to 2 workgroups per CU, 0.45 -> 0.69 ms)
+      int depth = defer_depth_host(P, mode, missing);
+      while (depth > 1 && smem + defer_lds_bytes(P, mode, missing, depth) > (size_t)(160 * 1024) / 3 - 1024) depth /= 2;
+      a.defer_cap = depth;
+      smem += defer_lds_bytes(P, mode, missing, depth);
     }
     mask_mode = kMaskPacked;
     if (smem > lds_limit)

@@ -77,6 +77,7 @@ struct SweepArgs {
   int single_trip;        // packed cores: nvec_pad == lanes-per-row * unroll, i.e. one batch of loads covers a row
   int defer_tiles;        // kDefer kernels: count this many of a wave's tiles, parking the counts in LDS, then run their epilogues and stores back to back
                           // (1 = the undeferred order; -1 on the host side = let launch_one choose by the launch size)
+  int defer_cap;          // tiles a wave has LDS room to park (<= defer_depth; the host halves it until masks + parked counts leave three workgroups per CU)
   int n_groups;           // caller's group count (<= kernel P; padded groups are never reported)
   size_t row_begin;
   size_t row_count;
@@ -1100,15 +1101,18 @@ constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
-constexpr bool defer_kernel() { return MM == 3 /* kMaskPacked */ && !GENERAL && P <= 2 && (LPR == 16 || LPR == 4) && (MODE & kModeWc) == 0; }
+constexpr bool defer_kernel() { return MM == 3 /* kMaskPacked */ && !GENERAL && (LPR == 16 || LPR == 4) && (P <= 2 ? (MODE & kModeWc) == 0 || !MISSING : P == 4 && !MISSING); }
 template <int P, int MODE, bool MISSING>
 constexpr int defer_values() { return MISSING ? 2 * P + ((MODE & kModeWc) != 0 ? 1 : 0) : P; }
 template <int P, int MODE, bool MISSING>
 constexpr int defer_depth() { return defer_values<P, MODE, MISSING>() <= 2 ? kDeferTiles : kDeferTiles / 2; }
-inline size_t defer_lds_bytes(int P, int mode, bool missing) {
+inline int defer_depth_host(int P, int mode, bool missing) {
   const int k = missing ? 2 * P + ((mode & kModeWc) != 0 ? 1 : 0) : P;
-  const int d = k <= 2 ? kDeferTiles : kDeferTiles / 2;
-  return (size_t)kWavesPerBlock * d * 64 * k * 4;
+  return k <= 2 ? kDeferTiles : kDeferTiles / 2;
+}
+inline size_t defer_lds_bytes(int P, int mode, bool missing, int depth) {
+  const int k = missing ? 2 * P + ((mode & kModeWc) != 0 ? 1 : 0) : P;
+  return (size_t)kWavesPerBlock * depth * 64 * k * 4;
 }
 
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
@@ -1181,9 +1185,10 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       // (the only tile loop of these kernels: defer_tiles = 1 is the undeferred order, through the same code)
       constexpr int K = defer_values<P, MODE, MISSING>();   // parked u32 per site: alt per group (+ called per group, + called in all, with missing calls)
       constexpr int D = defer_depth<P, MODE, MISSING>();    // tiles a wave can park
-      const int ch = A.defer_tiles < 1 ? 1 : (A.defer_tiles > D ? D : A.defer_tiles);
+      const int cap = A.defer_cap < 1 ? 1 : (A.defer_cap > D ? D : A.defer_cap);
+      const int ch = A.defer_tiles < 1 ? 1 : (A.defer_tiles > cap ? cap : A.defer_tiles);
       const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-      uint32_t* park = reinterpret_cast<uint32_t*>(smem + (size_t)P * nvec_pad * 16) + (size_t)wave * D * 64 * K;
+      uint32_t* park = reinterpret_cast<uint32_t*>(smem + (size_t)P * nvec_pad * 16) + (size_t)wave * cap * 64 * K;
       for (size_t tile0 = (size_t)blockIdx.x * kWavesPerBlock + wave; tile0 < ntiles; tile0 += tile_stride * ch) {
 #pragma unroll 1
         for (int b = 0; b < ch; ++b) {  // counts

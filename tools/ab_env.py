@@ -41,10 +41,27 @@ def main():
         dm.generate(S + N, 0, thr, poc, int(0.01 * (1 << 24)) if missing else 0)
         if layout == "packed":
             dm.pack(release_bytes=True)
+        kind = os.environ.get("AB_KIND", "hudson")  # hudson (two groups) | wc4 (Weir & Cockerham, four groups) | sum4 (summaries, four groups)
+        if kind != "hudson":
+            poc = (np.arange(H) * 4 // H).astype(np.uint8)
+            masks = np.stack([(poc == p) for p in range(4)]).astype(np.uint8)
         groups = device.Groups(dm, masks)
-        bufs = [device.DeviceBuffer(0, 8 * S) for _ in range(7)]
-        sites = _abi.HudsonSites(None, *(b.ptr for b in bufs))
-        totals = _abi.HudsonTotals()
+        if kind == "hudson":
+            bufs = [device.DeviceBuffer(0, 8 * S) for _ in range(7)]
+            sites = _abi.HudsonSites(None, *(b.ptr for b in bufs))
+            totals = _abi.HudsonTotals()
+            def sweep(rows):
+                _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, rows, _abi.FORMULA_DENSE, C.byref(sites), C.byref(totals), None))
+        elif kind == "wc4":
+            bufs = [device.DeviceBuffer(0, 8 * 7 * S), device.DeviceBuffer(0, 8 * 7 * S), device.DeviceBuffer(0, 7 * S), device.DeviceBuffer(0, 4 * 4 * S)]
+            totals = _abi.WcTotals()
+            def sweep(rows):
+                _abi.check(lib.fmh_wc_sweep(dm._h, groups._h, 0, rows, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, C.byref(totals), None))
+        else:
+            bufs = [device.DeviceBuffer(0, 4 * 4 * S), device.DeviceBuffer(0, 4 * 4 * S)]
+            totals = (_abi.PopTotals * 4)()
+            def sweep(rows):
+                _abi.check(lib.fmh_population_summaries(dm._h, groups._h, 0, rows, 0, bufs[0].ptr, bufs[1].ptr, totals, None))
         for rows in (S, S // 2, S // 4, S // 8, S // 10, S // 16):
             res = {}
             for rep in range(3):
@@ -54,20 +71,20 @@ def main():
                     else:
                         os.environ.pop(var, None)
                     for _ in range(3):
-                        _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, rows, _abi.FORMULA_DENSE, C.byref(sites), C.byref(totals), None))
+                        sweep(rows)
                     lib.fmh_timing_enable(1)
                     lib.fmh_timing_reset()
                     for _ in range(20):
-                        _abi.check(lib.fmh_hudson_sweep(dm._h, groups._h, 0, rows, _abi.FORMULA_DENSE, C.byref(sites), C.byref(totals), None))
+                        sweep(rows)
                     ms, n = C.c_double(), C.c_uint64()
                     lib.fmh_timing_read(C.byref(ms), C.byref(n))
                     lib.fmh_timing_enable(0)
                     res.setdefault(name, []).append(ms.value / max(n.value, 1))
             os.environ.pop(var, None)
             a, b = min(res["unset"]), min(res["set"])
-            print(json.dumps({"switch": sys.argv[1], "sites": rows, "haplotypes": H, "layout": layout + (" +1% missing" if missing else ""), "unset_ms": round(a, 4), "set_ms": round(b, 4),
+            print(json.dumps({"switch": sys.argv[1], "kind": kind, "sites": rows, "haplotypes": H, "layout": layout + (" +1% missing" if missing else ""), "unset_ms": round(a, 4), "set_ms": round(b, 4),
                               "set_over_unset": round(b / a, 4), "all_unset": [round(x, 4) for x in res["unset"]], "all_set": [round(x, 4) for x in res["set"]]}), flush=True)
-        del bufs, groups, dm
+        del bufs, groups, dm, sweep
 
 
 if __name__ == "__main__":
