@@ -1173,12 +1173,15 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
   const size_t ntiles = (A.row_count + kTileRows - 1) / kTileRows;
   const size_t tile_stride = (size_t)gridDim.x * kWavesPerBlock;
 
-  // Deferred epilogues (biallelic, nothing missing, one or two groups, sixteen-lane rows - the C4 shape).  A wave counts kDeferTiles of its
-  // tiles in a row, parking the per-site counts in LDS (8 bytes per site), and only then runs their epilogues: its track stores leave in one
-  // burst of kDeferTiles x 7 instructions instead of 7 after every tile.  The tiles, their order per lane and every per-site operation are
-  // unchanged (same bits, same regional sums); only WHEN a wave writes changes.  Measured with the do-nothing kernel of
-  // tools/microbench/store_bursts.hip (modes 20 / 21: the sweep's reads with one row in flight per lane group, stores per tile vs per eight
-  // tiles): 1.256 -> 1.150 ms at 16 waves per CU, 1.415 -> 1.322 ms at 12.
+  // Deferred epilogues (packed biallelic kernels: one or two groups with or without missing calls, four groups without; defer_kernel()).
+  // A wave counts `defer_tiles` of its tiles in a row, parking the per-site counts in LDS (4 bytes per site and value), and only then runs
+  // their epilogues: its track stores leave in one burst of defer_tiles x 7 instructions instead of 7 after every tile.  The tiles, their
+  // order per lane and every per-site operation are unchanged (same bits, same regional sums); only WHEN a wave writes changes.  Found with the
+  // do-nothing kernel of tools/microbench/store_bursts.hip (modes 20 / 21: the sweep's reads with one row in flight per lane group, stores per
+  // tile vs per eight tiles: 1.256 -> 1.150 ms at 16 waves per CU) after larger CONTIGUOUS bursts had turned out not to be the point (modes 2,
+  // 3, 18 vs 19).  C4 sweep, same process: 1.289 ms undeferred, 1.175 ms sixteen tiles deep (DESIGN.md section 3 "Deferred epilogues").
+  // The prefetching row loop is kept on four-lane rows only: its variants for sixteen-lane rows cost this loop structure 40 VGPRs (two waves
+  // per SIMD instead of three) for a path that long launches had stopped taking anyway.
   constexpr bool kDefer = defer_kernel<P, MODE, MISSING, GENERAL, MM, LPR>();
   if constexpr (kDefer) {
     {

@@ -59,9 +59,11 @@ mkdir -p $R/build/micro
 for wg in 3 4; do $R/build/micro/store_bursts 10000000 7 640 $wg >> $O/store_bursts_packed_row_width.jsonl; done
 $R/build/micro/store_bursts 10000000 7 5008 4 >> $O/store_bursts_u8_row_width.jsonl
 step "same-process A/B of the per-call switches at the C4 shape (tools/ab_env.py: unset vs set, one allocation, best of 3 x 20 launches)"
-for sw in FMH_PACKED_PREFETCH=1 FMH_PACKED_NO_PREFETCH=1 FMH_PACKED_UNROLL=4 FMH_PACKED_UNROLL=2 FMH_PACKED_LPR=4 FMH_GRID_PER_CU=2 FMH_GRID_PER_CU=4 FMH_GRID_PER_CU=6; do
+for sw in FMH_DEFER_TILES=1 FMH_DEFER_TILES=2 FMH_DEFER_TILES=4 FMH_DEFER_TILES=8 FMH_DEFER_TILES=12 FMH_DEFER_TILES=16 FMH_PACKED_UNROLL=4 FMH_PACKED_UNROLL=2 FMH_PACKED_LPR=4 FMH_GRID_PER_CU=2 FMH_GRID_PER_CU=4 FMH_GRID_PER_CU=6; do
   python3 $R/tools/ab_env.py $sw 10000000x2500 2>/dev/null | grep '^{' >> $O/ab_switches_c4_shape.jsonl
 done
+python3 $R/tools/ab_env.py FMH_DEFER_TILES=1 10000000x500 5000000x1250 5000000x2500:packed:m 2000000x5000 2>/dev/null | grep '^{' >> $O/ab_deferred_epilogues_other_shapes.jsonl
+for k in wc4 sum4; do AB_KIND=$k python3 $R/tools/ab_env.py FMH_DEFER_TILES=1 5000000x1250 2>/dev/null | grep '^{' >> $O/ab_deferred_epilogues_other_shapes.jsonl; done
 python3 $R/tools/ab_env.py FMH_PACKED_NO_PREFETCH=1 5000000x1250 4000000x500 2>/dev/null | grep '^{' >> $O/ab_prefetch_four_lane_rows.jsonl
 step "other configs"; python3 $R/tools/measure_configs.py C2 C2x10 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
 MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs_u8_layout.jsonl
