@@ -830,17 +830,6 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     const bool long_launch = lpr == 16 && P <= 2 && a.row_count > (size_t)ctx.cus * 12 * kTileRows * 5;
     a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH") && (!long_launch || getenv("FMH_PACKED_PREFETCH"));
     smem = (size_t)P * a.nvec_pad * 16;
-    // the C4 shape defers its epilogues (sweep_kernel, kDefer): room for the parked counts of kDeferTiles tiles per wave
-    if (!general && (lpr == 16 || lpr == 4) && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing)) {  // == defer_kernel<...>()
-      const char* e = getenv("FMH_DEFER_TILES");  // read per call: measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
-      a.defer_tiles = e && atoi(e) >= 1 && atoi(e) <= kDeferTiles ? atoi(e) : -1;
-      // room for the parked counts, as deep as leaves three workgroups per CU their LDS (wide rows: the mask image takes it, and a tile of
-      // megabytes has nothing to gain from deferral anyway; measured: 200 000 columns fell from 3 to 2 workgroups per CU, 0.45 -> 0.69 ms)
-      int depth = defer_depth_host(P, mode, missing);
-      while (depth > 1 && smem + defer_lds_bytes(P, mode, missing, depth) > (size_t)(160 * 1024) / 3 - 1024) depth /= 2;
-      a.defer_cap = depth;
-      smem += defer_lds_bytes(P, mode, missing, depth);
-    }
     mask_mode = kMaskPacked;
     if (smem > lds_limit)
       return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep fewer groups at a time on rows this wide", P, m->columns);
@@ -868,6 +857,20 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     const bool global_ok = P <= 2 && mode != kModeWc;
     if (want == kMaskLdsBits && mask_mode == kMaskLdsBytes) { smem = (size_t)P * a.nvec_pad * 2; mask_mode = kMaskLdsBits; }
     if (want == kMaskGlobalBytes && global_ok) { smem = 0; mask_mode = kMaskGlobalBytes; }
+  }
+  // Deferred epilogues (sweep_kernel, defer_kernel()): room behind the mask image for the counts a wave parks, as deep as leaves three workgroups
+  // per CU their LDS (wide rows: the mask image takes it, and a tile of megabytes has nothing to gain from deferral anyway; measured: 200 000
+  // columns fell from 3 to 2 workgroups per CU, 0.45 -> 0.69 ms, before the cap).  The deferring kernels have no other tile loop, so one tile's
+  // room is always added.
+  if (!mfma && !general && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing && mask_mode == kMaskPacked)) {  // == defer_kernel<...>()
+    const char* e = getenv("FMH_DEFER_TILES");  // read per call: measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
+    a.defer_tiles = e && atoi(e) >= 1 && atoi(e) <= kDeferTiles ? atoi(e) : -1;
+    smem = round_up(smem, 16);
+    int depth = defer_depth_host(P, mode, missing);
+    while (depth > 1 && smem + defer_lds_bytes(P, mode, missing, depth) > (size_t)(160 * 1024) / 3 - 1024) depth /= 2;
+    a.defer_cap = depth;
+    a.defer_offset = (uint32_t)smem;
+    smem += defer_lds_bytes(P, mode, missing, depth);
   }
   int grid = 0;
   // argument checks shared by every route, then the route's own launcher (sweep_*.hip)

@@ -77,6 +77,7 @@ struct SweepArgs {
   int single_trip;        // packed cores: nvec_pad == lanes-per-row * unroll, i.e. one batch of loads covers a row
   int defer_tiles;        // kDefer kernels: count this many of a wave's tiles, parking the counts in LDS, then run their epilogues and stores back to back
                           // (1 = the undeferred order; -1 on the host side = let launch_one choose by the launch size)
+  uint32_t defer_offset;  // byte offset of the parked counts in dynamic LDS (behind the mask image, 16-byte aligned)
   int defer_cap;          // tiles a wave has LDS room to park (<= defer_depth; the host halves it until masks + parked counts leave three workgroups per CU)
   int n_groups;           // caller's group count (<= kernel P; padded groups are never reported)
   size_t row_begin;
@@ -1101,7 +1102,9 @@ constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
-constexpr bool defer_kernel() { return MM == 3 /* kMaskPacked */ && !GENERAL && (LPR == 16 || LPR == 4) && (P <= 2 ? (MODE & kModeWc) == 0 || !MISSING : P == 4 && !MISSING); }
+constexpr bool defer_kernel() {
+  return !GENERAL && (LPR == 16 || LPR == 4) && (P <= 2 ? (MODE & kModeWc) == 0 || !MISSING : P == 4 && !MISSING && MM == 3 /* kMaskPacked */);
+}
 template <int P, int MODE, bool MISSING>
 constexpr int defer_values() { return MISSING ? 2 * P + ((MODE & kModeWc) != 0 ? 1 : 0) : P; }
 template <int P, int MODE, bool MISSING>
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
       const int cap = A.defer_cap < 1 ? 1 : (A.defer_cap > D ? D : A.defer_cap);
       const int ch = A.defer_tiles < 1 ? 1 : (A.defer_tiles > cap ? cap : A.defer_tiles);
       const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-      uint32_t* park = reinterpret_cast<uint32_t*>(smem + (size_t)P * nvec_pad * 16) + (size_t)wave * cap * 64 * K;
+      uint32_t* park = reinterpret_cast<uint32_t*>(smem + A.defer_offset) + (size_t)wave * cap * 64 * K;
       for (size_t tile0 = (size_t)blockIdx.x * kWavesPerBlock + wave; tile0 < ntiles; tile0 += tile_stride * ch) {
 #pragma unroll 1
         for (int b = 0; b < ch; ++b) {  // counts
@@ -1202,7 +1205,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
 #pragma unroll
           for (int p = 0; p < P; ++p) { alt_mine[p] = 0; n_mine[p] = 0; }
           bool counted = false;
-          if constexpr (!MISSING && LPR != 16) {
+          if constexpr (!MISSING && LPR != 16 && MM == kMaskPacked) {
             if (A.single_trip) {  // four-lane rows keep the prefetching row loop (level or 1-6 % ahead at every launch size)
               if (A.unroll == 5) tile_rows_packed_prefetch<P, 5, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
               else if (A.unroll == 3) tile_rows_packed_prefetch<P, 3, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
@@ -1219,7 +1222,13 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
               const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
               uint32_t n[P], n_all, aor, sp[P][1];
 #define FMH_COUNT_DEFER(UV) count_row_packed<P, MISSING, NEED_ALL, 1, UV, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, bits_ptr, gl, n, n_all, aor, sp)
-              if constexpr (LPR != 16) {
+              if constexpr (MM != kMaskPacked) {  // u8 rows: the dot4 core
+                uint32_t alt[P];
+                if (A.unroll == 8) count_row_biallelic<P, MISSING, NEED_ALL, 8, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+                else count_row_biallelic<P, MISSING, NEED_ALL, 4, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, gl, alt, n, n_all);
+#pragma unroll
+                for (int p = 0; p < P; ++p) sp[p][0] = alt[p];
+              } else if constexpr (LPR != 16) {
                 if (A.unroll == 5) FMH_COUNT_DEFER(5);
                 else if (A.unroll == 3) FMH_COUNT_DEFER(3);
                 else if (A.unroll == 2) FMH_COUNT_DEFER(2);

@@ -12,10 +12,6 @@ cd /tmp
 export TMPDIR=/tmp
 step() { echo "[$(date +%H:%M:%S)] $*"; }
 
-step "bench.py (C4, N = 1)"; python3 $R/bench.py --steps 20 --warmup 3 2> $O/c4_bench.err | grep '^{' > $O/c4_bench.json
-step "kernel trace of the same command"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -o c4 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline 2> $O/c4_trace.log | grep '^{' > $O/c4_bench_under_rocprof.json
-python3 $R/tools/summarize_rocprof.py trace $O/c4_trace $O/c4_kernel_stats.csv
 step "pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_pmc_fetch -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_fetch.log
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch $O/c4_pmc_fetch_summary.csv
 step "pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write.log
@@ -47,6 +43,11 @@ for layout, suffix, mode, b_site in (("packed", "", 3, 681), ("bytes", "_u8_layo
         "algorithmic_bytes": b_site * 10_000_000}
 json.dump(out, open(o + "/pmc_traffic.json", "w"), indent=1)
 PY
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json   # on this box's copy of the repo: the bench lines below report the traffic just measured
+step "bench.py (C4, N = 1)"; python3 $R/bench.py --steps 20 --warmup 3 2> $O/c4_bench.err | grep '^{' > $O/c4_bench.json
+step "kernel trace of the same command"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -o c4 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline 2> $O/c4_trace.log | grep '^{' > $O/c4_bench_under_rocprof.json
+python3 $R/tools/summarize_rocprof.py trace $O/c4_trace $O/c4_kernel_stats.csv
 step "strong-scaling step sizes on one GPU (the per-rank slab of 1, 2, 4, 8 GPUs): blocking fmh_hudson_sweep, the pipelined begin / end path on a local communicator (bench's N = 1 default) and on a one-rank RCCL group"
 for s in 10000000 5000000 2500000 1250000; do
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --sync-steps 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_blocking.jsonl
