@@ -16,8 +16,7 @@ step "pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_p
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch $O/c4_pmc_fetch_summary.csv
 step "pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write.log
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_write $O/c4_pmc_write_summary.csv
-step "the u8-row layout: bench, FETCH_SIZE, WRITE_SIZE"
-python3 $R/bench.py --steps 10 --warmup 2 --layout bytes --no-cpu-baseline 2>/dev/null | grep '^{' > $O/c4_bench_u8_layout.json
+step "the u8-row layout: FETCH_SIZE, WRITE_SIZE (its bench line follows the counters)"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_pmc_fetch8 -o f -- python3 $R/bench.py --steps 3 --warmup 1 --layout bytes --no-cpu-baseline > /dev/null 2> $O/c4_pmc_fetch8.log
 python3 $R/tools/summarize_rocprof.py pmc $O/c4_pmc_fetch8 $O/c4_pmc_fetch_summary_u8_layout.csv
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_pmc_write8 -o w -- python3 $R/bench.py --steps 3 --warmup 1 --layout bytes --no-cpu-baseline > /dev/null 2> $O/c4_pmc_write8.log
@@ -48,6 +47,7 @@ step "bench.py (C4, N = 1)"; python3 $R/bench.py --steps 20 --warmup 3 2> $O/c4_
 step "kernel trace of the same command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -o c4 -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline 2> $O/c4_trace.log | grep '^{' > $O/c4_bench_under_rocprof.json
 python3 $R/tools/summarize_rocprof.py trace $O/c4_trace $O/c4_kernel_stats.csv
+python3 $R/bench.py --steps 10 --warmup 2 --layout bytes --no-cpu-baseline 2>/dev/null | grep '^{' > $O/c4_bench_u8_layout.json
 step "strong-scaling step sizes on one GPU (the per-rank slab of 1, 2, 4, 8 GPUs): blocking fmh_hudson_sweep, the pipelined begin / end path on a local communicator (bench's N = 1 default) and on a one-rank RCCL group"
 for s in 10000000 5000000 2500000 1250000; do
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --sync-steps 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_blocking.jsonl
