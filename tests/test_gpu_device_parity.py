@@ -369,6 +369,57 @@ def test_mask_routes_agree(dev, monkeypatch):
         monkeypatch.delenv("FMH_MASK_MODE", raising=False)
 
 
+def test_deferred_epilogues_are_the_same_bits(dev, monkeypatch):
+    """The biallelic kernels with one, two (and, packed, four) groups count several of a wave's tiles before they run those tiles' epilogues
+    (DESIGN.md section 3 "Deferred epilogues"; depth chosen per launch, FMH_DEFER_TILES forces it).  The tiles a wave takes and their order
+    are the same at every depth, so every per-site value AND every regional total must be the same bits as the undeferred order - checked
+    here on ragged matrices with the grid held to a few workgroups (FMH_GRID_BLOCKS) so that a wave really sweeps dozens of tiles, on packed
+    and u8 rows, four- and sixteen-lane rows, with and without missing calls, and against the oracle's counts."""
+    rng = np.random.default_rng(1606)
+    cases = ((5000, 450, 0.0, "packed"), (4097, 3000, 0.0, "packed"), (3001, 2700, 0.02, "packed"), (2500, 600, 0.03, "packed"),
+             (3333, 640, 0.0, "bytes"), (2049, 700, 0.05, "bytes"))
+    for (S, N, p_missing, layout) in cases:
+        m = H.random_dense_matrix(rng, S, N, 2, 1, p_missing)
+        if layout == "bytes":
+            monkeypatch.setenv("FMH_LAYOUT", "bytes")
+        dm = upload(dev, m)
+        monkeypatch.delenv("FMH_LAYOUT", raising=False)
+        cut = N // 3
+        lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, N - 2))]
+        quarters = [H.haps_for_samples(range(i, N, 4)) for i in range(4)]
+        g2, g1, g4 = (dev.Groups.from_haplotype_lists(dm, x) for x in (lists, lists[:1], quarters))
+
+        def run():
+            return (dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE), dev.diversity_sites(dm, g1), dev.population_summaries(dm, g2, dev.FORMULA_SUMMARY),
+                    dev.population_summaries(dm, g4, dev.FORMULA_SUMMARY), dev.wc_sweep(dm, g4), dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE, 7, S - 11))
+
+        for blocks in ("1", "3"):
+            monkeypatch.setenv("FMH_GRID_BLOCKS", blocks)
+            monkeypatch.setenv("FMH_DEFER_TILES", "1")
+            base = run()
+            for depth in ("2", "5", "16"):
+                monkeypatch.setenv("FMH_DEFER_TILES", depth)
+                got = run()
+                what = f"{S}x{N} {layout} missing {p_missing} blocks {blocks} depth {depth}"
+                for i in (0, 5):
+                    for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+                        H.assert_bits_equal(got[i].sites[k], base[i].sites[k], k + " " + what)
+                    assert np.array_equal(got[i].sites["alt"], base[i].sites["alt"]) and np.array_equal(got[i].sites["called"], base[i].sites["called"]), what
+                    assert got[i].totals == base[i].totals and got[i].pop == base[i].pop, what
+                H.assert_bits_equal(got[1].pi, base[1].pi, "site pi " + what)
+                H.assert_bits_equal(got[1].theta, base[1].theta, "site theta " + what)
+                assert got[1].totals == base[1].totals, what
+                for i in (2, 3):
+                    assert np.array_equal(got[i].alt, base[i].alt) and np.array_equal(got[i].called, base[i].called) and got[i].totals == base[i].totals, what
+                assert np.array_equal(got[4].a, base[4].a, equal_nan=True) and np.array_equal(got[4].b, base[4].b, equal_nan=True), what
+                assert np.array_equal(got[4].state, base[4].state) and np.array_equal(got[4].sum_a, base[4].sum_a) and np.array_equal(got[4].sum_b, base[4].sum_b), what
+            monkeypatch.delenv("FMH_DEFER_TILES")
+        monkeypatch.delenv("FMH_GRID_BLOCKS")
+        exp = R.build_dense_population_summary(m, lists[0])
+        assert np.array_equal(base[0].sites["alt"][0], np.array(exp.alt_counts, dtype=np.uint32))
+        assert np.array_equal(base[0].sites["called"][0], np.array(exp.called_counts, dtype=np.uint32))
+
+
 def test_matrix_core_counting_route_agrees(dev, monkeypatch):
     """BASELINE config C5: the counts as an int8 MFMA contraction (FMH_COUNTS_MFMA, u8 rows, biallelic, nothing missing).  Same
     integers as the dot4 route, the same epilogue code after them: every track and total must be the same bits - and against
