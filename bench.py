@@ -168,6 +168,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--timing-sample", type=int, default=4,
+                    help="bracket every n-th sweep of the timed region with HIP events (roofline.achieved comes from their average); the two event "
+                         "records cost a few microseconds of stream time per timed launch, which is 2-3 %% of a 1.25 M-site step")
     ap.add_argument("--sites", type=int, default=10_000_000,
                     help="sites of the cohort: the WHOLE cohort with --scaling strong (split over the ranks), per GPU with --scaling weak")
     ap.add_argument("--haplotypes", type=int, default=5000)
@@ -370,7 +373,7 @@ def main() -> int:
         for _ in range(args.warmup):
             step()
         fence()
-        lib.fmh_timing_enable(1)
+        lib.fmh_timing_enable(max(1, args.timing_sample))  # HIP events around every n-th sweep of the timed region
         lib.fmh_timing_reset()
         t0 = time.perf_counter()
         for _ in range(args.steps):

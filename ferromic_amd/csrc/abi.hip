@@ -637,7 +637,8 @@ extern "C" int fmh_groups_sizes(const fmh_groups* g, int* n_groups, uint64_t* h_
 // ------------------------------------------------------------------------------------------------
 static Workspace g_ws[64];
 static std::mutex g_ws_mutex;
-static std::atomic<bool> g_timing{false};
+static std::atomic<int> g_timing{0};             // 0 = off, n = time every n-th sweep (fmh_timing_enable)
+static std::atomic<uint64_t> g_timing_seq{0};
 static double g_timing_ms = 0.0;
 static uint64_t g_timing_launches = 0;
 
@@ -706,7 +707,7 @@ struct LeaseHolder {
   }
 };
 
-extern "C" int fmh_timing_enable(int on) { g_timing = on != 0; return FMH_OK; }
+extern "C" int fmh_timing_enable(int on) { g_timing = on < 0 ? 0 : on; return FMH_OK; }
 extern "C" int fmh_timing_reset(void) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   g_timing_ms = 0.0;
@@ -890,7 +891,13 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   else if (mask_mode == kMaskLdsBits) rc = launch_sweep_bits(P, mode, missing, general, a, smem, st, ctx, &grid);
   else rc = launch_sweep_bytes(P, mode, missing, general, a, smem, st, ctx, &grid);
   FMH_TRY(rc);
-  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, b.part_f64, b.part_u64, grid, b.out_f64, b.out_u64);
+  hipStream_t fin = st;
+  if (b.finalize_stream && b.swept) {
+    HIP_TRY(hipEventRecord(b.swept, st));
+    HIP_TRY(hipStreamWaitEvent(b.finalize_stream, b.swept, 0));
+    fin = b.finalize_stream;
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, fin, b.part_f64, b.part_u64, grid, b.out_f64, b.out_u64);
   HIP_TRY(hipGetLastError());
   *launched = true;
   return FMH_OK;
@@ -901,7 +908,13 @@ void fmhi::timing_add(double ms) {
   g_timing_ms += ms;
   g_timing_launches += 1;
 }
-bool fmhi::timing_enabled() { return g_timing.load(); }
+// one decision per sweep: with fmh_timing_enable(n), n > 1, every n-th sweep is bracketed by events (the two event records cost a few
+// microseconds of stream time each, which matters next to a 0.16 ms kernel)
+bool fmhi::timing_enabled() {
+  const int n = g_timing.load();
+  if (n <= 0) return false;
+  return n == 1 || g_timing_seq.fetch_add(1) % (uint64_t)n == 0;
+}
 
 static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, void* stream, SweepResult* res) {
   if (!m || !g) return fail(FMH_ERR_INVALID, "matrix or groups is NULL");
@@ -915,7 +928,7 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   // The caller's stream, or - for the NULL stream - the lease's own (blocking: ordered against the legacy default stream like the NULL
   // stream itself, but not against the other leases), so that sweeps of different host threads (run_vcf's region workers) overlap on the device.
   hipStream_t st = stream ? (hipStream_t)stream : l->stream;
-  const bool timing = g_timing.load();  // one snapshot per sweep: another thread may flip the switch while this one runs
+  const bool timing = timing_enabled();  // one snapshot per sweep: another thread may flip the switch while this one runs
   const double* harmonic = nullptr;
   if (mode & kModeDiversity) {
     std::lock_guard<std::mutex> grow(w->in_use);

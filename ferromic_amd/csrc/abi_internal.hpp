@@ -120,6 +120,10 @@ struct SweepBuffers {
   unsigned long long* part_u64;
   double* out_f64;
   unsigned long long* out_u64;
+  // optional: run finalize_kernel on another stream, ordered behind the sweep by this event - the pipelined sharded sweeps put it on the
+  // communicator's stream, so that the next window's sweep follows this one's without the finalize launch and its two kernel boundaries between them
+  hipStream_t finalize_stream = nullptr;
+  hipEvent_t swept = nullptr;
 };
 }  // namespace fmhi
 struct fmh_matrix;

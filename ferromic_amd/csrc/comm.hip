@@ -390,17 +390,19 @@ extern "C" int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, 
   }
   s.timed = timing_enabled();
   const LaunchCtx ctx{c->cus, c->max_grid, s.ev0, s.ev1, s.timed};
-  const SweepBuffers bufs{s.part_f64, s.part_u64, s.out_f64, s.out_u64};
+  // the finalize kernel goes to the communicator's stream (behind the sweep's event): on the caller's stream the next window's sweep follows
+  // this one directly
+  const SweepBuffers bufs{s.part_f64, s.part_u64, s.out_f64, s.out_u64, c->stream, s.swept};
   s.launched = false;
   FMH_TRY(enqueue_sweep(m, g, kModeSummary | kModeHudson, a, st, ctx, bufs, nullptr, &s.launched));
   if (!s.launched) {  // an empty slab still takes part in the collective, with zeros
     HIP_TRY(hipMemsetAsync(s.out_f64, 0, kMaxF64 * 8, st));
     HIP_TRY(hipMemsetAsync(s.out_u64, 0, kMaxU64 * 8, st));
+    HIP_TRY(hipEventRecord(s.swept, st));
+    HIP_TRY(hipStreamWaitEvent(c->stream, s.swept, 0));
   }
   s.sizes[0] = g->sizes[0];
   s.sizes[1] = g->sizes[1];
-  HIP_TRY(hipEventRecord(s.swept, st));
-  HIP_TRY(hipStreamWaitEvent(c->stream, s.swept, 0));
   if (c->transport == 0) FMH_TRY(rccl_reduce_on_stream(c, s.out_f64, kMaxF64, s.out_u64, kMaxU64));
   HIP_TRY(hipMemcpyAsync(s.h_f64, s.out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(s.h_u64, s.out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, c->stream));

@@ -360,8 +360,9 @@ int fmh_wc_totals_unpack(fmh_wc_totals* t, int n_groups, const double* h_f64, co
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* Accumulated HIP-event time (ms) and launch count of the dominant sweep kernel since the last
- * reset, measured on the stream the kernel ran on.  Timing is off unless enabled (events add
- * ~2 us per launch). */
+ * reset, measured on the stream the kernel ran on.  Timing is off unless enabled: the two event
+ * records of a timed launch cost a few microseconds of stream time.  fmh_timing_enable(n) with
+ * n > 1 times every n-th sweep only (the launch count returned is that of the timed ones). */
 int fmh_timing_enable(int on);
 int fmh_timing_reset(void);
 int fmh_timing_read(double* h_total_ms, uint64_t* h_launches);
