@@ -824,12 +824,11 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.unroll = best_u;
     for (int k = 0; k < nus; ++k) if (env_punroll == us[k]) a.unroll = env_punroll;
     a.nvec_pad = (uint32_t)round_up(m->pvec, (size_t)lpr * a.unroll);
-    // The prefetching row loop (tile_rows_packed_prefetch) is taken when one batch of loads covers a row - except on sixteen-lane rows
-    // once a wave sweeps more than about five tiles: same-process A/B on two boxes (tools/ab_env.py FMH_PACKED_NO_PREFETCH=1, 5 000 haplotypes,
-    // two groups) has it 2.4-2.9 % ahead at 625 k sites, level at 1 M and 0.6-2.4 % behind from 1.25 M to 10 M sites; on four-lane rows
-    // (1 000 and 2 500 haplotypes) it is level or 1-6 % ahead at every size.  FMH_PACKED_PREFETCH=1 / FMH_PACKED_NO_PREFETCH=1 force it.
-    const bool long_launch = lpr == 16 && P <= 2 && a.row_count > (size_t)ctx.cus * 12 * kTileRows * 5;
-    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH") && (!long_launch || getenv("FMH_PACKED_PREFETCH"));
+    // The prefetching row loop (tile_rows_packed_prefetch) is taken when one batch of loads covers a row.  Same-process A/Bs (tools/ab_env.py
+    // FMH_PACKED_NO_PREFETCH=1): on four-lane rows (1 000 and 2 500 haplotypes) it is level or 1-6 % ahead at every launch size; on sixteen-lane
+    // rows with two groups (5 000 haplotypes) it was 2.4-2.9 % ahead at 625 k sites, level at 1 M and 0.6-2.4 % behind from 1.25 M to 10 M sites -
+    // those kernels (one and two groups, sixteen lanes) have since dropped it altogether for the deferred-epilogue loop (sweep_kernel, defer_kernel()).
+    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH");
     smem = (size_t)P * a.nvec_pad * 16;
     mask_mode = kMaskPacked;
     if (smem > lds_limit)
