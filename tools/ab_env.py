@@ -56,7 +56,10 @@ def main():
             bufs = [device.DeviceBuffer(0, 8 * 7 * S), device.DeviceBuffer(0, 8 * 7 * S), device.DeviceBuffer(0, 7 * S), device.DeviceBuffer(0, 4 * 4 * S)]
             totals = _abi.WcTotals()
             def sweep(rows):
-                _abi.check(lib.fmh_wc_sweep(dm._h, groups._h, 0, rows, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, C.byref(totals), None))
+                # tool-level switches (not library ones): TOOL_WC_NO_STATE / TOOL_WC_NO_AB / TOOL_WC_NO_COUNTS drop one family of per-site tracks
+                e = os.environ
+                _abi.check(lib.fmh_wc_sweep(dm._h, groups._h, 0, rows, None if e.get("TOOL_WC_NO_AB") else bufs[0].ptr, None if e.get("TOOL_WC_NO_AB") else bufs[1].ptr,
+                                            None if e.get("TOOL_WC_NO_STATE") else bufs[2].ptr, None if e.get("TOOL_WC_NO_COUNTS") else bufs[3].ptr, C.byref(totals), None))
         else:
             bufs = [device.DeviceBuffer(0, 4 * 4 * S), device.DeviceBuffer(0, 4 * 4 * S)]
             totals = (_abi.PopTotals * 4)()
