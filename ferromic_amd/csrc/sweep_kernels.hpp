@@ -1105,7 +1105,7 @@ template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
 constexpr bool defer_kernel() {
   // sixteen-lane rows only: on four-lane rows (at most 4 096 columns) deferral was level or behind at 1 000 haplotypes and 3-7 % ahead on long
   // launches at 2 500, while the restructured loop itself cost the C2 kernel (1 M x 1 000) 7 % - those kernels keep the plain tile loop
-  return !GENERAL && LPR == 16 && (P <= 2 ? (MODE & kModeWc) == 0 || !MISSING : P == 4 && !MISSING && MM == 3 /* kMaskPacked */);
+  return !GENERAL && LPR == 16 && (P <= 2 ? (MODE & kModeWc) == 0 || !MISSING : P == 4 && !MISSING);
 }
 template <int P, int MODE, bool MISSING>
 constexpr int defer_values() { return MISSING ? 2 * P + ((MODE & kModeWc) != 0 ? 1 : 0) : P; }

@@ -102,3 +102,19 @@ def test_falsta_records_have_the_reference_shape(exemplars, printed):
         toks = line.split(",")
         assert len(toks) == 8 and {shape(t) for t in toks} <= {"0", "NA", "d.dddddd", "Infinity", "-Infinity"}
     assert flines[6] == "NA,1.000000,-0.500000,NA,NA,NA,NA,NA"  # FST tracks default to NA (process.rs:3842-3856)
+
+
+def test_bench_tracks_diagnostic_runs_without_a_gpu():
+    """`run_vcf --bench_tracks`: formats and deflates the 17 tracks of a made-up 15-kb region 500 times on one thread (what the writers cost per
+    small region) - no inputs, no GPU.  Checked here: it runs, reports 17 members and a sane size."""
+    import re
+    import subprocess
+
+    from tests.test_gpu_run_vcf import BIN
+
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    res = subprocess.run([BIN, "--bench_tracks"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-1000:]
+    m = re.search(r"tracks of one region: ([0-9.]+) ms, (\d+) members, (\d+) bytes", res.stdout)
+    assert m and int(m.group(2)) == 17 and 1000 < int(m.group(3)) < 200000 and float(m.group(1)) < 50.0, res.stdout
