@@ -386,7 +386,7 @@ def main() -> int:
         elapsed = max_over_ranks(elapsed)
         avg_kernel_s = (kernel_ms.value / 1e3) / max(launches.value, 1)
         return {"scaling": scaling, "total_sites": total, "slab": (begin, end), "S": S, "seed": seed, "gen_s": gen_s, "pack_s": pack_s,
-                "elapsed": elapsed, "avg_kernel_s": avg_kernel_s, "totals": state["totals"], "u8_reference": u8_reference,
+                "elapsed": elapsed, "avg_kernel_s": avg_kernel_s, "timed_launches": int(launches.value), "totals": state["totals"], "u8_reference": u8_reference,
                 "bufs": bufs, "thr": thr, "dm": dm, "groups": groups}
 
     first = run_mode(args.scaling, True)
@@ -396,7 +396,7 @@ def main() -> int:
     secondary = None
     if world > 1 and not args.no_secondary:
         # release the primary cohort, then the other mode on the same ranks
-        keep = {k: first[k] for k in ("scaling", "total_sites", "elapsed", "avg_kernel_s", "S", "seed", "gen_s", "pack_s", "slab")}
+        keep = {k: first[k] for k in ("scaling", "total_sites", "elapsed", "avg_kernel_s", "timed_launches", "S", "seed", "gen_s", "pack_s", "slab")}
         first.clear()
         first.update(keep)
         other = run_mode("weak" if args.scaling == "strong" else "strong", False)
@@ -459,6 +459,8 @@ def main() -> int:
             "traffic_source": traffic_source,
             "kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, " + ("packed>" if packed else "u8>"),
             "kernel_ms_avg": avg_kernel_s * 1e3,
+            # HIP events bracket every n-th sweep of the timed region (--timing-sample): the average is over these launches
+            "kernel_launches_timed": first.get("timed_launches"), "timing_sample": max(1, args.timing_sample),
             "kernel_sites_per_launch": S,
             "algorithmic_bytes_per_site": b_site,
             # the same sites/s priced at SURVEY 8(d)'s u8-layout figure (H + 56 B/site): what a sweep over u8 rows would
