@@ -352,16 +352,15 @@ def main() -> int:
         u8_reference = None
         if args.layout == "packed":
             if primary and world == 1 and args.u8_reference_steps > 0 and S > 0:
-                os.environ["FMH_LAYOUT"] = "bytes"  # read per call by the library: sweeps take the u8 kernels while the rows exist
-                local = sweep_local()
-                lib.fmh_timing_enable(1)
-                lib.fmh_timing_reset()
-                for _ in range(args.u8_reference_steps):
+                with _abi.options(FMH_LAYOUT="bytes"):  # fmh_set_option: sweeps take the u8 kernels while the rows exist
                     local = sweep_local()
-                ms8, n8 = C.c_double(), C.c_uint64()
-                lib.fmh_timing_read(C.byref(ms8), C.byref(n8))
-                lib.fmh_timing_enable(0)
-                del os.environ["FMH_LAYOUT"]
+                    lib.fmh_timing_enable(1)
+                    lib.fmh_timing_reset()
+                    for _ in range(args.u8_reference_steps):
+                        local = sweep_local()
+                    ms8, n8 = C.c_double(), C.c_uint64()
+                    lib.fmh_timing_read(C.byref(ms8), C.byref(n8))
+                    lib.fmh_timing_enable(0)
                 k8 = ms8.value / 1e3 / max(n8.value, 1)
                 u8_reference = {"kernel": "fmh::sweep_kernel<2, Summary|Hudson, no-missing, biallelic, u8>", "kernel_ms_avg": k8 * 1e3,
                                 "algorithmic_bytes_per_site": H + W_OUT_HUDSON, "achieved": (H + W_OUT_HUDSON) * S / k8 / 1e9,

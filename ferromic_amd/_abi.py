@@ -102,6 +102,8 @@ _P = C.POINTER
 SYMBOLS = {
     "fmh_last_error": (C.c_char_p, []),
     "fmh_abi_version": (_i, []),
+    "fmh_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "fmh_get_option": (_i, [C.c_char_p, _P(C.c_longlong)]),
     "fmh_device_count": (_i, [_P(_i)]),
     "fmh_device_info": (_i, [_i, C.c_char_p, _sz, _P(_i), _P(_u64)]),
     "fmh_device_alloc": (_i, [_i, _sz, _P(_vp)]),
@@ -143,12 +145,22 @@ SYMBOLS = {
     "fmh_comm_init_local": (_i, [_i, _P(_vp)]),
     "fmh_comm_destroy": (_i, [_vp]),
     "fmh_comm_info": (_i, [_vp, _P(_i), _P(_i), _P(_i), _P(_i)]),
+    "fmh_comm_describe": (_i, [_vp, C.c_char_p, _sz]),
+    "fmh_comm_abort": (_i, [_vp]),
     "fmh_allreduce_totals": (_i, [_vp, _P(_d), _sz, _P(_u64), _sz]),
     "fmh_allreduce_totals_begin": (_i, [_vp, _P(_d), _sz, _P(_u64), _sz]),
     "fmh_allreduce_totals_end": (_i, [_vp, _P(_d), _P(_u64)]),
     "fmh_hudson_sweep_sharded_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _P(HudsonSites), _vp]),
     "fmh_hudson_sweep_sharded_end": (_i, [_vp, _P(HudsonTotals)]),
     "fmh_hudson_sweep_sharded": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
+    "fmh_wc_sweep_sharded_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "fmh_wc_sweep_sharded_end": (_i, [_vp, _P(WcTotals)]),
+    "fmh_wc_sweep_sharded": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(WcTotals), _vp]),
+    "fmh_population_summaries_sharded_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _vp]),
+    "fmh_population_summaries_sharded_end": (_i, [_vp, _P(PopTotals)]),
+    "fmh_population_summaries_sharded": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _P(PopTotals), _vp]),
+    "fmh_timing_read_reduce": (_i, [_P(_d), _P(_u64)]),
+    "fmh_timing_reset_reduce": (_i, []),
     "fmh_timing_enable": (_i, [_i]),
     "fmh_timing_reset": (_i, []),
     "fmh_timing_read": (_i, [_P(_d), _P(_u64)]),
@@ -210,6 +222,36 @@ def check(status: int) -> None:
     if status == FMH_ERR_NO_DEVICE:
         raise NoDeviceError(status, msg)
     raise FerromicHipError(status, msg)
+
+
+def set_option(key: str, value=None) -> None:
+    """fmh_set_option: a per-process switch of the library (keys = the FMH_* names of include/ferromic_hip.h); None = default.
+    The library reads the FMH_* environment once, at first use - later changes go through here, not through os.environ."""
+    check(load().fmh_set_option(key.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(key: str) -> int:
+    v = C.c_longlong()
+    check(load().fmh_get_option(key.encode(), C.byref(v)))
+    return int(v.value)
+
+
+class options:
+    """`with options(FMH_LAYOUT="bytes", FMH_DEFER_TILES=1): ...` - set for the block, previous values restored after it."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def device_count() -> int:

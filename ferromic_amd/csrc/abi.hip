@@ -42,6 +42,102 @@ int fmhi::fail(int code, const char* fmt, ...) {
 extern "C" const char* fmh_last_error(void) { return g_last_error.c_str(); }
 extern "C" int fmh_abi_version(void) { return FMH_ABI_VERSION; }
 
+// ------------------------------------------------------------------------------------------------
+// options: one table, the FMH_* environment read once, fmh_set_option afterwards
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct OptionRow {
+  const char* key;
+  std::atomic<long long> Options::*field;
+  long long dflt;
+  const char* words;  // "word=value,..." spellings accepted besides integers
+};
+const OptionRow kOptionRows[] = {
+    {"FMH_LAYOUT", &Options::layout_bytes, 0, "bytes=1,packed=0"},
+    {"FMH_MASK_MODE", &Options::mask_mode, -1, nullptr},
+    {"FMH_DEFER_TILES", &Options::defer_tiles, 0, nullptr},
+    {"FMH_PACKED_LPR", &Options::packed_lpr, 0, nullptr},
+    {"FMH_PACKED_UNROLL", &Options::packed_unroll, 0, nullptr},
+    {"FMH_PACKED_NO_PREFETCH", &Options::packed_no_prefetch, 0, nullptr},
+    {"FMH_COUNTS_MFMA", &Options::counts_mfma, 0, nullptr},
+    {"FMH_GRID_PER_CU", &Options::grid_per_cu, 0, nullptr},
+    {"FMH_GRID_BLOCKS", &Options::grid_blocks, 0, nullptr},
+    {"FMH_MAX_OCC", &Options::max_occ, 0, nullptr},
+    {"FMH_UNROLL", &Options::unroll, 0, nullptr},
+    {"FMH_PITCH_ALIGN", &Options::pitch_align, 16, nullptr},
+    {"FMH_COMM_TRANSPORT", &Options::comm_host, 0, "host=1,rccl=0"},
+    {"FMH_UPLOAD_THREADS", &Options::upload_threads, 0, nullptr},
+    {"FMH_PD_TWO_PLANES", &Options::pd_two_planes, 0, nullptr},
+    {"FMH_PD_INT8", &Options::pd_int8, 0, nullptr},
+    {"FMH_PD_PLANES_BYTES", &Options::pd_planes_bytes, (long long)8 << 30, nullptr},
+    {"FMH_PD_KCHUNK", &Options::pd_kchunk, 0, nullptr},
+    {"FMH_PD_SB", &Options::pd_sb, 0, nullptr},
+    {"FMH_PD_OCC", &Options::pd_occ, 0, nullptr},
+    {"FMH_WC_VARIANT", &Options::wc_variant, 0, nullptr},
+    {"FMH_GRAPH", &Options::graph, 1, nullptr},
+};
+bool parse_option(const OptionRow& row, const char* text, long long* out) {
+  if (row.words) {
+    const size_t n = strlen(text);
+    for (const char* w = row.words; *w;) {
+      const char* eq = strchr(w, '=');
+      const char* end = strchr(w, ',');
+      if (!end) end = w + strlen(w);
+      if ((size_t)(eq - w) == n && strncmp(w, text, n) == 0) { *out = atoll(eq + 1); return true; }
+      w = *end ? end + 1 : end;
+    }
+  }
+  char* stop = nullptr;
+  const long long v = strtoll(text, &stop, 10);
+  if (stop == text || *stop) return false;
+  *out = v;
+  return true;
+}
+}  // namespace
+
+constexpr size_t kOptionCount = sizeof kOptionRows / sizeof kOptionRows[0];
+static long long g_option_initial[kOptionCount];  // what the process started with: the environment's value, else the default
+
+Options& fmhi::options() {
+  static Options o;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (size_t i = 0; i < kOptionCount; ++i) {
+      const OptionRow& row = kOptionRows[i];
+      long long x = row.dflt;
+      // a variable that is set but empty or unparsable counts as "1" (round 2's presence switches: FMH_PACKED_NO_PREFETCH=, FMH_PD_INT8=yes)
+      if (const char* v = getenv(row.key)) { if (!parse_option(row, v, &x)) x = 1; }
+      g_option_initial[i] = x;
+      (o.*row.field).store(x);
+    }
+  });
+  return o;
+}
+
+extern "C" int fmh_set_option(const char* key, const char* value_or_null) {
+  if (!key) return fail(FMH_ERR_INVALID, "option key is NULL");
+  Options& o = options();
+  for (size_t i = 0; i < kOptionCount; ++i) {
+    const OptionRow& row = kOptionRows[i];
+    if (strcmp(row.key, key) != 0) continue;
+    long long x = g_option_initial[i];  // NULL: back to what the process started with
+    if (value_or_null && !parse_option(row, value_or_null, &x))
+      return fail(FMH_ERR_INVALID, "option %s: cannot parse '%s'%s%s", key, value_or_null, row.words ? " (integers or " : "", row.words ? row.words : "");
+    (o.*row.field).store(x);
+    return FMH_OK;
+  }
+  return fail(FMH_ERR_INVALID, "unknown option '%s'", key);
+}
+
+extern "C" int fmh_get_option(const char* key, long long* h_value) {
+  if (!key || !h_value) return fail(FMH_ERR_INVALID, "NULL argument");
+  Options& o = options();
+  for (const OptionRow& row : kOptionRows) {
+    if (strcmp(row.key, key) == 0) { *h_value = (o.*row.field).load(); return FMH_OK; }
+  }
+  return fail(FMH_ERR_INVALID, "unknown option '%s'", key);
+}
+
 static int device_count_checked(int* n) {
   int c = 0;
   hipError_t e = hipGetDeviceCount(&c);
@@ -199,8 +295,21 @@ extern "C" int fmh_stream_synchronize(int device, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // LDS the sweep needs for P (padded) groups of an `nvec`-vector row, masks as bytes (fast) or as bits (8x the width);
 // the kernels take at most 150 KiB.  sweep_lds_bytes() > limit means "does not fit in LDS in either form".
+// The limit comes from the device: the LDS a workgroup may opt into, less the kernels' static arrays (block reduction, W&C reciprocal
+// table: about 6 KiB) - 150 KiB on gfx950's 160 KiB.  g_lds[device] is filled by workspace(); 150 KiB until then.
 static const size_t kSweepLdsLimit = 150 * 1024;
-static size_t sweep_lds_limit(int padded, int mode) { (void)padded; (void)mode; return kSweepLdsLimit; }
+static std::atomic<size_t> g_lds_optin[64], g_lds_per_cu[64];
+static size_t device_lds_limit(int device) {
+  size_t optin = device >= 0 && device < 64 ? g_lds_optin[device].load(std::memory_order_relaxed) : 0;
+  const size_t per_cu = device >= 0 && device < 64 ? g_lds_per_cu[device].load(std::memory_order_relaxed) : 0;
+  if (optin < per_cu) optin = per_cu;  // runtimes that report the 64-KiB default as the opt-in limit: a workgroup may take the CU's LDS
+  return optin >= (size_t)128 * 1024 ? optin - 10 * 1024 : kSweepLdsLimit;
+}
+static size_t device_lds_per_cu(int device) {
+  const size_t v = device >= 0 && device < 64 ? g_lds_per_cu[device].load(std::memory_order_relaxed) : 0;
+  return v ? v : (size_t)160 * 1024;
+}
+static size_t sweep_lds_limit(int device) { return device_lds_limit(device); }
 static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 2; }
 
 static int check_dims(size_t variants, size_t samples, size_t ploidy) {
@@ -223,7 +332,7 @@ extern "C" int fmh_matrix_alloc(size_t variants, size_t samples, size_t ploidy, 
   m->samples = samples;
   m->ploidy = ploidy;
   m->columns = (uint32_t)(samples * ploidy);
-  static const int env_align = getenv("FMH_PITCH_ALIGN") ? atoi(getenv("FMH_PITCH_ALIGN")) : 16;
+  const int env_align = (int)options().pitch_align.load();
   m->pitch = round_up(m->columns, env_align >= 16 && env_align % 16 == 0 ? env_align : 16);
   m->nvec = (uint32_t)(round_up(m->columns, 16) / 16);
   m->bits_pitch = with_missing ? round_up(m->pitch / 8, 4) : 0;
@@ -286,7 +395,8 @@ hipError_t fmhi::unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint
   const size_t total = rows * (pitch / 16);
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 1 << 20);
   const size_t off = row0 * m->plane_pitch;
-  hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, st, m->p0 + off, m->p1 ? m->p1 + off : nullptr, m->p2 ? m->p2 + off : nullptr, m->plane_pitch, rows, data, pitch);
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(blocks), dim3(256), 0, st, m->p0 + off, m->p1 ? m->p1 + off : nullptr, m->p2 ? m->p2 + off : nullptr,
+                     m->pc ? m->pc + off : nullptr, m->plane_pitch, rows, data, pitch);
   return hipGetLastError();
 }
 
@@ -651,6 +761,8 @@ int fmhi::workspace(int device, Workspace** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     w.cus = prop.multiProcessorCount;
     w.max_grid = w.cus * 8;
+    g_lds_optin[device].store(prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin : prop.sharedMemPerBlock);
+    g_lds_per_cu[device].store(prop.maxSharedMemoryPerMultiProcessor);
     w.ready = true;
   }
   *out = &w;
@@ -794,21 +906,21 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   const bool missing = m->has_missing;
   const bool general = m->max_allele > 1;
   const int P = g->padded;
-  static const int env_unroll = getenv("FMH_UNROLL") ? atoi(getenv("FMH_UNROLL")) : 0;
-  a.unroll = env_unroll == 8 ? 8 : 4;
+  const Options& opt = options();  // one snapshot of the switches per enqueue (atomics; the environment is never read here)
+  a.unroll = opt.unroll.load() == 8 ? 8 : 4;
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
   size_t smem = (size_t)P * a.nvec_pad * 16;
   int mask_mode = kMaskLdsBytes;
   int lpr = 16;
-  const size_t lds_limit = sweep_lds_limit(P, mode);
+  const size_t lds_limit = sweep_lds_limit(m->device);
   if (packed) {
     // 128 columns per vector.  Rows of up to 32 vectors (4 096 columns) are shared by FOUR lanes (no idle vector slots
     // on short rows, a two-step reduction: C2 0.081 -> 0.042 ms, C3 0.94 -> 0.63 ms), wider ones by the sixteen lanes of a
     // DPP row (C4's 40 vectors: 1.32 vs 1.34 ms, 200 000 columns: 0.46 vs 0.66 ms); the batch depth U (vectors per lane in
     // flight per trip) is the one with the fewest padded slots, ties to the deeper batch.  (Eight lanes per row measured between
     // the two everywhere - C4 1.37 ms - and is not built.)
-    const int env_punroll = getenv("FMH_PACKED_UNROLL") ? atoi(getenv("FMH_PACKED_UNROLL")) : 0;  // read per call: tests flip them
-    const int env_lpr = getenv("FMH_PACKED_LPR") ? atoi(getenv("FMH_PACKED_LPR")) : 0;
+    const int env_punroll = (int)opt.packed_unroll.load();
+    const int env_lpr = (int)opt.packed_lpr.load();
     lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
     // eight groups: only the shallow batches are built (deeper ones kept P x U mask vectors live and spilled)
     const bool shallow = P == 8;
@@ -828,7 +940,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     // FMH_PACKED_NO_PREFETCH=1): on four-lane rows (1 000 and 2 500 haplotypes) it is level or 1-6 % ahead at every launch size; on sixteen-lane
     // rows with two groups (5 000 haplotypes) it was 2.4-2.9 % ahead at 625 k sites, level at 1 M and 0.6-2.4 % behind from 1.25 M to 10 M sites -
     // those kernels (one and two groups, sixteen lanes) have since dropped it altogether for the deferred-epilogue loop (sweep_kernel, defer_kernel()).
-    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !getenv("FMH_PACKED_NO_PREFETCH");
+    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && opt.packed_no_prefetch.load() == 0;
     smem = (size_t)P * a.nvec_pad * 16;
     mask_mode = kMaskPacked;
     if (smem > lds_limit)
@@ -841,19 +953,18 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   // BASELINE config C5: the counts as an int8 matrix-core contraction (sweep_mfma_kernels.hpp), for u8 rows that are biallelic with
   // nothing missing and at most four (padded) groups.  An alternative route: the contraction has <= 4 output rows and stays HBM-bound,
   // so it is measured beside the dot4 route, not chosen by default.  Read per call: tests flip it.
-  const char* env_mfma = getenv("FMH_COUNTS_MFMA");
-  const int mfma_unroll = env_mfma && atoi(env_mfma) == 2 ? 2 : 4;
+  const int env_mfma = (int)opt.counts_mfma.load();
+  const int mfma_unroll = env_mfma == 2 ? 2 : 4;
   // (rows whose byte masks do not fit LDS stay on the dot4 routes)
-  const bool mfma = !packed && env_mfma && atoi(env_mfma) != 0 && !missing && !general && P <= 4 &&
+  const bool mfma = !packed && env_mfma != 0 && !missing && !general && P <= 4 &&
                     (size_t)P * mfma_mask_stride(m->nvec, mfma_unroll) * 16 <= lds_limit;
   if (mfma) {
     a.unroll = mfma_unroll;
     a.nvec_pad = mfma_mask_stride(m->nvec, a.unroll);
     smem = (size_t)P * a.nvec_pad * 16;
   }
-  const char* force = packed || mfma ? nullptr : getenv("FMH_MASK_MODE");
-  if (force) {  // tests and measurements: take a slower mask route than needed
-    const int want = atoi(force);
+  const int want = packed || mfma ? -1 : (int)opt.mask_mode.load();
+  if (want >= 0) {  // tests and measurements: take a slower mask route than needed
     const bool global_ok = P <= 2 && mode != kModeWc;
     if (want == kMaskLdsBits && mask_mode == kMaskLdsBytes) { smem = (size_t)P * a.nvec_pad * 2; mask_mode = kMaskLdsBits; }
     if (want == kMaskGlobalBytes && global_ok) { smem = 0; mask_mode = kMaskGlobalBytes; }
@@ -863,11 +974,11 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   // columns fell from 3 to 2 workgroups per CU, 0.45 -> 0.69 ms, before the cap).  The deferring kernels have no other tile loop, so one tile's
   // room is always added.
   if (!mfma && !general && lpr == 16 && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing)) {  // == defer_kernel<...>()
-    const char* e = getenv("FMH_DEFER_TILES");  // read per call: measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
-    a.defer_tiles = e && atoi(e) >= 1 && atoi(e) <= kDeferTiles ? atoi(e) : -1;
+    const int e = (int)opt.defer_tiles.load();  // measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
+    a.defer_tiles = e >= 1 && e <= kDeferTiles ? e : -1;
     smem = round_up(smem, 16);
     int depth = defer_depth_host(P, mode, missing);
-    while (depth > 1 && smem + defer_lds_bytes(P, mode, missing, depth) > (size_t)(160 * 1024) / 3 - 1024) depth /= 2;
+    while (depth > 1 && smem + defer_lds_bytes(P, mode, missing, depth) > device_lds_per_cu(m->device) / 3 - 1024) depth /= 2;
     a.defer_cap = depth;
     a.defer_offset = (uint32_t)smem;
     smem += defer_lds_bytes(P, mode, missing, depth);
@@ -976,10 +1087,10 @@ extern "C" int fmh_population_summaries(const fmh_matrix* m, const fmh_groups* g
   a.formula = formula;
   a.alt = d_alt;
   a.called = d_called;
-  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > kSweepLdsLimit && g->n_groups > 2) {
+  if (m && g && sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(m->device) && g->n_groups > 2) {
     // rows too wide for all masks at once: the populations are independent, sweep them in smaller batches
     int batch = g->n_groups;
-    while (batch > 2 && sweep_lds_bytes(padded_groups(batch), m->nvec) > kSweepLdsLimit) batch = (batch + 1) / 2;
+    while (batch > 2 && sweep_lds_bytes(padded_groups(batch), m->nvec) > sweep_lds_limit(m->device)) batch = (batch + 1) / 2;
     for (int p0 = 0; p0 < g->n_groups; p0 += batch) {
       const int cnt = std::min(batch, g->n_groups - p0);
       fmh_groups* sub = nullptr;
@@ -1069,6 +1180,37 @@ static int wc_slot_sums(DeviceScratch& scratch, hipStream_t st, size_t nslots, s
   return FMH_OK;
 }
 
+// W&C kernel slots follow the padded-P pair order; maps them to the caller's G-group order (a.wc_slot for the kernel's stores,
+// slot_of for the host's unpacking; -1 = a padded group takes part, never reported)
+void fmhi::wc_slot_map(const fmh_groups* g, SweepArgs& a, int (&slot_of)[32]) {
+  for (int k = 0; k < 32; ++k) { a.wc_slot[k] = -1; slot_of[k] = -1; }
+  if (!g) return;
+  const int P = g->padded, G = g->n_groups;
+  a.wc_slot[0] = 0;
+  slot_of[0] = 0;
+  int k = 1;
+  for (int i = 0; i < P; ++i)
+    for (int j = i + 1; j < P; ++j, ++k) {
+      if (i < G && j < G) {
+        int idx = 1;
+        for (int x = 0; x < G; ++x)
+          for (int y = x + 1; y < G; ++y, ++idx)
+            if (x == i && y == j) slot_of[k] = idx;
+        a.wc_slot[k] = (int8_t)slot_of[k];
+      }
+    }
+}
+// true when fmh_wc_sweep runs ONE fused kernel that keeps the regional sums per lane (2..4 groups, masks in LDS): the route the
+// pipelined sharded sweep can finalise and reduce on the device; everything else (5..8 groups, alleles beyond 3 with eight groups,
+// rows too wide for all masks) sums its per-site tracks or goes through the counts route
+bool fmhi::wc_fused_lane_totals(const fmh_matrix* m, const fmh_groups* g) {
+  if (!m || !g || g->padded >= 8) return false;
+  return sweep_lds_bytes(g->padded, m->nvec) <= sweep_lds_limit(m->device);
+}
+bool fmhi::summaries_single_sweep(const fmh_matrix* m, const fmh_groups* g) {
+  return m && g && !(sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(m->device) && g->n_groups > 2);
+}
+
 extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a,
                             double* d_b, uint8_t* d_state, uint32_t* d_group_called, fmh_wc_totals* h_totals,
                             void* stream) {
@@ -1081,28 +1223,11 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   a.wc_b = d_b;
   a.wc_state = d_state;
   a.called = d_group_called;
-  // kernel slots follow the padded-P pair order; map them to the caller's G-group order
   int slot_of[32];
-  for (int k = 0; k < 32; ++k) { a.wc_slot[k] = -1; slot_of[k] = -1; }
-  if (g) {
-    const int P = g->padded, G = g->n_groups;
-    a.wc_slot[0] = 0;
-    slot_of[0] = 0;
-    int k = 1;
-    for (int i = 0; i < P; ++i)
-      for (int j = i + 1; j < P; ++j, ++k) {
-        if (i < G && j < G) {
-          int idx = 1;
-          for (int x = 0; x < G; ++x)
-            for (int y = x + 1; y < G; ++y, ++idx)
-              if (x == i && y == j) slot_of[k] = idx;
-          a.wc_slot[k] = (int8_t)slot_of[k];
-        }
-      }
-  }
+  wc_slot_map(g, a, slot_of);
   // the fused kernel for 5..8 groups keeps the counts of alleles 0..3 per site; cohorts with alleles beyond 3 take the counts route
   const bool many_alleles8 = m && g && g->padded == 8 && m->max_allele > 3;
-  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(g->padded, kModeWc))) {
+  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(m->device))) {
     // (or: rows too wide for all groups' masks to sit in LDS at once) count in smaller batches, components from the count tables
     const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
     std::vector<double> sa(nslots), sb(nslots);
@@ -1207,7 +1332,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   (void)all_alt;
   // (2) counts of every group, eight groups per sweep
   size_t batch = FMH_MAX_GROUPS;  // as many groups per sweep as the LDS holds masks for
-  while (batch > 2 && sweep_lds_bytes((int)batch, m->nvec) > kSweepLdsLimit) batch /= 2;  // two groups fit any width (global-mask route)
+  while (batch > 2 && sweep_lds_bytes((int)batch, m->nvec) > sweep_lds_limit(m->device)) batch /= 2;  // two groups fit any width (global-mask route)
   for (size_t g0 = 0; g0 < G; g0 += batch) {
     const int cnt = (int)std::min<size_t>(batch, G - g0);
     fmh_groups* g = nullptr;

@@ -46,11 +46,34 @@ void pool_trim(int device);
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// FMH_LAYOUT=bytes keeps the u8 kernels on matrices that still hold their byte rows (read per call: tests flip it)
-inline bool layout_bytes_forced() {
-  const char* v = getenv("FMH_LAYOUT");
-  return v && strcmp(v, "bytes") == 0;
-}
+// ---- per-process options (fmh_set_option / fmh_get_option, abi.hip) ------------------------------------------------------
+// Every switch that routes a kernel or sizes a launch lives here as an atomic integer.  The FMH_* environment is read ONCE, when the
+// library first needs an option (so `FMH_LAYOUT=bytes python ...` and a child process started with such an environment still work);
+// after that only fmh_set_option changes a value.  Nothing on a launch path reads the environment: round 2 read ten variables per enqueue, which
+// cost 1-2 us per sweep and raced with any host thread calling setenv.
+struct Options {
+  std::atomic<long long> layout_bytes{0};        // FMH_LAYOUT = bytes | packed: keep the u8 kernels on matrices that still hold their byte rows
+  std::atomic<long long> mask_mode{-1};          // FMH_MASK_MODE: force a slower mask route (tests / measurements)
+  std::atomic<long long> defer_tiles{0};         // FMH_DEFER_TILES: 1..16 forces the deferral depth (1 = undeferred); 0 = by the launch size
+  std::atomic<long long> packed_lpr{0};          // FMH_PACKED_LPR: 4 | 16 lanes per packed row; 0 = by the row width
+  std::atomic<long long> packed_unroll{0};       // FMH_PACKED_UNROLL: batch depth of the packed cores; 0 = fewest padded slots
+  std::atomic<long long> packed_no_prefetch{0};  // FMH_PACKED_NO_PREFETCH: plain row loop instead of tile_rows_packed_prefetch
+  std::atomic<long long> counts_mfma{0};         // FMH_COUNTS_MFMA: 1 | 2 = the int8 matrix-core counting route (BASELINE config C5)
+  std::atomic<long long> grid_per_cu{0};         // FMH_GRID_PER_CU: workgroups per CU of the persistent grid; 0 = the occupancy
+  std::atomic<long long> grid_blocks{0};         // FMH_GRID_BLOCKS: total workgroups (tests: many tile rounds on small inputs)
+  std::atomic<long long> max_occ{0};             // FMH_MAX_OCC: cap on the occupancy used for the grid
+  std::atomic<long long> unroll{0};              // FMH_UNROLL: 8 = deeper batches of the u8 cores
+  std::atomic<long long> pitch_align{16};        // FMH_PITCH_ALIGN: row pitch alignment of u8 matrices
+  std::atomic<long long> comm_host{0};           // FMH_COMM_TRANSPORT = host: in-process rendezvous instead of RCCL (fmh_comm_init_all)
+  std::atomic<long long> upload_threads{0};      // FMH_UPLOAD_THREADS: host packer threads; 0 = the CPU share
+  std::atomic<long long> pd_two_planes{0}, pd_int8{0}, pd_planes_bytes{(long long)8 << 30}, pd_kchunk{0}, pd_sb{0}, pd_occ{0};  // FMH_PD_*: pairwise path
+  std::atomic<long long> wc_variant{0};          // FMH_WC_VARIANT: W&C four-lane kernel variant (measurements; 0 = default)
+  std::atomic<long long> graph{1};               // FMH_GRAPH: 0 = never replay sharded sweeps from a captured hipGraph
+};
+Options& options();
+
+// FMH_LAYOUT=bytes keeps the u8 kernels on matrices that still hold their byte rows
+inline bool layout_bytes_forced() { return options().layout_bytes.load(std::memory_order_relaxed) != 0; }
 
 // RAII for the scratch of one call
 struct DeviceScratch {
@@ -139,6 +162,11 @@ hipError_t unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* d
 // sweep + finalize enqueued on `st`, no synchronisation (abi.hip)
 int enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, fmh::SweepArgs& a, hipStream_t st, const LaunchCtx& ctx,
                   const SweepBuffers& b, const double* harmonic, bool* launched);
+
+// W&C slot order of the padded kernel -> the caller's pair order; which W&C / summaries calls are one fused sweep (abi.hip)
+void wc_slot_map(const fmh_groups* g, fmh::SweepArgs& a, int (&slot_of)[32]);
+bool wc_fused_lane_totals(const fmh_matrix* m, const fmh_groups* g);
+bool summaries_single_sweep(const fmh_matrix* m, const fmh_groups* g);
 
 // One function per (mask route, lanes per row): dispatches on (P, mode, missing, general) to the instantiation, sizes the
 // persistent grid and launches.  FMH_ERR_UNSUPPORTED for a combination the route does not build.

@@ -43,6 +43,8 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;     // optional
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mutex;
@@ -78,6 +80,12 @@ int rccl_api(RcclApi** out) {
     BIND(GroupEnd, "ncclGroupEnd");
     BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+    api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
+    if (origin.find('/') == std::string::npos) {  // a bare soname: report the file the dynamic linker actually mapped
+      Dl_info info;
+      if (dladdr(reinterpret_cast<void*>(api.AllReduce), &info) && info.dli_fname) origin += std::string(" -> ") + info.dli_fname;
+    }
     g_rccl = api;
   }
   *out = &g_rccl;
@@ -97,6 +105,8 @@ struct HostGroup {
   int n = 0, arrived = 0;
   uint64_t generation = 0;
   bool mismatch = false;
+  bool aborted = false;  // fmh_comm_abort: every waiter and every later caller returns an error instead of blocking
+  int aborted_by = -1;
   std::vector<std::vector<double>> f;
   std::vector<std::vector<uint64_t>> u;
   std::vector<double> rf;
@@ -105,6 +115,7 @@ struct HostGroup {
   // sums in rank order (deterministic), every rank leaves with the same vectors
   int allreduce(int rank, double* f64, size_t nf, uint64_t* u64, size_t nu) {
     std::unique_lock<std::mutex> lock(mu);
+    if (aborted) return fail(FMH_ERR_INVALID, "the communicator was aborted by rank %d: a peer failed before its collective", aborted_by);
     f[rank].assign(f64, f64 + nf);
     u[rank].assign(u64, u64 + nu);
     const uint64_t gen = generation;
@@ -123,13 +134,19 @@ struct HostGroup {
       ++generation;
       cv.notify_all();
     } else {
-      cv.wait(lock, [&] { return generation != gen; });
+      cv.wait(lock, [&] { return generation != gen || aborted; });
+      if (aborted && generation == gen) return fail(FMH_ERR_INVALID, "the communicator was aborted by rank %d: a peer failed before its collective", aborted_by);
     }
     if (mismatch) return fail(FMH_ERR_INVALID, "fmh_allreduce_totals: the ranks passed vectors of different lengths");
     // still under the lock: no rank can complete the NEXT round (and overwrite rf / ru) before this one has re-entered
     for (size_t i = 0; i < nf; ++i) f64[i] = rf[i];
     for (size_t i = 0; i < nu; ++i) u64[i] = ru[i];
     return FMH_OK;
+  }
+  void abort(int rank) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!aborted) { aborted = true; aborted_by = rank; }
+    cv.notify_all();
   }
 };
 
@@ -142,9 +159,18 @@ struct ShardSlot {
   double* h_f64 = nullptr;     // pinned
   unsigned long long* h_u64 = nullptr;
   hipEvent_t swept = nullptr, reduced = nullptr, ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t red0 = nullptr, red1 = nullptr;  // around the grouped all-reduce on the communicator's stream (fmh_timing_read_reduce)
   bool busy = false, launched = false, timed = false;
-  uint64_t sizes[2] = {0, 0};
+  int kind = 0;          // ShardKind
+  int n_groups = 0, padded = 0;
+  int slot_of[32];       // W&C: kernel slot -> caller slot
+  uint64_t sizes[FMH_MAX_GROUPS] = {0};
+  size_t row_count = 0;
+  unsigned long long* h_aux = nullptr;  // pinned: scalars added to the finalised vector before the reduce (W&C sites_attempted)
 };
+enum ShardKind : int { kShardHudson = 0, kShardWc = 1, kShardPops = 2 };
+const char* kind_name(int k) { return k == kShardHudson ? "Hudson" : k == kShardWc ? "W&C" : "population-summaries"; }
+constexpr int kOffWcAttempted = 62;  // u64 slot of the W&C vector that carries sites_attempted (rows swept: a plain sum over slabs)
 }  // namespace
 
 struct fmh_comm {
@@ -161,6 +187,7 @@ struct fmh_comm {
   unsigned long long* h_u64 = nullptr;
   hipEvent_t done = nullptr;
   bool pending = false;
+  std::atomic<bool> aborted{false};
   size_t pend_nf = 0, pend_nu = 0;
   // fmh_hudson_sweep_sharded_*: FIFO of slots
   ShardSlot slot[FMH_SHARDED_IN_FLIGHT];
@@ -192,6 +219,9 @@ int comm_alloc(fmh_comm* c) {
     HIP_TRY(hipEventCreateWithFlags(&s.reduced, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&s.ev0));
     HIP_TRY(hipEventCreate(&s.ev1));
+    HIP_TRY(hipEventCreate(&s.red0));
+    HIP_TRY(hipEventCreate(&s.red1));
+    HIP_TRY(hipHostMalloc((void**)&s.h_aux, 8 * 8, hipHostMallocDefault));
   }
   return FMH_OK;
 }
@@ -206,7 +236,8 @@ void comm_free(fmh_comm* c) {
   for (auto& s : c->slot) {
     (void)hipFree(s.part_f64); (void)hipFree(s.part_u64); (void)hipFree(s.out_f64); (void)hipFree(s.out_u64);
     (void)hipHostFree(s.h_f64); (void)hipHostFree(s.h_u64);
-    for (hipEvent_t e : {s.swept, s.reduced, s.ev0, s.ev1}) if (e) (void)hipEventDestroy(e);
+    (void)hipHostFree(s.h_aux);
+    for (hipEvent_t e : {s.swept, s.reduced, s.ev0, s.ev1, s.red0, s.red1}) if (e) (void)hipEventDestroy(e);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   (void)hipGetLastError();
@@ -265,8 +296,7 @@ extern "C" int fmh_comm_init_all(const int* h_devices, int n, fmh_comm** h_out) 
   if (n < 1 || n > 64) return fail(FMH_ERR_INVALID, "communicator size %d out of range 1..64", n);
   for (int i = 0; i < n; ++i) h_out[i] = nullptr;
   std::set<int> distinct(h_devices, h_devices + n);
-  const char* env = getenv("FMH_COMM_TRANSPORT");
-  const bool host = distinct.size() != (size_t)n || (env && strcmp(env, "host") == 0);
+  const bool host = distinct.size() != (size_t)n || options().comm_host.load() != 0;
   std::vector<fmh_comm*> made;
   auto bail = [&](int code) { for (fmh_comm* c : made) comm_free(c); for (int i = 0; i < n; ++i) h_out[i] = nullptr; return code; };
   std::shared_ptr<HostGroup> group;
@@ -326,14 +356,45 @@ extern "C" int fmh_comm_info(const fmh_comm* c, int* world, int* rank, int* devi
   return FMH_OK;
 }
 
+// What the communicator is, for reports (bench.py prints it for N > 1): transport, world, rank, device and - for RCCL - which
+// library file the process bound and its version.
+extern "C" int fmh_comm_describe(const fmh_comm* c, char* h_text, size_t cap) {
+  if (!c || !h_text || cap == 0) return fail(FMH_ERR_INVALID, "NULL argument");
+  const char* names[3] = {"rccl", "host", "local"};
+  std::string lib = "none", ver = "n/a";
+  if (c->transport == 0) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    lib = g_rccl.origin;
+    int v = 0;
+    if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == 0) ver = std::to_string(v);
+  }
+  snprintf(h_text, cap, "transport=%s world=%d rank=%d device=%d rccl_library=%s rccl_version=%s in_flight=%d", names[c->transport < 0 || c->transport > 2 ? 1 : c->transport],
+           c->world, c->rank, c->device, lib.c_str(), ver.c_str(), FMH_SHARDED_IN_FLIGHT);
+  return FMH_OK;
+}
+
+// A rank that failed before its collective: wakes the peers of an in-process group with an error (they would otherwise wait for ever)
+// and aborts the RCCL communicator.  The communicator is unusable afterwards (destroy it); every later collective on it fails.
+extern "C" int fmh_comm_abort(fmh_comm* c) {
+  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
+  c->aborted = true;
+  if (c->host) c->host->abort(c->rank);
+  if (c->transport == 0 && c->nccl && g_rccl.CommAbort) {
+    (void)g_rccl.CommAbort(c->nccl);  // also releases a peer thread of this process that is blocked on this communicator's stream
+    c->nccl = nullptr;
+  }
+  return FMH_OK;
+}
+
 extern "C" int fmh_allreduce_totals_begin(fmh_comm* c, const double* h_f64, size_t n_f64, const uint64_t* h_u64, size_t n_u64) {
   if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
   if ((n_f64 && !h_f64) || (n_u64 && !h_u64)) return fail(FMH_ERR_INVALID, "NULL vector");
   if (n_f64 > FMH_COMM_MAX_VALUES || n_u64 > FMH_COMM_MAX_VALUES) return fail(FMH_ERR_INVALID, "at most %d values per vector", FMH_COMM_MAX_VALUES);
   if (c->pending) return fail(FMH_ERR_INVALID, "a reduce is already in flight on this communicator: call fmh_allreduce_totals_end first");
+  if (c->aborted) return fail(FMH_ERR_INVALID, "the communicator was aborted");
   FMH_TRY(use_device(c->device));
-  memcpy(c->h_f64, h_f64, n_f64 * 8);
-  memcpy(c->h_u64, h_u64, n_u64 * 8);
+  if (n_f64) memcpy(c->h_f64, h_f64, n_f64 * 8);
+  if (n_u64) memcpy(c->h_u64, h_u64, n_u64 * 8);
   c->pend_nf = n_f64;
   c->pend_nu = n_u64;
   if (c->transport == 0) {
@@ -359,8 +420,8 @@ extern "C" int fmh_allreduce_totals_end(fmh_comm* c, double* h_f64, uint64_t* h_
   } else if (c->transport == 1) {
     FMH_TRY(c->host->allreduce(c->rank, c->h_f64, c->pend_nf, reinterpret_cast<uint64_t*>(c->h_u64), c->pend_nu));
   }
-  memcpy(h_f64, c->h_f64, c->pend_nf * 8);
-  memcpy(h_u64, c->h_u64, c->pend_nu * 8);
+  if (c->pend_nf) memcpy(h_f64, c->h_f64, c->pend_nf * 8);
+  if (c->pend_nu) memcpy(h_u64, c->h_u64, c->pend_nu * 8);
   return FMH_OK;
 }
 
@@ -369,17 +430,132 @@ extern "C" int fmh_allreduce_totals(fmh_comm* c, double* h_f64, size_t n_f64, ui
   return fmh_allreduce_totals_end(c, h_f64, h_u64);
 }
 
-// ---- pipelined sharded Hudson sweep ------------------------------------------------------------------------------------
+// ---- pipelined sharded sweeps: Hudson pair, Weir & Cockerham, population summaries ---------------------------------------------
+// One code path for the three: sweep on the caller's stream -> finalize_kernel on the communicator's stream (behind the sweep's
+// event) -> grouped ncclAllReduce of the 64 + 64 finalised accumulators in place -> one D2H into pinned memory.  _begin returns once
+// the work is enqueued; _end waits for the OLDEST sweep in flight (whatever its kind) and unpacks it.
+namespace {
+
+double g_reduce_ms = 0.0;   // accumulated event time of the all-reduces of timed sharded sweeps (fmh_timing_read_reduce)
+uint64_t g_reduce_n = 0;
+std::mutex g_reduce_mu;
+
+// Everything that can be refused is refused here, BEFORE anything is enqueued: a rank that returns an error from _begin has not
+// entered the collective, and the caller (run_vcf's slab threads) can abort the group instead of leaving the peers inside RCCL.
+int sharded_check(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count) {
+  if (!c || !m || !g) return fail(FMH_ERR_INVALID, "NULL argument");
+  if (c->aborted) return fail(FMH_ERR_INVALID, "the communicator was aborted");
+  if (m->device != c->device) return fail(FMH_ERR_INVALID, "matrix lives on device %d, the communicator on device %d", m->device, c->device);
+  if (g->device != m->device || g->pitch != m->pitch || g->columns != m->columns) return fail(FMH_ERR_INVALID, "groups were built for a different matrix geometry");
+  if (row_begin > m->variants || row_count > m->variants - row_begin) return fail(FMH_ERR_INVALID, "row range [%zu, +%zu) exceeds %zu variants", row_begin, row_count, m->variants);
+  if (c->head - c->tail >= FMH_SHARDED_IN_FLIGHT) return fail(FMH_ERR_INVALID, "%d sharded sweeps already in flight: call the matching _end first", FMH_SHARDED_IN_FLIGHT);
+  return FMH_OK;
+}
+
+// After a failure inside _begin (a HIP error once work was enqueued): nothing of this slot may still be running when it is reused
+void settle_after_failure(fmh_comm* c, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipGetLastError();
+}
+
+// sweep (mode, args) + device-side reduce + D2H, enqueued into the next free slot.  `host_vec`: the slot's totals were computed by a
+// blocking call and sit in s.h_f64 / s.h_u64 already (the routes that are not one fused sweep): they are copied up and reduced the same way.
+int sharded_enqueue(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, hipStream_t st, ShardSlot& s, bool host_vec) {
+  s.timed = timing_enabled();
+  s.launched = false;
+  auto body = [&]() -> int {
+    if (!host_vec) {
+      const LaunchCtx ctx{c->cus, c->max_grid, s.ev0, s.ev1, s.timed};
+      // the finalize kernel goes to the communicator's stream (behind the sweep's event): on the caller's stream the next window's sweep
+      // follows this one directly
+      const SweepBuffers bufs{s.part_f64, s.part_u64, s.out_f64, s.out_u64, c->stream, s.swept};
+      FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, nullptr, &s.launched));
+      if (!s.launched) {  // an empty slab still takes part in the collective, with zeros
+        HIP_TRY(hipMemsetAsync(s.out_f64, 0, kMaxF64 * 8, st));
+        HIP_TRY(hipMemsetAsync(s.out_u64, 0, kMaxU64 * 8, st));
+        HIP_TRY(hipEventRecord(s.swept, st));
+        HIP_TRY(hipStreamWaitEvent(c->stream, s.swept, 0));
+      }
+      if (s.kind == kShardWc) {  // rows swept: not a kernel accumulator
+        s.h_aux[0] = (unsigned long long)a.row_count;
+        HIP_TRY(hipMemcpyAsync(s.out_u64 + kOffWcAttempted, s.h_aux, 8, hipMemcpyHostToDevice, c->stream));
+      }
+    } else {
+      HIP_TRY(hipMemcpyAsync(s.out_f64, s.h_f64, kMaxF64 * 8, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(s.out_u64, s.h_u64, kMaxU64 * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->transport == 0) {
+      if (s.timed) HIP_TRY(hipEventRecord(s.red0, c->stream));
+      FMH_TRY(rccl_reduce_on_stream(c, s.out_f64, kMaxF64, s.out_u64, kMaxU64));
+      if (s.timed) HIP_TRY(hipEventRecord(s.red1, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(s.h_f64, s.out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(s.h_u64, s.out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(s.reduced, c->stream));
+    return FMH_OK;
+  };
+  const int rc = body();
+  if (rc != FMH_OK) { settle_after_failure(c, st); return rc; }  // the slot was never marked busy: nothing of it may still be in flight
+  s.busy = true;
+  ++c->head;
+  return FMH_OK;
+}
+
+// waits for the oldest sweep in flight; the slot is released only once its work is known to have finished (or, after an error, has
+// been waited for), so the next _begin never reuses buffers under running kernels
+int sharded_collect(fmh_comm* c, int kind, ShardSlot** out) {
+  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
+  if (c->head == c->tail) return fail(FMH_ERR_INVALID, "no sharded sweep in flight on this communicator");
+  FMH_TRY(use_device(c->device));
+  ShardSlot& s = c->slot[c->tail % FMH_SHARDED_IN_FLIGHT];
+  if (s.kind != kind) return fail(FMH_ERR_INVALID, "the oldest sharded sweep in flight is a %s sweep: collect it with its own _end", kind_name(s.kind));
+  int rc = FMH_OK;
+  hipError_t e = hipEventSynchronize(s.reduced);
+  if (e != hipSuccess) {
+    rc = fail(FMH_ERR_HIP, "hipEventSynchronize(reduced): %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+  }
+  if (rc == FMH_OK && c->transport == 1) rc = c->host->allreduce(c->rank, s.h_f64, kMaxF64, reinterpret_cast<uint64_t*>(s.h_u64), kMaxU64);
+  // (transport 2, a local one-rank communicator: nothing to add)
+  ++c->tail;
+  s.busy = false;
+  if (rc != FMH_OK) return rc;
+  if (s.timed) {
+    float ms = 0.f;
+    if (s.launched) { if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) timing_add(ms); else (void)hipGetLastError(); }
+    if (c->transport == 0) {
+      if (hipEventElapsedTime(&ms, s.red0, s.red1) == hipSuccess) { std::lock_guard<std::mutex> lock(g_reduce_mu); g_reduce_ms += ms; g_reduce_n += 1; }
+      else (void)hipGetLastError();
+    }
+  }
+  *out = &s;
+  return FMH_OK;
+}
+
+}  // namespace
+
+extern "C" int fmh_timing_read_reduce(double* h_total_ms, uint64_t* h_reduces) {
+  std::lock_guard<std::mutex> lock(g_reduce_mu);
+  if (h_total_ms) *h_total_ms = g_reduce_ms;
+  if (h_reduces) *h_reduces = g_reduce_n;
+  return FMH_OK;
+}
+extern "C" int fmh_timing_reset_reduce(void) {
+  std::lock_guard<std::mutex> lock(g_reduce_mu);
+  g_reduce_ms = 0.0;
+  g_reduce_n = 0;
+  return FMH_OK;
+}
+
 extern "C" int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
                                               int formula, const fmh_hudson_sites* sites, void* stream) {
-  if (!c || !m || !g) return fail(FMH_ERR_INVALID, "NULL argument");
+  FMH_TRY(sharded_check(c, m, g, row_begin, row_count));
   if (formula != FMH_FORMULA_SPARSE && formula != FMH_FORMULA_DENSE && formula != FMH_FORMULA_SUMMARY) return fail(FMH_ERR_INVALID, "unknown formula %d", formula);
   if (g->n_groups != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups, got %d", g->n_groups);
-  if (m->device != c->device) return fail(FMH_ERR_INVALID, "matrix lives on device %d, the communicator on device %d", m->device, c->device);
-  if (c->head - c->tail >= FMH_SHARDED_IN_FLIGHT) return fail(FMH_ERR_INVALID, "%d sharded sweeps already in flight: call fmh_hudson_sweep_sharded_end first", FMH_SHARDED_IN_FLIGHT);
   FMH_TRY(use_device(c->device));
   ShardSlot& s = c->slot[c->head % FMH_SHARDED_IN_FLIGHT];
-  hipStream_t st = (hipStream_t)stream;
   SweepArgs a{};
   a.row_begin = row_begin;
   a.row_count = row_count;
@@ -388,44 +564,18 @@ extern "C" int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, 
     a.fst = sites->d_fst; a.dxy = sites->d_dxy; a.pi1 = sites->d_pi1; a.pi2 = sites->d_pi2;
     a.num = sites->d_num; a.den = sites->d_den; a.alt = sites->d_alt; a.called = sites->d_called;
   }
-  s.timed = timing_enabled();
-  const LaunchCtx ctx{c->cus, c->max_grid, s.ev0, s.ev1, s.timed};
-  // the finalize kernel goes to the communicator's stream (behind the sweep's event): on the caller's stream the next window's sweep follows
-  // this one directly
-  const SweepBuffers bufs{s.part_f64, s.part_u64, s.out_f64, s.out_u64, c->stream, s.swept};
-  s.launched = false;
-  FMH_TRY(enqueue_sweep(m, g, kModeSummary | kModeHudson, a, st, ctx, bufs, nullptr, &s.launched));
-  if (!s.launched) {  // an empty slab still takes part in the collective, with zeros
-    HIP_TRY(hipMemsetAsync(s.out_f64, 0, kMaxF64 * 8, st));
-    HIP_TRY(hipMemsetAsync(s.out_u64, 0, kMaxU64 * 8, st));
-    HIP_TRY(hipEventRecord(s.swept, st));
-    HIP_TRY(hipStreamWaitEvent(c->stream, s.swept, 0));
-  }
+  s.kind = kShardHudson;
+  s.n_groups = 2;
   s.sizes[0] = g->sizes[0];
   s.sizes[1] = g->sizes[1];
-  if (c->transport == 0) FMH_TRY(rccl_reduce_on_stream(c, s.out_f64, kMaxF64, s.out_u64, kMaxU64));
-  HIP_TRY(hipMemcpyAsync(s.h_f64, s.out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(s.h_u64, s.out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipEventRecord(s.reduced, c->stream));
-  s.busy = true;
-  ++c->head;
-  return FMH_OK;
+  s.row_count = row_count;
+  return sharded_enqueue(c, m, g, kModeSummary | kModeHudson, a, (hipStream_t)stream, s, false);
 }
 
 extern "C" int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* t) {
-  if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
-  if (c->head == c->tail) return fail(FMH_ERR_INVALID, "no sharded sweep in flight on this communicator");
-  FMH_TRY(use_device(c->device));
-  ShardSlot& s = c->slot[c->tail % FMH_SHARDED_IN_FLIGHT];
-  ++c->tail;
-  s.busy = false;
-  HIP_TRY(hipEventSynchronize(s.reduced));
-  if (c->transport == 1) FMH_TRY(c->host->allreduce(c->rank, s.h_f64, kMaxF64, reinterpret_cast<uint64_t*>(s.h_u64), kMaxU64));
-  // (transport 2, a local one-rank communicator: nothing to add)
-  if (s.timed && s.launched) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) timing_add(ms); else (void)hipGetLastError();
-  }
+  ShardSlot* sp = nullptr;
+  FMH_TRY(sharded_collect(c, kShardHudson, &sp));
+  const ShardSlot& s = *sp;
   if (t) {
     memset(t, 0, sizeof *t);
     const double* f = s.h_f64;
@@ -446,9 +596,119 @@ extern "C" int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* t) {
 
 extern "C" int fmh_hudson_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int formula,
                                         const fmh_hudson_sites* sites, fmh_hudson_totals* t, void* stream) {
-  if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with fmh_hudson_sweep_sharded_end first");
+  if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with their _end first");
   FMH_TRY(fmh_hudson_sweep_sharded_begin(c, m, g, row_begin, row_count, formula, sites, stream));
   return fmh_hudson_sweep_sharded_end(c, t);
+}
+
+// ---- W&C (calculate_overall_fst_wc's sums, stats.rs:2145-2374, over the ranks) -------------------------------------------------
+extern "C" int fmh_wc_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a,
+                                          double* d_b, uint8_t* d_state, uint32_t* d_group_called, void* stream) {
+  FMH_TRY(sharded_check(c, m, g, row_begin, row_count));
+  if (g->n_groups < 2) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups, got %d", g->n_groups);
+  FMH_TRY(use_device(c->device));
+  ShardSlot& s = c->slot[c->head % FMH_SHARDED_IN_FLIGHT];
+  s.kind = kShardWc;
+  s.n_groups = g->n_groups;
+  s.padded = g->padded;
+  s.row_count = row_count;
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = FMH_FORMULA_SPARSE;
+  a.wc_a = d_a; a.wc_b = d_b; a.wc_state = d_state; a.called = d_group_called;
+  wc_slot_map(g, a, s.slot_of);
+  if (wc_fused_lane_totals(m, g)) return sharded_enqueue(c, m, g, kModeWc, a, (hipStream_t)stream, s, false);
+  // five to eight groups, or rows too wide for all masks at once: the blocking call (its regional sums come from the per-site tracks or the
+  // counts route), then the same device-side reduce of its totals, laid out like the fused kernel's vector in CALLER slot order
+  fmh_wc_totals local;
+  FMH_TRY(fmh_wc_sweep(m, g, row_begin, row_count, d_a, d_b, d_state, d_group_called, &local, stream));
+  memset(s.h_f64, 0, kMaxF64 * 8);
+  memset(s.h_u64, 0, kMaxU64 * 8);
+  const int slots = 1 + g->n_groups * (g->n_groups - 1) / 2;
+  for (int k = 0; k < slots; ++k) { s.h_f64[kOffWcA + k] = local.sum_a[k]; s.h_f64[kOffWcB + k] = local.sum_b[k]; s.h_u64[kOffWcInf + k] = local.informative_sites[k]; }
+  s.h_u64[kOffWcAttempted] = local.sites_attempted;
+  for (int k = 0; k < 32; ++k) s.slot_of[k] = k < slots ? k : -1;
+  return sharded_enqueue(c, m, g, kModeWc, a, (hipStream_t)stream, s, true);
+}
+
+extern "C" int fmh_wc_sweep_sharded_end(fmh_comm* c, fmh_wc_totals* t) {
+  ShardSlot* sp = nullptr;
+  FMH_TRY(sharded_collect(c, kShardWc, &sp));
+  const ShardSlot& s = *sp;
+  if (t) {
+    memset(t, 0, sizeof *t);
+    t->sites_attempted = s.h_u64[kOffWcAttempted];
+    for (int k = 0; k < 29; ++k) {
+      const int slot = s.slot_of[k];
+      if (slot < 0) continue;
+      t->sum_a[slot] = s.h_f64[kOffWcA + k];
+      t->sum_b[slot] = s.h_f64[kOffWcB + k];
+      t->informative_sites[slot] = s.h_u64[kOffWcInf + k];
+    }
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_wc_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a, double* d_b,
+                                    uint8_t* d_state, uint32_t* d_group_called, fmh_wc_totals* t, void* stream) {
+  if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with their _end first");
+  FMH_TRY(fmh_wc_sweep_sharded_begin(c, m, g, row_begin, row_count, d_a, d_b, d_state, d_group_called, stream));
+  return fmh_wc_sweep_sharded_end(c, t);
+}
+
+// ---- population summaries (build_dense_population_summary's scalars, stats.rs:1367-1470, over the ranks) -----------------------
+extern "C" int fmh_population_summaries_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                                      int formula, uint32_t* d_alt, uint32_t* d_called, void* stream) {
+  FMH_TRY(sharded_check(c, m, g, row_begin, row_count));
+  if (formula != FMH_FORMULA_SPARSE && formula != FMH_FORMULA_DENSE && formula != FMH_FORMULA_SUMMARY) return fail(FMH_ERR_INVALID, "unknown formula %d", formula);
+  FMH_TRY(use_device(c->device));
+  ShardSlot& s = c->slot[c->head % FMH_SHARDED_IN_FLIGHT];
+  s.kind = kShardPops;
+  s.n_groups = g->n_groups;
+  s.padded = g->padded;
+  s.row_count = row_count;
+  for (int p = 0; p < g->n_groups; ++p) s.sizes[p] = g->sizes[p];
+  SweepArgs a{};
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = formula;
+  a.alt = d_alt;
+  a.called = d_called;
+  if (summaries_single_sweep(m, g)) return sharded_enqueue(c, m, g, kModeSummary, a, (hipStream_t)stream, s, false);
+  // rows too wide for all masks at once: the blocking call re-batches the groups; its totals take the same device-side reduce
+  fmh_pop_totals local[FMH_MAX_GROUPS];
+  FMH_TRY(fmh_population_summaries(m, g, row_begin, row_count, formula, d_alt, d_called, local, stream));
+  memset(s.h_f64, 0, kMaxF64 * 8);
+  memset(s.h_u64, 0, kMaxU64 * 8);
+  for (int p = 0; p < g->n_groups; ++p) {
+    s.h_f64[kOffPopF64 + p] = local[p].pi_sum;
+    s.h_u64[kOffPopSeg + p] = local[p].segregating_sites;
+    s.h_u64[kOffPopUnc + p] = local[p].uncallable_sites;
+  }
+  return sharded_enqueue(c, m, g, kModeSummary, a, (hipStream_t)stream, s, true);
+}
+
+extern "C" int fmh_population_summaries_sharded_end(fmh_comm* c, fmh_pop_totals* t) {
+  ShardSlot* sp = nullptr;
+  FMH_TRY(sharded_collect(c, kShardPops, &sp));
+  const ShardSlot& s = *sp;
+  if (t) {
+    for (int p = 0; p < s.n_groups; ++p) {
+      t[p].haplotype_capacity = s.sizes[p];
+      t[p].segregating_sites = s.h_u64[kOffPopSeg + p];
+      t[p].uncallable_sites = s.h_u64[kOffPopUnc + p];
+      t[p].pi_sum = s.h_f64[kOffPopF64 + p];
+    }
+  }
+  return FMH_OK;
+}
+
+extern "C" int fmh_population_summaries_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int formula,
+                                                uint32_t* d_alt, uint32_t* d_called, fmh_pop_totals* t, void* stream) {
+  if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with their _end first");
+  FMH_TRY(fmh_population_summaries_sharded_begin(c, m, g, row_begin, row_count, formula, d_alt, d_called, stream));
+  return fmh_population_summaries_sharded_end(c, t);
 }
 
 // ---- packing of the totals structs ----------------------------------------------------------------------------------------

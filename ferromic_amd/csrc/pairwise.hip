@@ -22,18 +22,18 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   const int n_alleles = (int)m->max_allele + 1;
   const bool missing = m->has_missing;
   // biallelic and nothing missing: one plane (allele 1) and an all-ones row after the last sample (pairwise_kernels.hpp)
-  static const bool env_two_planes = getenv("FMH_PD_TWO_PLANES") != nullptr;  // measurements / tests: the general route
+  const bool env_two_planes = options().pd_two_planes.load() != 0;  // measurements / tests: the general route
   const bool single = !missing && n_alleles == 2 && !env_two_planes;
   const int n_planes = single ? 1 : (missing ? n_alleles + 2 : n_alleles);  // + genotype length, + valid flag only when calls can be missing
   const size_t tile_edge = kPdBig;
   const size_t n_pad = round_up(n_samples + (single ? 1 : 0), kPdBig);
   // counts 0..4 are exact in FP4 (e2m1): twice the MFMA rate of int8 at half the plane bytes (pairwise_kernels.hpp)
-  static const bool env_int8 = getenv("FMH_PD_INT8") != nullptr;  // measurements / tests: the int8 route
+  const bool env_int8 = options().pd_int8.load() != 0;  // measurements / tests: the int8 route
   const bool fp4 = m->ploidy <= 4 && !env_int8;
   const size_t spb = fp4 ? 2 : 1;            // sites per byte of a plane row
   const size_t ksites = kPdStageK * spb;     // sites per K block = per Gram stage
   // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
-  static const size_t budget = getenv("FMH_PD_PLANES_BYTES") ? (size_t)atoll(getenv("FMH_PD_PLANES_BYTES")) : ((size_t)8 << 30);
+  const size_t budget = (size_t)options().pd_planes_bytes.load();
   size_t slab = std::max<size_t>(budget / ((size_t)n_planes * n_pad), kPdStageK) / kPdStageK * ksites;
   slab = std::min(round_up(m->variants, ksites), slab);
   // a matrix with a packed image feeds the planes kernel its bit rows (1/8 of the bytes); FMH_LAYOUT=bytes keeps the u8 route
@@ -66,7 +66,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     HIP_TRY(hipMemsetAsync(d_totals, 0, totals_bytes, st));
   }
   const size_t nt = n_pad / tile_edge, tiles = nt * (nt + 1) / 2;
-  static const size_t env_chunk = getenv("FMH_PD_KCHUNK") ? (size_t)atoll(getenv("FMH_PD_KCHUNK")) : 0;
+  const size_t env_chunk = (size_t)options().pd_kchunk.load();
   uint8_t* unpacked = nullptr;
   if (via_unpack) {
     HIP_TRY(hipMalloc((void**)&unpacked, std::min(slab, m->variants) * m->pitch));
@@ -111,7 +111,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
       // samples per planes workgroup: the tile's raw bytes (one K block of sites x sb x ploidy) stay within 32 KiB of LDS, so
       // four workgroups share a CU and one's loads overlap another's packing (measured, 1 M x 2 500 FP4: 64 KiB tiles 1.94 ms,
       // 32 KiB 1.76 ms, 16 KiB 1.97 ms)
-      static const uint32_t env_sb = getenv("FMH_PD_SB") ? (uint32_t)atoi(getenv("FMH_PD_SB")) : 0;  // measurements
+      const uint32_t env_sb = (uint32_t)options().pd_sb.load();  // measurements
       uint32_t sb = env_sb ? env_sb : kPdBlock;
       while ((size_t)sb * m->ploidy * ksites > 32 * 1024 && sb > 4) sb /= 2;
       const size_t planes_smem = ksites * ((size_t)sb * m->ploidy + ((size_t)sb * m->ploidy + 7) / 8 + 1);
@@ -136,7 +136,7 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
       if (oe == hipSuccess) oe = fp4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4, true>, 1024, 2 * kPdBigStageBytes)
                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pd_gram256_kernel<4, 4, false>, 1024, 2 * kPdBigStageBytes);
       if (oe != hipSuccess || occ < 1) occ = 1;
-      static const int env_occ = getenv("FMH_PD_OCC") ? atoi(getenv("FMH_PD_OCC")) : 0;
+      const int env_occ = (int)options().pd_occ.load();
       if (env_occ > 0 && occ > env_occ) occ = env_occ;
       gram_occ[m->device][fp4] = occ;
     }

@@ -373,6 +373,12 @@ struct WcSite {
 // slot is obtained once (kernel argument when PRE, else computed here) and applied to every allele; the slot's a and b
 // are the sums of the per-allele terms in allele order.  emit(k, a, b, has_data) is called for EVERY slot: k = 0 overall
 // (has_data always; (0, 0) when fewer than two groups have data), k >= 1 pairs (has_data = both groups have data).
+// Between two slots: nothing of slot k + 1 is scheduled above the end of slot k.  The slots are independent, and left alone the scheduler
+// interleaves all seven of a four-group site for instruction-level parallelism the f64 pipe does not need (a dependent v_fma_f64 issues
+// back to back), at the price of every slot's operands being live at once.
+#ifndef FMH_SLOT_FENCE
+#define FMH_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int P, int NA, bool PRE, class Emit>
 __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint32_t (&n)[P], const uint32_t (&c)[NA][P], Emit&& emit) {
   constexpr int NWS = 1 + (P * (P - 1)) / 2;
@@ -417,6 +423,7 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
       }
     }
     emit(0, wa, wb, true);
+    FMH_SLOT_FENCE();
   }
   int k = 1;
 #pragma unroll
@@ -454,6 +461,7 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
         }
       }
       emit(k, wa, wb, both);
+      FMH_SLOT_FENCE();
       ++k;
     }
   }
@@ -1480,6 +1488,121 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
     site_epilogue<P, MODE, MISSING, GENERAL>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T, c4);
   }
 
+  reduce_block_totals<P, MODE>(A, T);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// the pipelined tile loop: packed, biallelic, nothing missing, one batch of loads per row (single_trip)
+// ------------------------------------------------------------------------------------------------
+// sweep_kernel's plain tile loop has no load in flight while a wave runs an epilogue: with the W&C epilogue of four groups (about 900 VALU
+// instructions per tile, as many as the counting) and two waves per SIMD that is a third of every wave's time, and whenever both waves of a
+// SIMD are there at once its share of the memory pipeline idles (profiles/r02: C3 at 0.58 of the peak with SQ_WAIT_ANY at only 47 %).  Here the
+// row steps of ALL of a wave's tiles form one stream with two rows of loads in flight: the loads of the next tile's first two row steps are
+// issued before the epilogue of the current tile and land under it.  Costs the 2 x U x 4 load registers across the epilogue - free for a kernel
+// that sits at two waves per SIMD anyway (207 -> at most 256 VGPRs).  Tiles, their order per lane, every per-site operation and the order of
+// the regional sums are those of the plain loop: same bits.
+template <int P, int MODE, int U, int LPR>
+__device__ __forceinline__ void tiles_pipelined(const SweepArgs& A, const MatrixView& mv, const uint4* __restrict__ lm, uint32_t nvec_pad,
+                                                LaneTotals<P, MODE>& T) {
+  constexpr bool MREG = P * U <= 12;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int grp = lane / LPR, gl = lane % LPR;
+  const size_t ntiles = (A.row_count + kTileRows - 1) / kTileRows;
+  const size_t tile_stride = (size_t)gridDim.x * kWavesPerBlock;
+  size_t tile = (size_t)blockIdx.x * kWavesPerBlock + wave;
+  if (tile >= ntiles) return;
+  const uint32_t last = mv.nvec - 1;
+  uint32_t voff[U];  // a lane's byte offsets inside any row (clamped to the row's last vector: the masks beyond it are zero)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t v = (uint32_t)gl + LPR * u;
+    voff[u] = (v < last ? v : last) * 16;
+  }
+  uint4 m[MREG ? P : 1][MREG ? U : 1];
+  if constexpr (MREG) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int u = 0; u < U; ++u) m[p][u] = lm[(uint32_t)p * nvec_pad + (uint32_t)gl + LPR * u];
+  }
+  auto load_row = [&](uint4 (&dst)[U], size_t t, int s) {
+    const size_t rel = t * kTileRows + (size_t)grp * LPR + s;
+    const size_t row = A.row_begin + (rel < A.row_count ? rel : A.row_count - 1);  // rows past the end re-read the last one
+    const uint8_t* rp = mv.data + row * mv.pitch;
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[u] = load_stream(rp + voff[u]);
+  };
+  auto count_row = [&](const uint4 (&x)[U], int s, uint32_t (&alt_mine)[P]) {
+    if constexpr (!MREG) asm volatile("" ::: "memory");  // keep the mask reads inside the row (hoisted they are the P x U register image)
+    uint32_t alt[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      alt[p] = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if constexpr (MREG) alt[p] = popc128(and128(x[u], m[p][u]), alt[p]);
+        else alt[p] = popc128(and128(x[u], lm[(uint32_t)p * nvec_pad + (uint32_t)gl + LPR * u]), alt[p]);
+      }
+      alt[p] = group_sum<LPR>(alt[p]);
+    }
+    if (gl == s) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) alt_mine[p] = alt[p];
+    }
+  };
+  uint4 a[U], b[U];
+  load_row(a, tile, 0);
+  load_row(b, tile, 1);
+  for (; tile < ntiles; tile += tile_stride) {
+    const size_t nxt = tile + tile_stride < ntiles ? tile + tile_stride : tile;  // after the last tile: its own rows once more (L2 hits, unused)
+    uint32_t alt_mine[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) alt_mine[p] = 0;
+#pragma unroll
+    for (int s = 0; s < LPR; s += 2) {
+      count_row(a, s, alt_mine);
+      if (s + 2 < LPR) load_row(a, tile, s + 2); else load_row(a, nxt, s + 2 - LPR);
+      count_row(b, s + 1, alt_mine);
+      if (s + 3 < LPR) load_row(b, tile, s + 3); else load_row(b, nxt, s + 3 - LPR);
+    }
+    SiteTally<P> mine;
+    WcSite<P> wc;
+    double hud_dot = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { mine.n[p] = A.group_size[p]; mine.alt[p] = alt_mine[p]; mine.distinct[p] = 0; mine.ssq[p] = 0; }
+    mine.n_all = mv.columns;
+    if constexpr ((MODE & kModeWc) != 0) {
+      constexpr int NW = 1 + (P * (P - 1)) / 2;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) { wc.a[k] = 0.0; wc.b[k] = 0.0; }
+    }
+    finish_biallelic_site<P, MODE>(mine, hud_dot);
+    const size_t my_rel = tile * kTileRows + lane;
+    site_epilogue<P, MODE, false, false>(A, my_rel, my_rel < A.row_count, mine, hud_dot, wc, T);
+  }
+}
+
+template <int P, int MODE, int LPR>
+__global__ __launch_bounds__(kBlock) void sweep_kernel_pipe(const SweepArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const MatrixView mv = A.mv;
+  const uint32_t nvec = mv.nvec, nvec_pad = A.nvec_pad;
+  uint4* staged = reinterpret_cast<uint4*>(smem);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)P * nvec_pad; i += kBlock) {
+    const uint32_t p = i / nvec_pad, v = i - p * nvec_pad;
+    staged[i] = v < nvec ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(A.mask_bits) + (size_t)p * (A.mask_pitch / 8) + (size_t)v * 16)
+                         : make_uint4(0, 0, 0, 0);
+  }
+  if constexpr ((MODE & kModeWc) != 0) wc_rcp_init<P>(A);
+  __syncthreads();
+  LaneTotals<P, MODE> T;
+  T.clear();
+  if (A.unroll == 5) tiles_pipelined<P, MODE, 5, LPR>(A, mv, staged, nvec_pad, T);
+  else if (A.unroll == 3) tiles_pipelined<P, MODE, 3, LPR>(A, mv, staged, nvec_pad, T);
+  else if (A.unroll == 2) tiles_pipelined<P, MODE, 2, LPR>(A, mv, staged, nvec_pad, T);
+  else tiles_pipelined<P, MODE, 1, LPR>(A, mv, staged, nvec_pad, T);
   reduce_block_totals<P, MODE>(A, T);
 }
 

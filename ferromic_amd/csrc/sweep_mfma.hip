@@ -20,7 +20,7 @@ int launch_mfma(const SweepArgs& args, size_t smem, hipStream_t st, const Launch
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, smem));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
-    static const int env_occ = getenv("FMH_MAX_OCC") ? atoi(getenv("FMH_MAX_OCC")) : 0;
+    const int env_occ = (int)options().max_occ.load();
     if (env_occ > 0 && occ > env_occ) occ = env_occ;
     cached_occ[dev] = occ;
     cached_smem[dev] = smem;

@@ -8,7 +8,6 @@
 // and packed on the device: 8x the bytes on the wire.  No kernel is involved; nothing here computes a statistic.
 #include <hip/hip_runtime.h>
 
-#include <emmintrin.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -18,6 +17,7 @@
 
 #include "abi_internal.hpp"
 #include "host_cpus.hpp"
+#include "host_pack.hpp"
 
 using namespace fmhi;
 
@@ -34,75 +34,35 @@ struct Staging {
 };
 Staging g_staging[64];
 
-std::mutex g_staging_init;
-
-int staging(int device, Staging** out) {
-  if (device < 0 || device >= 64) return fail(FMH_ERR_INVALID, "device index %d unsupported", device);
-  Staging& s = g_staging[device];
-  std::lock_guard<std::mutex> init(g_staging_init);
-  if (!s.ready) {
-    for (int k = 0; k < 2; ++k) {
-      HIP_TRY(hipHostMalloc((void**)&s.pinned[k], kStageBytes, hipHostMallocDefault));
-      HIP_TRY(hipStreamCreateWithFlags(&s.stream[k], hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming));
-    }
-    s.ready = true;
+// Called with s.mu held (the uploader's lock, which upload_release takes too): `ready` is only ever read or written under it, so a
+// release cannot free the slabs between the check and their use.  A partial failure frees what was created.
+int ensure_staging(Staging& s) {
+  if (s.ready) return FMH_OK;
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipHostMalloc((void**)&s.pinned[k], kStageBytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream[k], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming);
   }
-  *out = &s;
+  if (e != hipSuccess) {
+    for (int k = 0; k < 2; ++k) {
+      if (s.pinned[k]) (void)hipHostFree(s.pinned[k]);
+      if (s.stream[k]) (void)hipStreamDestroy(s.stream[k]);
+      if (s.done[k]) (void)hipEventDestroy(s.done[k]);
+      s.pinned[k] = nullptr; s.stream[k] = nullptr; s.done[k] = nullptr;
+    }
+    (void)hipGetLastError();
+    return fail(e == hipErrorNoDevice ? FMH_ERR_NO_DEVICE : FMH_ERR_HIP, "pinned staging for uploads: %s", hipGetErrorString(e));
+  }
+  s.ready = true;
   return FMH_OK;
 }
 
 unsigned host_threads(size_t bytes) {
   if (bytes < ((size_t)2 << 20)) return 1;  // small matrices (run_vcf's many small regions): no thread start-up
   unsigned n = fmh_host::usable_cpus();
-  if (const char* e = getenv("FMH_UPLOAD_THREADS")) n = (unsigned)atoi(e);
+  if (const long long e = options().upload_threads.load(); e > 0) n = (unsigned)e;
   return std::max(1u, std::min(n, 16u));
-}
-
-// 8 bits of the missing bitset starting at bit `b` (LSB-first u64 words, stats.rs:1298-1302); bits past `total` read as 0
-inline uint32_t missing_bits16(const uint64_t* words, size_t b, size_t total) {
-  if (b >= total) return 0;
-  const size_t w = b >> 6, sh = b & 63, last = (total - 1) >> 6;
-  uint64_t v = words[w] >> sh;
-  if (sh > 48 && w < last) v |= words[w + 1] << (64 - sh);
-  const size_t left = total - b;
-  return (uint32_t)(left >= 16 ? (v & 0xFFFF) : (v & ((1ull << left) - 1)));
-}
-
-// rows [r0, r1) of the host matrix -> plane rows in `dst` (plane k at dst + k * rows_in_slab * pitch); returns true when a
-// CALLED entry carries a bit above the planes (a max_allele below the data)
-bool pack_rows_host(const uint8_t* data, const uint64_t* missing, size_t columns, size_t total_bits, size_t r0, size_t r1, int nplanes,
-                    bool with_called, uint8_t* dst, size_t slab_row0, size_t slab_rows, size_t pitch) {
-  const __m128i himask = _mm_set1_epi8((char)(nplanes >= 3 ? 0xF8 : (nplanes == 2 ? 0xFC : 0xFE)));
-  const __m128i zero = _mm_setzero_si128();
-  bool overflow = false;
-  uint8_t* planes[4] = {dst, dst + slab_rows * pitch, dst + 2 * slab_rows * pitch, dst + (size_t)nplanes * slab_rows * pitch};  // [nplanes] = called
-  for (size_t r = r0; r < r1; ++r) {
-    const uint8_t* row = data + r * columns;
-    const size_t o = (r - slab_row0) * pitch;
-    for (int k = 0; k < nplanes; ++k) memset(planes[k] + o, 0, pitch);
-    if (with_called) memset(planes[3] + o, 0, pitch);
-    for (size_t c = 0; c < columns; c += 16) {
-      __m128i v;
-      if (c + 16 <= columns) {
-        v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(row + c));
-      } else {  // ragged tail
-        alignas(16) uint8_t tmp[16] = {0};
-        memcpy(tmp, row + c, columns - c);
-        v = _mm_load_si128(reinterpret_cast<const __m128i*>(tmp));
-      }
-      uint32_t called = c + 16 <= columns ? 0xFFFFu : ((1u << (columns - c)) - 1u);
-      if (missing) called &= ~missing_bits16(missing, r * columns + c, total_bits);
-      const uint32_t high = 0xFFFFu ^ (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_and_si128(v, himask), zero));
-      overflow |= (high & called) != 0;
-      const uint16_t b0 = (uint16_t)_mm_movemask_epi8(_mm_slli_epi16(v, 7));
-      memcpy(planes[0] + o + (c >> 3), &b0, 2);
-      if (nplanes >= 2) { const uint16_t b1 = (uint16_t)_mm_movemask_epi8(_mm_slli_epi16(v, 6)); memcpy(planes[1] + o + (c >> 3), &b1, 2); }
-      if (nplanes >= 3) { const uint16_t b2 = (uint16_t)_mm_movemask_epi8(_mm_slli_epi16(v, 5)); memcpy(planes[2] + o + (c >> 3), &b2, 2); }
-      if (with_called) { const uint16_t bc = (uint16_t)called; memcpy(planes[3] + o + (c >> 3), &bc, 2); }
-    }
-  }
-  return overflow;
 }
 
 }  // namespace
@@ -112,9 +72,10 @@ int fmhi::upload_planes_from_bytes(fmh_matrix* m, const uint8_t* h_data, const u
   *overflow = false;
   if (m->variants == 0) return FMH_OK;
   FMH_TRY(use_device(m->device));
-  Staging* st = nullptr;
-  FMH_TRY(staging(m->device, &st));
+  if (m->device < 0 || m->device >= 64) return fail(FMH_ERR_INVALID, "device index %d unsupported", m->device);
+  Staging* st = &g_staging[m->device];
   std::lock_guard<std::mutex> lock(st->mu);
+  FMH_TRY(ensure_staging(*st));
   const int nplanes = m->p2 ? 3 : (m->p1 ? 2 : 1);
   const bool with_called = m->pc != nullptr;
   const size_t pitch = m->plane_pitch, per_row = (size_t)(nplanes + (with_called ? 1 : 0)) * pitch;
@@ -132,7 +93,7 @@ int fmhi::upload_planes_from_bytes(fmh_matrix* m, const uint8_t* h_data, const u
     uint8_t* dst = st->pinned[b];
     auto work = [&](unsigned t, unsigned n) {
       const size_t a = r0 + rows * t / n, e = r0 + rows * (t + 1) / n;
-      if (pack_rows_host(h_data, h_missing, m->columns, total_bits, a, e, nplanes, with_called, dst, r0, rows, pitch)) any_overflow = true;
+      if (fmh_host::pack_rows_host(h_data, h_missing, m->columns, total_bits, a, e, nplanes, with_called, dst, r0, rows, pitch)) any_overflow = true;
     };
     const unsigned n = (unsigned)std::min<size_t>(T, rows);
     if (n <= 1) {
@@ -180,7 +141,7 @@ void fmhi::upload_release(int device) {
     (void)hipHostFree(s.pinned[k]);
     (void)hipStreamDestroy(s.stream[k]);
     (void)hipEventDestroy(s.done[k]);
-    s.pinned[k] = nullptr;
+    s.pinned[k] = nullptr; s.stream[k] = nullptr; s.done[k] = nullptr;
   }
   s.ready = false;
 }

@@ -177,8 +177,10 @@ __global__ void pack_rows_kernel(const uint8_t* __restrict__ data, size_t pitch,
 }
 
 // planes -> bytes: one thread per (row, 16 columns); padding columns come out zero
-__global__ void unpack_rows_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2, size_t plane_pitch, size_t rows,
-                                   uint8_t* __restrict__ data, size_t pitch) {
+// (pc = called plane or null: the value bits of a missing entry are masked out, so that a download does not depend on which upload route
+// built the matrix - fmh_matrix_create_packed takes the caller's planes as they are)
+__global__ void unpack_rows_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2, const uint8_t* __restrict__ pc,
+                                   size_t plane_pitch, size_t rows, uint8_t* __restrict__ data, size_t pitch) {
   const size_t vecs = pitch / 16, total = rows * vecs;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const size_t row = idx / vecs;
@@ -188,6 +190,10 @@ __global__ void unpack_rows_kernel(const uint8_t* __restrict__ p0, const uint8_t
       lo = *reinterpret_cast<const uint16_t*>(p0 + row * plane_pitch + (size_t)v * 2);
       if (p1) hi = *reinterpret_cast<const uint16_t*>(p1 + row * plane_pitch + (size_t)v * 2);
       if (p2) top = *reinterpret_cast<const uint16_t*>(p2 + row * plane_pitch + (size_t)v * 2);
+      if (pc) {
+        const uint32_t c = *reinterpret_cast<const uint16_t*>(pc + row * plane_pitch + (size_t)v * 2);
+        lo &= c; hi &= c; top &= c;
+      }
     }
     uint4 a = called_bytes(lo);
     if (p1) {

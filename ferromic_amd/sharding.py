@@ -82,6 +82,23 @@ class Comm:
         _abi.check(_abi.load().fmh_allreduce_totals(self._h, f, nf, u, nu))
         return list(f)[:nf], [int(x) for x in u][:nu]
 
+    def describe(self) -> dict:
+        """fmh_comm_describe parsed: transport, world, rank, device, rccl_library, rccl_version, in_flight."""
+        buf = C.create_string_buffer(1024)
+        _abi.check(_abi.load().fmh_comm_describe(self._h, buf, len(buf)))
+        out = {}
+        for item in buf.value.decode("utf-8", "replace").split(" "):
+            if "=" in item:
+                k, v = item.split("=", 1)
+                out[k] = int(v) if v.lstrip("-").isdigit() else v
+            elif out:  # a path with blanks: glue it back on the previous value
+                last = list(out)[-1]
+                out[last] = f"{out[last]} {item}"
+        return out
+
+    def abort(self) -> None:
+        _abi.check(_abi.load().fmh_comm_abort(self._h))
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _abi.load().fmh_comm_destroy(self._h)

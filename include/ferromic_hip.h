@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FMH_ABI_VERSION 2
+#define FMH_ABI_VERSION 3
 #define FMH_MAX_GROUPS 8 /* populations per sweep */
 #define FMH_MAX_PAIRS 28 /* FMH_MAX_GROUPS choose 2 */
 
@@ -65,6 +65,20 @@ int fmh_device_count(int* h_count);
 /* name, CU count and total memory of a device (for reports) */
 int fmh_device_info(int device, char* h_name, size_t name_cap, int* h_compute_units, uint64_t* h_total_mem);
 
+/* ---- options ------------------------------------------------------------------------------------
+ * Per-process switches that route kernels or size launches (tests, measurements, and the two a deployment may want:
+ * FMH_LAYOUT and FMH_COMM_TRANSPORT).  Keys are the names of the environment variables of the same meaning; the FMH_*
+ * environment is read ONCE, when the library first needs an option, and never again - nothing on a launch path calls
+ * getenv - so a later change goes through fmh_set_option (value NULL = back to what the process
+ * started with: the environment's value, else the default; integers, or the words listed):
+ *   FMH_LAYOUT (bytes | packed)   FMH_MASK_MODE (1 | 2)   FMH_DEFER_TILES (1..16)   FMH_PACKED_LPR (4 | 16)   FMH_PACKED_UNROLL
+ *   FMH_PACKED_NO_PREFETCH   FMH_COUNTS_MFMA (1 | 2)   FMH_GRID_PER_CU   FMH_GRID_BLOCKS   FMH_MAX_OCC   FMH_UNROLL   FMH_PITCH_ALIGN
+ *   FMH_COMM_TRANSPORT (host | rccl)   FMH_UPLOAD_THREADS   FMH_PD_TWO_PLANES   FMH_PD_INT8   FMH_PD_PLANES_BYTES   FMH_PD_KCHUNK
+ *   FMH_PD_SB   FMH_PD_OCC   FMH_WC_VARIANT   FMH_GRAPH
+ * Values are atomics: setting one while another thread launches is safe (that launch sees the old or the new value). */
+int fmh_set_option(const char* key, const char* value_or_null);
+int fmh_get_option(const char* key, long long* h_value);
+
 /* ---- raw device memory helpers for hosts that do not bring their own allocator --------------- */
 int fmh_device_alloc(int device, size_t bytes, void** d_out);
 /* Blocks are recycled through a pool without stream ordering: the caller's outstanding stream work on the block must be
@@ -90,8 +104,9 @@ int fmh_device_release_scratch(int device);
  * staging, so that only the planes cross PCIe.  Other matrices
  * (max_allele > 7, rows beyond 600 000 columns, FMH_LAYOUT=bytes) keep the u8 rows, padded to a 16-byte pitch, with the
  * missing bitset re-laid as one "called" bit-row per site.  A called value above max_allele is a caller error: the packed
- * layout would lose its high bits, so fmh_matrix_create / fmh_matrix_pack detect it on the device and return
- * FMH_ERR_INVALID (the u8 layout keeps the bytes as they are and only uses max_allele as a loop bound).
+ * layout would lose its high bits, so fmh_matrix_create (while it packs the rows on the host) and fmh_matrix_pack (on the
+ * device) detect it and return FMH_ERR_INVALID; the u8 layout keeps the bytes as they are and only uses max_allele as a
+ * loop bound.  fmh_matrix_create_packed takes the caller's planes at their word.
  */
 int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing_or_null, size_t variants,
                       size_t samples, size_t ploidy, uint8_t max_allele, int device, fmh_matrix** out);
@@ -125,7 +140,8 @@ int fmh_matrix_info(const fmh_matrix* m, size_t* variants, size_t* samples, size
 /* the u8 rows and called bit-rows; NULL for a matrix that holds only its packed image */
 int fmh_matrix_device_ptrs(const fmh_matrix* m, void** d_data, void** d_called_bits);
 /* Copy back in the reference host layout (tests / oracle). h_missing_or_null must hold
- * ceil(variants*stride/64) words when the matrix has a mask. */
+ * ceil(variants*stride/64) words when the matrix has a mask.  The byte of a MISSING entry is 0 whichever route built the
+ * matrix (the planes of a missing entry are masked with the called plane on the way out). */
 int fmh_matrix_download(const fmh_matrix* m, uint8_t* h_data, uint64_t* h_missing_or_null);
 /* max over called entries, computed on the device (what from_variants computes at stats.rs:490) */
 int fmh_matrix_scan_max_allele(const fmh_matrix* m, uint8_t* h_max, void* stream);
@@ -308,6 +324,13 @@ int fmh_comm_init_local(int device, fmh_comm** out);
 int fmh_comm_destroy(fmh_comm* c);
 /* transport: 0 = RCCL, 1 = in-process host rendezvous, 2 = local (one rank, nothing to exchange) */
 int fmh_comm_info(const fmh_comm* c, int* world, int* rank, int* device, int* transport);
+/* One line for reports: "transport=rccl world=8 rank=3 device=3 rccl_library=<file the process bound> rccl_version=<ncclGetVersion> ..." */
+int fmh_comm_describe(const fmh_comm* c, char* h_text, size_t cap);
+/* For a rank that FAILED before its collective (allocation, upload, validation): wakes the peers of an in-process group, which return
+ * FMH_ERR_INVALID from the collective they are waiting in instead of blocking for ever, and aborts the RCCL communicator
+ * (ncclCommAbort).  The communicator only accepts fmh_comm_destroy afterwards.  Every sharded _begin validates its arguments before
+ * it enqueues anything, so a rank whose _begin returned an error has not entered the collective and may call this. */
+int fmh_comm_abort(fmh_comm* c);
 
 /* Element-wise sum over all ranks, in place, blocking (collective: every rank calls it with the same lengths;
  * n_f64, n_u64 <= FMH_COMM_MAX_VALUES). */
@@ -334,6 +357,26 @@ int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_g
 int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* h_global_totals);
 int fmh_hudson_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
                              int formula, const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_global_totals, void* stream);
+
+/*
+ * The same pipeline for the other two regional reductions north_star names ("RCCL reduce ... for the sum-a / sum-b and global pi
+ * accumulators"): sweep -> finalise on the device -> grouped ncclAllReduce of the 64 + 64 accumulators on the communicator's stream ->
+ * one D2H; no host hop, FMH_SHARDED_IN_FLIGHT sweeps of ANY kind may be in flight per communicator and each _end collects the oldest
+ * (it must be of its kind).  W&C: calculate_overall_fst_wc's sums (stats.rs:2145-2374) - two to four groups run as one fused kernel; five
+ * to eight groups, or rows too wide for all masks, run the blocking fmh_wc_sweep inside _begin and only the reduce is pipelined.
+ * Population summaries: build_dense_population_summary's scalars (stats.rs:1367-1470) for up to FMH_MAX_GROUPS populations.
+ * Per-site tracks stay on the rank that owns the rows; haplotype_capacity is the local mask popcount (identical on every rank).
+ */
+int fmh_wc_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a,
+                               double* d_b, uint8_t* d_state, uint32_t* d_group_called, void* stream);
+int fmh_wc_sweep_sharded_end(fmh_comm* c, fmh_wc_totals* h_global_totals);
+int fmh_wc_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, double* d_a, double* d_b,
+                         uint8_t* d_state, uint32_t* d_group_called, fmh_wc_totals* h_global_totals, void* stream);
+int fmh_population_summaries_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
+                                           int formula, uint32_t* d_alt, uint32_t* d_called, void* stream);
+int fmh_population_summaries_sharded_end(fmh_comm* c, fmh_pop_totals* h_global_totals /*[n_groups]*/);
+int fmh_population_summaries_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int formula,
+                                     uint32_t* d_alt, uint32_t* d_called, fmh_pop_totals* h_global_totals, void* stream);
 
 /*
  * Packing of the totals structs into the f64 + u64 vectors a sum-reduce moves (fmh_allreduce_totals, or MPI / any other
@@ -366,6 +409,10 @@ int fmh_wc_totals_unpack(fmh_wc_totals* t, int n_groups, const double* h_f64, co
 int fmh_timing_enable(int on);
 int fmh_timing_reset(void);
 int fmh_timing_read(double* h_total_ms, uint64_t* h_launches);
+/* The same for the grouped all-reduce of the timed sharded sweeps (RCCL transport): HIP events on the communicator's stream around
+ * ncclGroupStart .. ncclGroupEnd - the device-side latency of one 2 x 512-byte reduce. */
+int fmh_timing_read_reduce(double* h_total_ms, uint64_t* h_reduces);
+int fmh_timing_reset_reduce(void);
 
 #ifdef __cplusplus
 }

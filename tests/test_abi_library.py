@@ -36,7 +36,7 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(lib, name), f"{name} declared in include/ferromic_hip.h but not exported"
         assert name in _abi.SYMBOLS, f"{name} has no ctypes prototype in ferromic_amd/_abi.py"
     assert sorted(_abi.SYMBOLS) == names
-    assert lib.fmh_abi_version() == 2
+    assert lib.fmh_abi_version() == 3
 
 
 def test_struct_layouts_match_header(lib):
@@ -138,3 +138,47 @@ def test_comm_and_packing_entry_points_without_a_gpu(lib):
         assert lib.fmh_comm_get_unique_id(buf) == _abi.FMH_ERR_NO_DEVICE
         h = C.c_void_p()
         assert lib.fmh_comm_init_all((C.c_int * 2)(0, 0), 2, (C.c_void_p * 2)()) != 0
+
+
+def test_options_are_set_through_the_abi_not_the_environment(lib):
+    """fmh_set_option / fmh_get_option (no GPU needed): integers and the listed words parse, NULL restores what the process started with,
+    unknown keys and garbage are refused, and the FMH_* environment is read once - a later os.environ change is NOT seen, a child
+    process started with the variable set sees it as its initial value."""
+    import subprocess
+    import sys
+
+    from ferromic_amd import _abi
+
+    assert _abi.get_option("FMH_DEFER_TILES") == 0 and _abi.get_option("FMH_MASK_MODE") == -1 and _abi.get_option("FMH_LAYOUT") == 0
+    _abi.set_option("FMH_LAYOUT", "bytes")
+    assert _abi.get_option("FMH_LAYOUT") == 1
+    _abi.set_option("FMH_LAYOUT", "packed")
+    assert _abi.get_option("FMH_LAYOUT") == 0
+    with _abi.options(FMH_DEFER_TILES=7, FMH_GRID_BLOCKS=3):
+        assert _abi.get_option("FMH_DEFER_TILES") == 7 and _abi.get_option("FMH_GRID_BLOCKS") == 3
+    assert _abi.get_option("FMH_DEFER_TILES") == 0 and _abi.get_option("FMH_GRID_BLOCKS") == 0
+    assert lib.fmh_set_option(b"FMH_NO_SUCH_SWITCH", b"1") == _abi.FMH_ERR_INVALID and b"unknown option" in lib.fmh_last_error()
+    assert lib.fmh_set_option(b"FMH_DEFER_TILES", b"deep") == _abi.FMH_ERR_INVALID
+    assert lib.fmh_set_option(None, b"1") == _abi.FMH_ERR_INVALID
+    os.environ["FMH_GRID_PER_CU"] = "5"  # after the snapshot: ignored
+    try:
+        assert _abi.get_option("FMH_GRID_PER_CU") == 0
+        code = ("from ferromic_amd import _abi; print(_abi.get_option('FMH_GRID_PER_CU'), _abi.get_option('FMH_LAYOUT'), _abi.get_option('FMH_COMM_TRANSPORT'));"
+                "_abi.set_option('FMH_GRID_PER_CU', 2); _abi.set_option('FMH_GRID_PER_CU', None); print(_abi.get_option('FMH_GRID_PER_CU'))")
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                             env=dict(os.environ, FMH_LAYOUT="bytes", FMH_COMM_TRANSPORT="host"))
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert res.stdout.split() == ["5", "1", "1", "5"], res.stdout
+    finally:
+        del os.environ["FMH_GRID_PER_CU"]
+
+
+def test_no_getenv_on_the_launch_path():
+    """The kernel-routing sources read no environment variable: every switch is an option (abi_internal.hpp Options)."""
+    csrc = os.path.join(ROOT, "ferromic_amd", "csrc")
+    for name in ("sweep_launch.inc", "sweep_mfma.hip", "pairwise.hip", "upload.hip", "abi_internal.hpp"):
+        with open(os.path.join(csrc, name)) as fh:
+            assert "getenv" not in fh.read(), name
+    with open(os.path.join(csrc, "abi.hip")) as fh:
+        text = fh.read()
+    assert text.count("getenv(") == 1, "abi.hip reads the environment in options() only"

@@ -165,3 +165,178 @@ def test_host_transport_slabs_equal_whole(ranks):
         assert out[r][0].numerator_sum == out[0][0].numerator_sum and out[r][1].sum_a[0] == out[0][1].sum_a[0]
     for c in comms:
         c.close()
+
+
+def _wc_equal(a, b, slots, rel):
+    assert a.sites_attempted == b.sites_attempted
+    for k in range(slots):
+        assert a.informative_sites[k] == b.informative_sites[k], k
+        if rel == 0.0:
+            assert a.sum_a[k] == b.sum_a[k] and a.sum_b[k] == b.sum_b[k], k
+        else:
+            assert a.sum_a[k] == pytest.approx(b.sum_a[k], rel=rel, abs=1e-13) and a.sum_b[k] == pytest.approx(b.sum_b[k], rel=rel, abs=1e-13), k
+
+
+def test_rccl_collective_path_with_one_rank():
+    """The device-side sharded W&C and population-summaries sweeps on a one-rank RCCL group equal the plain calls bit for bit (same
+    kernel, same grid, a sum over one rank); the communicator describes itself; the reduce latency is measured; mixed kinds
+    pipeline in FIFO order and an _end of the wrong kind is refused."""
+    from ferromic_amd import _abi, device, sharding
+
+    lib = _abi.load()
+    comm = sharding.Comm.single(0)
+    d = comm.describe()
+    assert d["transport"] == "rccl" and d["world"] == 1 and d["rank"] == 0 and d["device"] == 0 and d["in_flight"] == 2
+    assert "rccl" in str(d["rccl_library"]).lower() and str(d["rccl_version"]).isdigit(), d
+    S, N = 40_001, 130
+    for (G, max_allele, missing) in ((4, 1, 0.0), (3, 1, 0.02), (2, 3, 0.01), (6, 1, 0.0)):
+        rng = np.random.default_rng(G * 100 + max_allele)
+        data, words = _cohort(S, N, 17 + G, missing=missing)
+        if max_allele > 1:
+            data = (data * rng.integers(1, max_allele + 1, size=data.shape)).astype(np.uint8)
+        dm = device.DeviceMatrix.from_host(data, words, S, N, 2, max_allele)
+        masks = np.zeros((G, 2 * N), np.uint8)
+        for k in range(G):
+            masks[k, 2 * (k * N // G):2 * ((k + 1) * N // G)] = 1
+        g = device.Groups(dm, masks)
+        slots = 1 + G * (G - 1) // 2
+        plain_w, got_w = _abi.WcTotals(), _abi.WcTotals()
+        da, db = device.DeviceBuffer(0, 8 * slots * S), device.DeviceBuffer(0, 8 * slots * S)
+        _abi.check(lib.fmh_wc_sweep(dm._h, g._h, 0, S, da.ptr, db.ptr, None, None, C.byref(plain_w), None))
+        a_plain = da.to_numpy(np.float64, slots * S)
+        _abi.check(lib.fmh_wc_sweep_sharded(comm._h, dm._h, g._h, 0, S, da.ptr, db.ptr, None, None, C.byref(got_w), None))
+        _wc_equal(got_w, plain_w, slots, 0.0)
+        assert np.array_equal(da.to_numpy(np.float64, slots * S), a_plain, equal_nan=True)
+        plain_p, got_p = (_abi.PopTotals * G)(), (_abi.PopTotals * G)()
+        _abi.check(lib.fmh_population_summaries(dm._h, g._h, 0, S, _abi.FORMULA_SUMMARY, None, None, plain_p, None))
+        _abi.check(lib.fmh_population_summaries_sharded(comm._h, dm._h, g._h, 0, S, _abi.FORMULA_SUMMARY, None, None, got_p, None))
+        for p in range(G):
+            for k, _ in _abi.PopTotals._fields_:
+                assert getattr(got_p[p], k) == getattr(plain_p[p], k), (G, p, k)
+        # two kinds in flight: collected oldest first, by their own _end only
+        half = S // 2
+        _abi.check(lib.fmh_wc_sweep_sharded_begin(comm._h, dm._h, g._h, 0, half, None, None, None, None, None))
+        _abi.check(lib.fmh_population_summaries_sharded_begin(comm._h, dm._h, g._h, half, S - half, _abi.FORMULA_SUMMARY, None, None, None))
+        assert lib.fmh_population_summaries_sharded_end(comm._h, got_p) == _abi.FMH_ERR_INVALID and b"W&C" in lib.fmh_last_error()
+        assert lib.fmh_hudson_sweep_sharded_end(comm._h, None) == _abi.FMH_ERR_INVALID
+        w1 = _abi.WcTotals()
+        _abi.check(lib.fmh_wc_sweep_sharded_end(comm._h, C.byref(w1)))
+        _abi.check(lib.fmh_population_summaries_sharded_end(comm._h, got_p))
+        w2 = _abi.WcTotals()
+        _abi.check(lib.fmh_wc_sweep_sharded(comm._h, dm._h, g._h, half, S - half, None, None, None, None, C.byref(w2), None))
+        assert w1.sites_attempted == half and w2.sites_attempted == S - half
+        for k in range(slots):
+            assert w1.informative_sites[k] + w2.informative_sites[k] == plain_w.informative_sites[k]
+            assert w1.sum_a[k] + w2.sum_a[k] == pytest.approx(plain_w.sum_a[k], rel=1e-11, abs=1e-13)
+        # an empty slab takes part with zeros
+        _abi.check(lib.fmh_wc_sweep_sharded(comm._h, dm._h, g._h, 5, 0, None, None, None, None, C.byref(w2), None))
+        assert w2.sites_attempted == 0 and w2.informative_sites[0] == 0 and w2.sum_a[0] == 0.0
+    # the reduce is timed with events on the communicator's stream when sweeps are timed
+    lib.fmh_timing_enable(1)
+    lib.fmh_timing_reset()
+    lib.fmh_timing_reset_reduce()
+    for _ in range(5):
+        _abi.check(lib.fmh_population_summaries_sharded(comm._h, dm._h, g._h, 0, S, _abi.FORMULA_SUMMARY, None, None, got_p, None))
+    ms, n = C.c_double(), C.c_uint64()
+    lib.fmh_timing_read_reduce(C.byref(ms), C.byref(n))
+    lib.fmh_timing_enable(0)
+    assert n.value == 5 and 0.0 < ms.value < 1000.0, (n.value, ms.value)
+    # refusals happen before anything is enqueued
+    assert lib.fmh_wc_sweep_sharded_begin(comm._h, dm._h, g._h, S, 1, None, None, None, None, None) == _abi.FMH_ERR_INVALID
+    one = device.Groups(dm, masks[:1])
+    assert lib.fmh_wc_sweep_sharded_begin(comm._h, dm._h, one._h, 0, S, None, None, None, None, None) == _abi.FMH_ERR_INVALID
+    _abi.check(lib.fmh_population_summaries_sharded(comm._h, dm._h, g._h, 0, S, _abi.FORMULA_SUMMARY, None, None, got_p, None))  # still usable
+    comm.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_host_transport_device_side_wc_and_summaries(ranks):
+    """fmh_wc_sweep_sharded / fmh_population_summaries_sharded over `ranks` slab matrices (in-process transport) equal the whole
+    matrix: integers exactly, f64 sums to 1e-11 (the rank-order sum differs from the one-grid order), for 2..4 groups (one fused
+    kernel) and 5 groups (the blocking route inside _begin)."""
+    from ferromic_amd import _abi, device, sharding
+
+    lib = _abi.load()
+    S, N = 30_011, 100
+    data, words = _cohort(S, N, 23 + ranks, missing=0.02)
+    miss_bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:S * 2 * N].reshape(S, 2 * N)
+    whole = device.DeviceMatrix.from_host(data, words, S, N, 2, 1)
+    comms = sharding.Comm.init_all([0] * ranks)
+    for G in (2, 4, 5):
+        masks = np.zeros((G, 2 * N), np.uint8)
+        for k in range(G):
+            masks[k, 2 * (k * N // G):2 * ((k + 1) * N // G)] = 1
+        gw = device.Groups(whole, masks)
+        slots = 1 + G * (G - 1) // 2
+        ref_w, ref_p = _abi.WcTotals(), (_abi.PopTotals * G)()
+        _abi.check(lib.fmh_wc_sweep(whole._h, gw._h, 0, S, None, None, None, None, C.byref(ref_w), None))
+        _abi.check(lib.fmh_population_summaries(whole._h, gw._h, 0, S, _abi.FORMULA_SPARSE, None, None, ref_p, None))
+        out, errors = [None] * ranks, []
+
+        def work(r):
+            try:
+                b, e = sharding.slab_for_rank(S, r, ranks)
+                w = np.packbits(miss_bits[b:e].reshape(-1), bitorder="little")
+                w = np.frombuffer(np.pad(w, (0, (-w.size) % 8)).tobytes(), dtype="<u8").copy()
+                dm = device.DeviceMatrix.from_host(data[b:e], w, e - b, N, 2, 1)
+                g = device.Groups(dm, masks)
+                wc, pt = _abi.WcTotals(), (_abi.PopTotals * G)()
+                # both enqueued before either is collected: the two reduces travel back to back
+                _abi.check(lib.fmh_wc_sweep_sharded_begin(comms[r]._h, dm._h, g._h, 0, e - b, None, None, None, None, None))
+                _abi.check(lib.fmh_population_summaries_sharded_begin(comms[r]._h, dm._h, g._h, 0, e - b, _abi.FORMULA_SPARSE, None, None, None))
+                _abi.check(lib.fmh_wc_sweep_sharded_end(comms[r]._h, C.byref(wc)))
+                _abi.check(lib.fmh_population_summaries_sharded_end(comms[r]._h, pt))
+                out[r] = (wc, pt)
+            except Exception as exc:  # noqa: BLE001
+                errors.append((r, exc))
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(ranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        for r in range(ranks):
+            wc, pt = out[r]
+            _wc_equal(wc, ref_w, slots, 1e-11)
+            assert wc.sites_attempted == S
+            for p in range(G):
+                assert (pt[p].segregating_sites, pt[p].uncallable_sites, pt[p].haplotype_capacity) == \
+                       (ref_p[p].segregating_sites, ref_p[p].uncallable_sites, ref_p[p].haplotype_capacity)
+                assert pt[p].pi_sum == pytest.approx(ref_p[p].pi_sum, rel=1e-12)
+        for r in range(1, ranks):  # rank-order summation: every rank leaves with the same bits
+            assert out[r][0].sum_a[0] == out[0][0].sum_a[0] and out[r][1][0].pi_sum == out[0][1][0].pi_sum
+    for c in comms:
+        c.close()
+
+
+def test_abort_wakes_the_peers_instead_of_hanging():
+    """A rank that fails before its collective calls fmh_comm_abort: the peers blocked in the in-process rendezvous return an error
+    (they used to wait for ever), and every later collective on the group is refused."""
+    import time
+
+    from ferromic_amd import _abi, sharding
+
+    lib = _abi.load()
+    comms = sharding.Comm.init_all([0, 0, 0])
+    results = {}
+
+    def waiter(r):
+        f, u = (C.c_double * 2)(1.0, 2.0), (C.c_uint64 * 1)(3)
+        results[r] = (lib.fmh_allreduce_totals(comms[r]._h, f, 2, u, 1), lib.fmh_last_error())
+
+    threads = [threading.Thread(target=waiter, args=(r,)) for r in (0, 2)]
+    for t in threads:
+        t.start()
+    time.sleep(0.3)  # both are inside the rendezvous, waiting for rank 1
+    assert all(t.is_alive() for t in threads)
+    comms[1].abort()  # rank 1 "failed" before its collective
+    for t in threads:
+        t.join(timeout=30)
+    assert not any(t.is_alive() for t in threads), "peers still blocked after fmh_comm_abort"
+    for r in (0, 2):
+        assert results[r][0] == _abi.FMH_ERR_INVALID and b"aborted by rank 1" in results[r][1], results[r]
+    f, u = (C.c_double * 1)(1.0), (C.c_uint64 * 1)(1)
+    assert lib.fmh_allreduce_totals(comms[0]._h, f, 1, u, 1) == _abi.FMH_ERR_INVALID
+    for c in comms:
+        c.close()

@@ -330,7 +330,7 @@ def test_rows_wider_than_lds_for_all_masks(dev):
             k4 += 1
 
 
-def test_mask_routes_agree(dev, monkeypatch):
+def test_mask_routes_agree(dev, fmh_opts):
     """The sweep keeps the group masks as bytes in LDS, as bits in LDS (rows too wide for bytes) or as bytes in global
     memory (rows too wide for bits); FMH_MASK_MODE forces the slower routes on rows that do not need them.  All three
     must give the same bits, with and without missing calls, on the biallelic and the general counting paths."""
@@ -352,10 +352,10 @@ def test_mask_routes_agree(dev, monkeypatch):
             ps = dev.population_summaries(dm, g3, dev.FORMULA_SUMMARY)
             return hs, dv, w, ps
 
-        monkeypatch.delenv("FMH_MASK_MODE", raising=False)
+        fmh_opts.delenv("FMH_MASK_MODE", raising=False)
         base = run()
         for forced in ("2", "1"):
-            monkeypatch.setenv("FMH_MASK_MODE", forced)
+            fmh_opts.setenv("FMH_MASK_MODE", forced)
             got = run()
             for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
                 H.assert_bits_equal(got[0].sites[k], base[0].sites[k], f"{k} mode {forced}")
@@ -366,10 +366,10 @@ def test_mask_routes_agree(dev, monkeypatch):
             assert np.array_equal(got[2].state, base[2].state) and np.array_equal(got[2].group_called, base[2].group_called)
             assert np.array_equal(got[3].alt, base[3].alt) and np.array_equal(got[3].called, base[3].called)
             assert got[3].totals == base[3].totals
-        monkeypatch.delenv("FMH_MASK_MODE", raising=False)
+        fmh_opts.delenv("FMH_MASK_MODE", raising=False)
 
 
-def test_deferred_epilogues_are_the_same_bits(dev, monkeypatch):
+def test_deferred_epilogues_are_the_same_bits(dev, fmh_opts):
     """The biallelic kernels with one, two (and, packed, four) groups count several of a wave's tiles before they run those tiles' epilogues
     (DESIGN.md section 3 "Deferred epilogues"; depth chosen per launch, FMH_DEFER_TILES forces it).  The tiles a wave takes and their order
     are the same at every depth, so every per-site value AND every regional total must be the same bits as the undeferred order - checked
@@ -381,9 +381,9 @@ def test_deferred_epilogues_are_the_same_bits(dev, monkeypatch):
     for (S, N, p_missing, layout) in cases:
         m = H.random_dense_matrix(rng, S, N, 2, 1, p_missing)
         if layout == "bytes":
-            monkeypatch.setenv("FMH_LAYOUT", "bytes")
+            fmh_opts.setenv("FMH_LAYOUT", "bytes")
         dm = upload(dev, m)
-        monkeypatch.delenv("FMH_LAYOUT", raising=False)
+        fmh_opts.delenv("FMH_LAYOUT", raising=False)
         cut = N // 3
         lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, N - 2))]
         quarters = [H.haps_for_samples(range(i, N, 4)) for i in range(4)]
@@ -394,11 +394,11 @@ def test_deferred_epilogues_are_the_same_bits(dev, monkeypatch):
                     dev.population_summaries(dm, g4, dev.FORMULA_SUMMARY), dev.wc_sweep(dm, g4), dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE, 7, S - 11))
 
         for blocks in ("1", "3"):
-            monkeypatch.setenv("FMH_GRID_BLOCKS", blocks)
-            monkeypatch.setenv("FMH_DEFER_TILES", "1")
+            fmh_opts.setenv("FMH_GRID_BLOCKS", blocks)
+            fmh_opts.setenv("FMH_DEFER_TILES", "1")
             base = run()
             for depth in ("2", "5", "16"):
-                monkeypatch.setenv("FMH_DEFER_TILES", depth)
+                fmh_opts.setenv("FMH_DEFER_TILES", depth)
                 got = run()
                 what = f"{S}x{N} {layout} missing {p_missing} blocks {blocks} depth {depth}"
                 for i in (0, 5):
@@ -413,14 +413,14 @@ def test_deferred_epilogues_are_the_same_bits(dev, monkeypatch):
                     assert np.array_equal(got[i].alt, base[i].alt) and np.array_equal(got[i].called, base[i].called) and got[i].totals == base[i].totals, what
                 assert np.array_equal(got[4].a, base[4].a, equal_nan=True) and np.array_equal(got[4].b, base[4].b, equal_nan=True), what
                 assert np.array_equal(got[4].state, base[4].state) and np.array_equal(got[4].sum_a, base[4].sum_a) and np.array_equal(got[4].sum_b, base[4].sum_b), what
-            monkeypatch.delenv("FMH_DEFER_TILES")
-        monkeypatch.delenv("FMH_GRID_BLOCKS")
+            fmh_opts.delenv("FMH_DEFER_TILES")
+        fmh_opts.delenv("FMH_GRID_BLOCKS")
         exp = R.build_dense_population_summary(m, lists[0])
         assert np.array_equal(base[0].sites["alt"][0], np.array(exp.alt_counts, dtype=np.uint32))
         assert np.array_equal(base[0].sites["called"][0], np.array(exp.called_counts, dtype=np.uint32))
 
 
-def test_matrix_core_counting_route_agrees(dev, monkeypatch):
+def test_matrix_core_counting_route_agrees(dev, fmh_opts):
     """BASELINE config C5: the counts as an int8 MFMA contraction (FMH_COUNTS_MFMA, u8 rows, biallelic, nothing missing).  Same
     integers as the dot4 route, the same epilogue code after them: every track and total must be the same bits - and against
     the oracle on the counts themselves.  Shapes exercise ragged K (columns not a multiple of 16 / 64 / 256), tiles with rows
@@ -428,7 +428,7 @@ def test_matrix_core_counting_route_agrees(dev, monkeypatch):
     from oracle import ferromic_ref as R
 
     rng = np.random.default_rng(90210)
-    monkeypatch.setenv("FMH_LAYOUT", "bytes")
+    fmh_opts.setenv("FMH_LAYOUT", "bytes")
     for (S, N) in ((70, 900), (129, 37), (64, 128), (1000, 1301), (3, 8), (257, 5000)):
         m = H.random_dense_matrix(rng, S, N, 2, 1, 0.0)
         dm = upload(dev, m)
@@ -450,12 +450,12 @@ def test_matrix_core_counting_route_agrees(dev, monkeypatch):
             ps = dev.population_summaries(dm, g4, dev.FORMULA_SUMMARY)
             return hs, hr, dv, w3, w4, w2, ps
 
-        monkeypatch.delenv("FMH_COUNTS_MFMA", raising=False)
+        fmh_opts.delenv("FMH_COUNTS_MFMA", raising=False)
         base = run()
         s1 = R.build_dense_population_summary(m, lists[0])
         assert np.array_equal(base[0].sites["alt"][0], np.array(s1.alt_counts, dtype=np.uint32))
         for unroll in ("1", "2"):
-            monkeypatch.setenv("FMH_COUNTS_MFMA", unroll)
+            fmh_opts.setenv("FMH_COUNTS_MFMA", unroll)
             got = run()
             for i in (0, 1):
                 for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
@@ -471,7 +471,7 @@ def test_matrix_core_counting_route_agrees(dev, monkeypatch):
                 assert np.array_equal(got[i].informative_sites, base[i].informative_sites)
             assert np.array_equal(got[6].alt, base[6].alt) and np.array_equal(got[6].called, base[6].called)
             assert got[6].totals == base[6].totals
-        monkeypatch.delenv("FMH_COUNTS_MFMA", raising=False)
+        fmh_opts.delenv("FMH_COUNTS_MFMA", raising=False)
 
 
 def test_eight_groups_on_rows_beyond_the_bit_mask_budget(dev):
@@ -508,7 +508,7 @@ def test_eight_groups_on_rows_beyond_the_bit_mask_budget(dev):
         assert np.array_equal(got.called[g], np.array(exp.called_counts, dtype=np.uint32))
 
 
-def test_packed_and_byte_layouts_agree(dev, monkeypatch):
+def test_packed_and_byte_layouts_agree(dev, fmh_opts):
     """A generated cohort is swept from its u8 rows (FMH_LAYOUT=bytes), from the bit-packed image next to them, and from
     the packed image alone (bytes released); every output must be the same bits.  Then the packed-only matrix is
     downloaded (unpack), scanned for its max allele and sent through the pairwise Gram (unpack staging)."""
@@ -516,9 +516,9 @@ def test_packed_and_byte_layouts_agree(dev, monkeypatch):
     for (S, N, max_allele, p_missing) in ((300, 700, 1, 0.0), (257, 333, 1, 0.04), (130, 1100, 3, 0.0), (90, 260, 2, 0.1), (70, 40, 3, 0.02),
                                           (150, 900, 7, 0.0), (97, 333, 5, 0.06), (64, 2700, 4, 0.01), (40, 70, 6, 0.0)):  # three planes
         m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
-        monkeypatch.setenv("FMH_LAYOUT", "bytes")
+        fmh_opts.setenv("FMH_LAYOUT", "bytes")
         dm = upload(dev, m)                       # u8 rows only
-        monkeypatch.delenv("FMH_LAYOUT")
+        fmh_opts.delenv("FMH_LAYOUT")
         cut = N // 3
         lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, N - 3))]
         thirds = [H.haps_for_samples(range(i, N, 3)) for i in range(3)]
@@ -549,14 +549,14 @@ def test_packed_and_byte_layouts_agree(dev, monkeypatch):
         dm.pack()                                  # packed image next to the bytes: the sweeps switch to it
         same(run())
         for lpr, unroll in (("4", "1"), ("4", "5"), ("16", "2"), ("16", "4")):   # both lane layouts of the packed cores, odd batch depths
-            monkeypatch.setenv("FMH_PACKED_LPR", lpr)
-            monkeypatch.setenv("FMH_PACKED_UNROLL", unroll)
+            fmh_opts.setenv("FMH_PACKED_LPR", lpr)
+            fmh_opts.setenv("FMH_PACKED_UNROLL", unroll)
             same(run())
-        monkeypatch.delenv("FMH_PACKED_LPR")
-        monkeypatch.delenv("FMH_PACKED_UNROLL")
-        monkeypatch.setenv("FMH_LAYOUT", "bytes")  # ... unless told otherwise
+        fmh_opts.delenv("FMH_PACKED_LPR")
+        fmh_opts.delenv("FMH_PACKED_UNROLL")
+        fmh_opts.setenv("FMH_LAYOUT", "bytes")  # ... unless told otherwise
         same(run())
-        monkeypatch.delenv("FMH_LAYOUT")
+        fmh_opts.delenv("FMH_LAYOUT")
         dm.pack(release_bytes=True)                # packed image alone
         same(run())
         host_after = dm.download()
@@ -643,11 +643,10 @@ def test_upload_routes_agree(dev, S, N, max_allele, p_missing):
     data = np.frombuffer(m.data, dtype=np.uint8).reshape(S, cols)
     words = H.missing_words_np(m)
     a = upload(dev, m)                                     # host-packed
-    os.environ["FMH_LAYOUT"] = "bytes"
-    try:
+    from ferromic_amd import _abi
+
+    with _abi.options(FMH_LAYOUT="bytes"):
         b = upload(dev, m)                                 # u8 rows on the device ...
-    finally:
-        del os.environ["FMH_LAYOUT"]
     b.pack(release_bytes=True)                             # ... packed there
     nplanes = 1 if m.max_allele <= 1 else (2 if m.max_allele <= 3 else 3)
     pitch = (cols + 7) // 8 + 5                            # a host pitch of its own

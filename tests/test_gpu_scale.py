@@ -228,7 +228,7 @@ def test_c3_full_size(dev):
     assert H.rel_close(float(w.sum_a[0] / (w.sum_a[0] + w.sum_b[0])), float(exp.sum_a[0] / (exp.sum_a[0] + exp.sum_b[0])))
 
 
-def test_c5_full_size(dev, monkeypatch):
+def test_c5_full_size(dev, fmh_opts):
     """BASELINE config C5 at its full size - 2 M sites x 10 000 haplotypes, 2 populations, pi + Hudson - through all three counting
     routes: int8 MFMA contraction on u8 rows (the route the config names), v_dot4 on u8 rows, popcounts on the packed planes; each
     against the C oracle on the same cohort regenerated on the host: counts and all six f64 tracks bit for bit at every site,
@@ -258,8 +258,8 @@ def test_c5_full_size(dev, monkeypatch):
         assert got.totals["dxy_uncallable_sites"] == exp.totals["dxy_uncallable_sites"]
         assert got.totals["sites_with_components"] == exp.totals["sites_with_components"]
 
-    monkeypatch.setenv("FMH_LAYOUT", "bytes")
-    monkeypatch.setenv("FMH_COUNTS_MFMA", "1")
+    fmh_opts.setenv("FMH_LAYOUT", "bytes")
+    fmh_opts.setenv("FMH_COUNTS_MFMA", "1")
     mfma = dev.hudson_sweep(dm, g, dev.FORMULA_DENSE)
     check(mfma, "int8 MFMA route")
     cuts = [0, 444_441, 1_500_007, S]
@@ -268,9 +268,9 @@ def test_c5_full_size(dev, monkeypatch):
         tot = sum(p.totals[k] for p in parts)
         assert (tot == v) if isinstance(v, int) else H.rel_close(tot, v), k
     del mfma, parts
-    monkeypatch.delenv("FMH_COUNTS_MFMA")
+    fmh_opts.delenv("FMH_COUNTS_MFMA")
     check(dev.hudson_sweep(dm, g, dev.FORMULA_DENSE), "dot4 route")
-    monkeypatch.delenv("FMH_LAYOUT")
+    fmh_opts.delenv("FMH_LAYOUT")
     dm.pack(release_bytes=True)
     check(dev.hudson_sweep(dm, g, dev.FORMULA_DENSE), "packed route")
 

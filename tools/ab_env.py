@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-process A/B of a library switch that is read per call (FMH_PACKED_NO_PREFETCH, FMH_PACKED_UNROLL, FMH_PACKED_LPR, FMH_MASK_MODE, ...):
+"""Same-process A/B of a library option (fmh_set_option: FMH_PACKED_NO_PREFETCH, FMH_PACKED_UNROLL, FMH_PACKED_LPR, FMH_MASK_MODE, ...):
 
     tools/ab_env.py FMH_PACKED_NO_PREFETCH=1
 
@@ -69,10 +69,7 @@ def main():
             res = {}
             for rep in range(3):
                 for name, env in (("unset", None), ("set", value)):
-                    if env is not None:
-                        os.environ[var] = env
-                    else:
-                        os.environ.pop(var, None)
+                    _abi.set_option(var, env)  # None = the value the process started with
                     for _ in range(3):
                         sweep(rows)
                     lib.fmh_timing_enable(1)
@@ -83,7 +80,7 @@ def main():
                     lib.fmh_timing_read(C.byref(ms), C.byref(n))
                     lib.fmh_timing_enable(0)
                     res.setdefault(name, []).append(ms.value / max(n.value, 1))
-            os.environ.pop(var, None)
+            _abi.set_option(var, None)
             a, b = min(res["unset"]), min(res["set"])
             print(json.dumps({"switch": sys.argv[1], "kind": kind, "sites": rows, "haplotypes": H, "layout": layout + (" +1% missing" if missing else ""), "unset_ms": round(a, 4), "set_ms": round(b, 4),
                               "set_over_unset": round(b / a, 4), "all_unset": [round(x, 4) for x in res["unset"]], "all_set": [round(x, 4) for x in res["set"]]}), flush=True)
