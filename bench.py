@@ -157,6 +157,69 @@ def recorded_traffic(sites: int, haplotypes: int, layout: str):
     return rec["hbm_bytes_per_launch"], where + f", kernel sources {sha}"
 
 
+# Recorded from N = 1 runs of the default cohort (10 M sites x 5 000 haplotypes, seed 10 002 500, profiles/r02/c4_bench.json and this round's):
+# the integer totals are exact whatever the sharding, so any N must reproduce them; the f64 ratio within the 1e-9 contract.
+N1_RECORDED = {
+    (10_000_000, 5000, 10_002_500): {"segregating_sites": [9949061, 9949159], "hudson_fst": 0.028471767808637662,
+                                     "pi_sum": [3068822.9373544613, 3069429.427405202]},
+}
+
+
+def parity_vs_n1(args, first, totals, rank, world, local_rank, lib, masks, poc, N, H):
+    """N > 1 strong scaling: the all-rank totals against one GPU sweeping the WHOLE cohort - (a) the recorded N = 1 constants when the run
+    is the default cohort, (b) computed here, after the timed region, by rank 0 (the cohort is a pure function of the global site index, so
+    rank 0 regenerates all of it: 10 M x 5 000 is 50 GB of u8 rows for the generator + 6.4 GB of planes, on a 288 GB card)."""
+    from ferromic_amd import _abi, device
+
+    out = {"mode": first["scaling"]}
+    if first["scaling"] != "strong":
+        out["note"] = "weak scaling sweeps an N x larger cohort: no one-GPU counterpart of the same cohort"
+        return out
+    got = {"segregating_sites": [int(totals.pop[0].segregating_sites), int(totals.pop[1].segregating_sites)],
+           "sites_with_components": int(totals.sites_with_components), "dxy_uncallable_sites": int(totals.dxy_uncallable_sites),
+           "hudson_fst": totals.numerator_sum / totals.denominator_sum if totals.denominator_sum > 1e-12 else None,
+           "pi_sum": [totals.pop[0].pi_sum, totals.pop[1].pi_sum]}
+
+    def compare(ref):
+        res = {}
+        for k in ("segregating_sites", "sites_with_components", "dxy_uncallable_sites"):
+            if k in ref:
+                res[k] = ref[k] == got[k]
+        if ref.get("hudson_fst") is not None and got["hudson_fst"] is not None:
+            res["hudson_fst_rel_err"] = abs(got["hudson_fst"] - ref["hudson_fst"]) / abs(ref["hudson_fst"])
+        if "pi_sum" in ref:
+            res["pi_sum_rel_err"] = max(abs(a - b) / abs(b) for a, b in zip(got["pi_sum"], ref["pi_sum"]))
+        res["ok"] = all(v for k, v in res.items() if isinstance(v, bool)) and res.get("hudson_fst_rel_err", 0.0) <= 1e-9 and res.get("pi_sum_rel_err", 0.0) <= 1e-9
+        return res
+
+    rec = N1_RECORDED.get((first["total_sites"], H, first["seed"]))
+    out["recorded"] = dict(compare(rec), source="bench.py N1_RECORDED (N = 1 runs of this cohort)") if rec else None
+    if rank != 0 or args.no_verify_n1:
+        return out
+    total = first["total_sites"]
+    if total * H > 120e9:
+        out["computed"] = {"skipped": f"{total} x {H} u8 rows exceed the verification budget"}
+        return out
+    try:
+        thr = synthetic_thresholds(total, 0, first["seed"])
+        dm = device.DeviceMatrix.alloc(total, N, 2, with_missing=False, max_allele=1, device=local_rank)
+        dm.generate(first["seed"], 0, thr, poc, 0)
+        if args.layout == "packed":
+            dm.pack(release_bytes=True)
+        g = device.Groups(dm, masks)
+        ref_t = _abi.HudsonTotals()
+        _abi.check(lib.fmh_hudson_sweep(dm._h, g._h, 0, total, _abi.FORMULA_DENSE, None, C.byref(ref_t), None))
+        ref = {"segregating_sites": [int(ref_t.pop[0].segregating_sites), int(ref_t.pop[1].segregating_sites)],
+               "sites_with_components": int(ref_t.sites_with_components), "dxy_uncallable_sites": int(ref_t.dxy_uncallable_sites),
+               "hudson_fst": ref_t.numerator_sum / ref_t.denominator_sum if ref_t.denominator_sum > 1e-12 else None,
+               "pi_sum": [ref_t.pop[0].pi_sum, ref_t.pop[1].pi_sum]}
+        out["computed"] = dict(compare(ref), source=f"rank 0 swept all {total} sites itself after the timed region (fmh_hudson_sweep, one GPU)", n1_values=ref)
+        del g, dm
+    except Exception as exc:  # noqa: BLE001 - the check must never cost the line
+        out["computed"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -192,6 +255,8 @@ def parse_args():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded path (communicator, device-side reduce, pipelining) even with one rank: measures its "
                          "software cost on a one-GPU box")
+    ap.add_argument("--no-verify-n1", action="store_true",
+                    help="N > 1, strong scaling: skip rank 0's own sweep of the whole cohort after the timed region (parity_vs_n1.computed)")
     ap.add_argument("--sync-steps", action="store_true",
                     help="N = 1: one blocking fmh_hudson_sweep per step instead of the pipelined begin / end pair on a local communicator")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
@@ -374,6 +439,7 @@ def main() -> int:
         fence()
         lib.fmh_timing_enable(max(1, args.timing_sample))  # HIP events around every n-th sweep of the timed region
         lib.fmh_timing_reset()
+        lib.fmh_timing_reset_reduce()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -381,17 +447,46 @@ def main() -> int:
         elapsed = time.perf_counter() - t0
         kernel_ms, launches = C.c_double(), C.c_uint64()
         lib.fmh_timing_read(C.byref(kernel_ms), C.byref(launches))
+        kmin, kmax = C.c_double(), C.c_double()
+        lib.fmh_timing_read_minmax(C.byref(kmin), C.byref(kmax))
+        red_ms, red_n = C.c_double(), C.c_uint64()
+        lib.fmh_timing_read_reduce(C.byref(red_ms), C.byref(red_n))
         lib.fmh_timing_enable(0)
+        local_elapsed = elapsed
         elapsed = max_over_ranks(elapsed)
         avg_kernel_s = (kernel_ms.value / 1e3) / max(launches.value, 1)
+        # what THIS rank did, gathered on rank 0 below: its slab, its kernel times (HIP events on its launch stream), the device-side latency of
+        # its grouped all-reduce (events on the communicator's stream), its own wall clock over the timed steps
+        mine = {"rank": rank, "device": local_rank, "slab": [begin, end], "sites": S, "kernel_ms_avg": avg_kernel_s * 1e3, "kernel_ms_min": kmin.value,
+                "kernel_ms_max": kmax.value, "kernel_launches_timed": int(launches.value),
+                "reduce_ms_avg": (red_ms.value / red_n.value) if red_n.value else None, "reduces_timed": int(red_n.value),
+                "elapsed_ms_per_step": local_elapsed / args.steps * 1e3}
         return {"scaling": scaling, "total_sites": total, "slab": (begin, end), "S": S, "seed": seed, "gen_s": gen_s, "pack_s": pack_s,
                 "elapsed": elapsed, "avg_kernel_s": avg_kernel_s, "timed_launches": int(launches.value), "totals": state["totals"], "u8_reference": u8_reference,
-                "bufs": bufs, "thr": thr, "dm": dm, "groups": groups}
+                "bufs": bufs, "thr": thr, "dm": dm, "groups": groups, "mine": mine}
 
     first = run_mode(args.scaling, True)
     totals = first["totals"]
     S = first["S"]
     value = first["total_sites"] * args.steps / first["elapsed"]
+    # ---- N > 1: the line carries its own evidence (who reduced, over what, what every rank did) --------------------------------
+    comm_report = None
+    per_rank = None
+    if sharded:
+        if comm is not None:
+            comm_report = comm.describe()  # from the library: transport, world, rank, device, the librccl file it bound, ncclGetVersion
+            comm_report["source"] = "fmh_comm_describe (libferromic_hip.so)"
+        else:
+            comm_report = {"transport": f"torch.distributed ({args.backend})", "world": world, "rank": rank, "device": local_rank, "rccl_library": None,
+                           "source": "bench.py: the library's communicator is not in use" + (" (rehearsal on one device)" if args.rehearse_on_one_device else "")}
+        mine = dict(first["mine"])
+        mine["comm"] = {k: comm_report.get(k) for k in ("transport", "world", "rank", "device")}
+        if dist is not None and world > 1:
+            box = [None] * world
+            dist.all_gather_object(box, mine)
+            per_rank = box
+        else:
+            per_rank = [mine]
     secondary = None
     if world > 1 and not args.no_secondary:
         # release the primary cohort, then the other mode on the same ranks
@@ -472,11 +567,22 @@ def main() -> int:
         "results": {
             "hudson_fst": totals.numerator_sum / totals.denominator_sum if totals.denominator_sum > 1e-12 else None,
             "segregating_sites": [int(totals.pop[0].segregating_sites), int(totals.pop[1].segregating_sites)],
+            "sites_with_components": int(totals.sites_with_components),
+            "dxy_uncallable_sites": int(totals.dxy_uncallable_sites),
             "pi_sum": [totals.pop[0].pi_sum, totals.pop[1].pi_sum],
         },
     }
     if secondary is not None:
         result["secondary"] = secondary
+    if sharded:
+        ks = [r["kernel_ms_avg"] for r in per_rank]
+        reds = [r["reduce_ms_avg"] for r in per_rank if r["reduce_ms_avg"] is not None]
+        result["comm"] = dict(comm_report, per_rank=per_rank, ranks_reporting=len(per_rank),
+                              kernel_ms_avg_min_over_ranks=min(ks), kernel_ms_avg_max_over_ranks=max(ks),
+                              reduce_ms_avg_max_over_ranks=max(reds) if reds else None,
+                              reduce_note="HIP events on the communicator's stream around ncclGroupStart .. ncclGroupEnd of the two 512-byte all-reduces "
+                                          "(every timed step); null when the library's RCCL communicator is not the transport")
+        result["parity_vs_n1"] = parity_vs_n1(args, first, totals, rank, world, local_rank, lib, masks, poc, N, H)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         bufs = first["bufs"]
@@ -503,7 +609,8 @@ def main() -> int:
     if dist is not None:
         barrier()
         dist.destroy_process_group()
-    return 0
+    # the line is out; a run whose RCCL communicator could not be created (summed through torch.distributed instead) is not a clean run
+    return 3 if transport_note else 0
 
 
 if __name__ == "__main__":

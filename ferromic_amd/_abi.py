@@ -164,6 +164,7 @@ SYMBOLS = {
     "fmh_timing_enable": (_i, [_i]),
     "fmh_timing_reset": (_i, []),
     "fmh_timing_read": (_i, [_P(_d), _P(_u64)]),
+    "fmh_timing_read_minmax": (_i, [_P(_d), _P(_d)]),
 }
 
 _lib: Optional[C.CDLL] = None

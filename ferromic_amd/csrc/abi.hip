@@ -749,7 +749,7 @@ static Workspace g_ws[64];
 static std::mutex g_ws_mutex;
 static std::atomic<int> g_timing{0};             // 0 = off, n = time every n-th sweep (fmh_timing_enable)
 static std::atomic<uint64_t> g_timing_seq{0};
-static double g_timing_ms = 0.0;
+static double g_timing_ms = 0.0, g_timing_min = 0.0, g_timing_max = 0.0;
 static uint64_t g_timing_launches = 0;
 
 int fmhi::workspace(int device, Workspace** out) {
@@ -823,7 +823,14 @@ extern "C" int fmh_timing_enable(int on) { g_timing = on < 0 ? 0 : on; return FM
 extern "C" int fmh_timing_reset(void) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   g_timing_ms = 0.0;
+  g_timing_min = g_timing_max = 0.0;
   g_timing_launches = 0;
+  return FMH_OK;
+}
+extern "C" int fmh_timing_read_minmax(double* h_min_ms, double* h_max_ms) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (h_min_ms) *h_min_ms = g_timing_min;
+  if (h_max_ms) *h_max_ms = g_timing_max;
   return FMH_OK;
 }
 extern "C" int fmh_timing_read(double* ms, uint64_t* launches) {
@@ -1015,6 +1022,8 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
 
 void fmhi::timing_add(double ms) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (g_timing_launches == 0 || ms < g_timing_min) g_timing_min = ms;
+  if (g_timing_launches == 0 || ms > g_timing_max) g_timing_max = ms;
   g_timing_ms += ms;
   g_timing_launches += 1;
 }

@@ -409,6 +409,8 @@ int fmh_wc_totals_unpack(fmh_wc_totals* t, int n_groups, const double* h_f64, co
 int fmh_timing_enable(int on);
 int fmh_timing_reset(void);
 int fmh_timing_read(double* h_total_ms, uint64_t* h_launches);
+/* shortest and longest of the launches timed since the last reset (0, 0 when none) */
+int fmh_timing_read_minmax(double* h_min_ms, double* h_max_ms);
 /* The same for the grouped all-reduce of the timed sharded sweeps (RCCL transport): HIP events on the communicator's stream around
  * ncclGroupStart .. ncclGroupEnd - the device-side latency of one 2 x 512-byte reduce. */
 int fmh_timing_read_reduce(double* h_total_ms, uint64_t* h_reduces);

@@ -37,6 +37,20 @@ def test_two_ranks_equal_one_rank():
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["config"]["sites_per_gpu"] == S and strong["config"]["total_sites"] == 2 * S
     assert strong["value"] == pytest.approx(2 * S * 2 / (strong["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert strong["secondary"]["scaling"] == "weak" and strong["secondary"]["sites_per_gpu"] == 2 * S and strong["secondary"]["total_sites"] == 4 * S
+    # the N > 1 line carries its own evidence: who summed, what every rank swept and measured, and the all-rank totals against one GPU
+    # sweeping the whole cohort (computed by rank 0 after the timed region)
+    c = strong["comm"]
+    assert c["world"] == 2 and "torch.distributed" in c["transport"] and c["ranks_reporting"] == 2 and c["rccl_library"] is None
+    assert [r["rank"] for r in c["per_rank"]] == [0, 1] and [r["slab"] for r in c["per_rank"]] == [[0, S], [S, 2 * S]]
+    for r in c["per_rank"]:
+        assert r["sites"] == S and r["kernel_launches_timed"] >= 1 and 0 < r["kernel_ms_min"] <= r["kernel_ms_avg"] <= r["kernel_ms_max"]
+        assert r["elapsed_ms_per_step"] > 0 and r["reduce_ms_avg"] is None  # torch transport: no library-side reduce to time
+    assert c["kernel_ms_avg_min_over_ranks"] <= c["kernel_ms_avg_max_over_ranks"]
+    pv = strong["parity_vs_n1"]
+    assert pv["mode"] == "strong" and pv["recorded"] is None  # not the default cohort: no recorded constants
+    assert pv["computed"]["ok"] is True and pv["computed"]["segregating_sites"] is True and pv["computed"]["sites_with_components"] is True
+    assert pv["computed"]["hudson_fst_rel_err"] <= 1e-9 and pv["computed"]["pi_sum_rel_err"] <= 1e-9
+    assert weak["parity_vs_n1"]["mode"] == "weak" and "computed" not in weak["parity_vs_n1"]
     # the same 2 x S sites generated and swept by one rank (same seed recipe: seed = total sites + samples)
     one = run([sys.executable, "bench.py", "--sites", str(2 * S)] + common)
     assert one["scaling"] == "strong" and "secondary" not in one
@@ -63,6 +77,13 @@ def test_rccl_collective_path_with_one_rank():
     coll = run([sys.executable, "bench.py", "--force-collective"] + common)
     assert "RCCL" in coll["config"]["parallelism"] and "no collective" in plain["config"]["parallelism"] and "pipelined" in plain["config"]["parallelism"]
     assert coll["results"] == plain["results"]
+    # what summed: reported by the library itself (fmh_comm_describe), with the librccl file it bound and the measured reduce latency
+    c = coll["comm"]
+    assert c["transport"] == "rccl" and c["world"] == 1 and c["rank"] == 0 and "rccl" in str(c["rccl_library"]).lower() and str(c["rccl_version"]).isdigit()
+    assert c["source"].startswith("fmh_comm_describe") and c["ranks_reporting"] == 1 and c["per_rank"][0]["slab"] == [0, 250000]
+    assert c["per_rank"][0]["reduces_timed"] >= 1 and 0 < c["per_rank"][0]["reduce_ms_avg"] < 50 and c["reduce_ms_avg_max_over_ranks"] > 0
+    assert coll["parity_vs_n1"]["computed"]["ok"] is True and coll["parity_vs_n1"]["computed"]["hudson_fst_rel_err"] == 0.0  # one rank: the same sweep
+    assert "comm" not in plain and "parity_vs_n1" not in plain
     blocking = run([sys.executable, "bench.py", "--sync-steps"] + common)
     assert "blocking" in blocking["config"]["parallelism"] and blocking["results"] == plain["results"]
     assert coll["roofline"]["kernel_ms_avg"] > 0  # HIP events of the pipelined launches
