@@ -133,7 +133,9 @@ def cpu_baseline(args, sample: int, thr_full: np.ndarray, poc: np.ndarray, seed:
 def kernel_source_sha() -> str:
     """Identity of the sweep kernel sources: profiles/pmc_traffic.json records the one its counters were collected on."""
     h = hashlib.sha256()
-    for name in ("sweep_kernels.hpp", "sweep_launch.inc"):
+    # the kernels, their launcher (grid, deferral depth) and abi.hip, where the batch depth, lanes per row and the deferral's LDS room - which
+    # decide the access pattern - are chosen
+    for name in ("sweep_kernels.hpp", "sweep_launch.inc", "abi.hip"):
         with open(os.path.join(ROOT, "ferromic_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

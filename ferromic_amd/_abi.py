@@ -87,6 +87,10 @@ class HudsonSites(C.Structure):
     ]
 
 
+class PairDiversitySites(C.Structure):
+    _fields_ = [("d_pi", C.c_void_p), ("d_theta", C.c_void_p)]
+
+
 class WcTotals(C.Structure):
     _fields_ = [
         ("sum_a", C.c_double * (1 + MAX_PAIRS)),
@@ -130,6 +134,7 @@ SYMBOLS = {
     "fmh_population_summaries": (_i, [_vp, _vp, _sz, _sz, _i, _vp, _vp, _P(PopTotals), _vp]),
     "fmh_hudson_sweep": (_i, [_vp, _vp, _sz, _sz, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_diversity_sites": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(PopTotals), _vp]),
+    "fmh_pair_region_sweep": (_i, [_vp, _vp, _sz, _sz, _i, _i, _P(PairDiversitySites), _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_wc_sweep": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(WcTotals), _vp]),
     "fmh_wc_sweep_many": (_i, [_vp, _vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fmh_pairwise_differences": (_i, [_vp, _sz, _vp, _vp, _vp]),
@@ -159,6 +164,8 @@ SYMBOLS = {
     "fmh_population_summaries_sharded_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _vp]),
     "fmh_population_summaries_sharded_end": (_i, [_vp, _P(PopTotals)]),
     "fmh_population_summaries_sharded": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _P(PopTotals), _vp]),
+    "fmh_pair_region_sweep_sharded_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _P(PairDiversitySites), _P(HudsonSites), _vp]),
+    "fmh_pair_region_sweep_sharded": (_i, [_vp, _vp, _vp, _sz, _sz, _i, _i, _P(PairDiversitySites), _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_timing_read_reduce": (_i, [_P(_d), _P(_u64)]),
     "fmh_timing_reset_reduce": (_i, []),
     "fmh_timing_enable": (_i, [_i]),

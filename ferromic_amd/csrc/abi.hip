@@ -902,6 +902,11 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
         const bool pu[2] = {true, true};
         a.wc_shape[k] = wc_shape<2>(pn, pu);
       }
+    a.wc_live_mask = a.wc_s2ok_mask = 0;
+    for (int q = 0; q < k; ++q) {
+      if (a.wc_shape[q].live) a.wc_live_mask |= 1u << q;
+      if (a.wc_shape[q].s2_ok) a.wc_s2ok_mask |= 1u << q;
+    }
   }
   a.part_f64 = b.part_f64;
   a.part_u64 = b.part_u64;
@@ -963,7 +968,8 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   const int env_mfma = (int)opt.counts_mfma.load();
   const int mfma_unroll = env_mfma == 2 ? 2 : 4;
   // (rows whose byte masks do not fit LDS stay on the dot4 routes)
-  const bool mfma = !packed && env_mfma != 0 && !missing && !general && P <= 4 &&
+  const bool fused_region = (mode & kModeDiversity) != 0 && P == 2;  // not built on the matrix-core route
+  const bool mfma = !packed && !fused_region && env_mfma != 0 && !missing && !general && P <= 4 &&
                     (size_t)P * mfma_mask_stride(m->nvec, mfma_unroll) * 16 <= lds_limit;
   if (mfma) {
     a.unroll = mfma_unroll;
@@ -993,9 +999,11 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   int grid = 0;
   // argument checks shared by every route, then the route's own launcher (sweep_*.hip)
   if (mode == (kModeSummary | kModeHudson) && P != 2) return fail(FMH_ERR_INVALID, "Hudson sweep needs exactly 2 groups");
-  if (mode == (kModeSummary | kModeDiversity) && P != 1) return fail(FMH_ERR_INVALID, "diversity sweep needs exactly 1 group");
+  if (mode == (kModeSummary | kModeDiversity) && P > 2) return fail(FMH_ERR_INVALID, "diversity sweep needs 1 group (or the 2 of a fused region sweep)");
+  if (mode == (kModeSummary | kModeHudson | kModeDiversity) && P != 2) return fail(FMH_ERR_INVALID, "the fused region sweep needs exactly 2 groups");
   if (mode == kModeWc && P == 1) return fail(FMH_ERR_INVALID, "W&C sweep needs at least 2 groups");
-  if (mode != kModeSummary && mode != (kModeSummary | kModeHudson) && mode != (kModeSummary | kModeDiversity) && mode != kModeWc)
+  if (mode != kModeSummary && mode != (kModeSummary | kModeHudson) && mode != (kModeSummary | kModeDiversity) && mode != (kModeSummary | kModeHudson | kModeDiversity) &&
+      mode != kModeWc)
     return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
   if (mask_mode == kMaskGlobalBytes && (P > 2 || mode == kModeWc))
     return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
@@ -1080,6 +1088,23 @@ static void fill_pop_totals(const fmh_groups* g, const SweepResult& r, int p, fm
   t->pi_sum = r.f64[kOffPopF64 + p];
 }
 
+static void fill_hudson_totals(const fmh_groups* g, const SweepResult& r, fmh_hudson_totals* t) {
+  memset(t, 0, sizeof *t);
+  t->numerator_sum = r.f64[kOffHudF64 + 0];
+  t->denominator_sum = r.f64[kOffHudF64 + 1];
+  t->pi1_sum = r.f64[kOffHudF64 + 2];
+  t->pi2_sum = r.f64[kOffHudF64 + 3];
+  t->dxy_sum_all = r.f64[kOffHudF64 + 4];
+  t->site_num_sum = r.f64[kOffHudF64 + 5];
+  t->site_den_sum = r.f64[kOffHudF64 + 6];
+  t->site_dxy_sum = r.f64[kOffHudF64 + 7];
+  t->dxy_uncallable_sites = r.u64[kOffHudU64 + 0];
+  t->sites_with_components = r.u64[kOffHudU64 + 1];
+  t->site_dxy_skipped = r.u64[kOffHudU64 + 2];
+  fill_pop_totals(g, r, 0, &t->pop[0]);
+  fill_pop_totals(g, r, 1, &t->pop[1]);
+}
+
 static int check_formula(int formula) {
   if (formula != FMH_FORMULA_SPARSE && formula != FMH_FORMULA_DENSE && formula != FMH_FORMULA_SUMMARY)
     return fail(FMH_ERR_INVALID, "unknown formula %d", formula);
@@ -1131,23 +1156,7 @@ extern "C" int fmh_hudson_sweep(const fmh_matrix* m, const fmh_groups* g, size_t
   }
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeSummary | kModeHudson, a, stream, &r));
-  if (h_totals) {
-    fmh_hudson_totals* t = h_totals;
-    memset(t, 0, sizeof *t);
-    t->numerator_sum = r.f64[kOffHudF64 + 0];
-    t->denominator_sum = r.f64[kOffHudF64 + 1];
-    t->pi1_sum = r.f64[kOffHudF64 + 2];
-    t->pi2_sum = r.f64[kOffHudF64 + 3];
-    t->dxy_sum_all = r.f64[kOffHudF64 + 4];
-    t->site_num_sum = r.f64[kOffHudF64 + 5];
-    t->site_den_sum = r.f64[kOffHudF64 + 6];
-    t->site_dxy_sum = r.f64[kOffHudF64 + 7];
-    t->dxy_uncallable_sites = r.u64[kOffHudU64 + 0];
-    t->sites_with_components = r.u64[kOffHudU64 + 1];
-    t->site_dxy_skipped = r.u64[kOffHudU64 + 2];
-    fill_pop_totals(g, r, 0, &t->pop[0]);
-    fill_pop_totals(g, r, 1, &t->pop[1]);
-  }
+  if (h_totals) fill_hudson_totals(g, r, h_totals);
   return FMH_OK;
 }
 
@@ -1166,6 +1175,52 @@ extern "C" int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, siz
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeSummary | kModeDiversity, a, stream, &r));
   if (h_totals) fill_pop_totals(g, r, 0, h_totals);
+  return FMH_OK;
+}
+
+// What run_vcf's region driver needs of groups 0 and 1 of a region matrix (process.rs:2468-3653: process_variants for each group, then
+// the Hudson pair) in ONE read of the matrix: the population summaries of both groups by `summary_formula`, the per-site diversity of both
+// groups, and - with hudson_formula >= 0 - the Hudson per-site records and totals by THAT formula set (the region driver takes
+// calculate_pi_dense for the regional pi of a diploid dense matrix and the sparse per-site path for Hudson).  Round 2 issued
+// fmh_population_summaries + 2 x fmh_diversity_sites + fmh_hudson_sweep: four reads.
+int fmhi::pair_region_args(const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula, int hudson_formula, const fmh_pair_diversity_sites* div,
+                           const fmh_hudson_sites* sites, SweepArgs& a, int* mode) {
+  FMH_TRY(check_formula(summary_formula));
+  if (hudson_formula >= 0) FMH_TRY(check_formula(hudson_formula));
+  if (g && g->n_groups != 2) return fail(FMH_ERR_INVALID, "the fused region sweep needs exactly 2 groups, got %d", g->n_groups);
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.formula = summary_formula;
+  a.hudson_formula_p1 = hudson_formula >= 0 && hudson_formula != summary_formula ? hudson_formula + 1 : 0;
+  if (div) { a.site_pi = div->d_pi; a.site_theta = div->d_theta; }
+  if (sites && hudson_formula >= 0) {
+    a.fst = sites->d_fst; a.dxy = sites->d_dxy; a.pi1 = sites->d_pi1; a.pi2 = sites->d_pi2;
+    a.num = sites->d_num; a.den = sites->d_den;
+  }
+  if (sites) { a.alt = sites->d_alt; a.called = sites->d_called; }
+  *mode = kModeSummary | kModeDiversity | (hudson_formula >= 0 ? kModeHudson : 0);
+  return FMH_OK;
+}
+
+extern "C" int fmh_pair_region_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula,
+                                     int hudson_formula, const fmh_pair_diversity_sites* diversity_or_null, const fmh_hudson_sites* sites_or_null,
+                                     fmh_hudson_totals* h_totals, void* stream) {
+  SweepArgs a{};
+  int mode = 0;
+  FMH_TRY(pair_region_args(g, row_begin, row_count, summary_formula, hudson_formula, diversity_or_null, sites_or_null, a, &mode));
+  SweepResult r;
+  FMH_TRY(run_sweep(m, g, mode, a, stream, &r));
+  if (h_totals) fill_hudson_totals(g, r, h_totals);
+  return FMH_OK;
+}
+
+// the device's harmonic table, grown on demand (comm.hip's sharded fused sweep needs it outside run_sweep)
+int fmhi::harmonic_table(int device, size_t max_k, hipStream_t st, const double** out) {
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(device, &w));
+  std::lock_guard<std::mutex> grow(w->in_use);
+  FMH_TRY(ensure_harmonic(w, max_k, st));
+  *out = w->harmonic;
   return FMH_OK;
 }
 

@@ -163,6 +163,10 @@ hipError_t unpack_rows(const fmh_matrix* m, size_t row0, size_t rows, uint8_t* d
 int enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, fmh::SweepArgs& a, hipStream_t st, const LaunchCtx& ctx,
                   const SweepBuffers& b, const double* harmonic, bool* launched);
 
+// the fused region sweep's kernel arguments and mode (abi.hip); the device's harmonic table
+int pair_region_args(const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula, int hudson_formula, const fmh_pair_diversity_sites* div,
+                     const fmh_hudson_sites* sites, fmh::SweepArgs& a, int* mode);
+int harmonic_table(int device, size_t max_k, hipStream_t st, const double** out);
 // W&C slot order of the padded kernel -> the caller's pair order; which W&C / summaries calls are one fused sweep (abi.hip)
 void wc_slot_map(const fmh_groups* g, fmh::SweepArgs& a, int (&slot_of)[32]);
 bool wc_fused_lane_totals(const fmh_matrix* m, const fmh_groups* g);

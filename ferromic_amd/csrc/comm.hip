@@ -461,7 +461,8 @@ void settle_after_failure(fmh_comm* c, hipStream_t st) {
 
 // sweep (mode, args) + device-side reduce + D2H, enqueued into the next free slot.  `host_vec`: the slot's totals were computed by a
 // blocking call and sit in s.h_f64 / s.h_u64 already (the routes that are not one fused sweep): they are copied up and reduced the same way.
-int sharded_enqueue(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, hipStream_t st, ShardSlot& s, bool host_vec) {
+int sharded_enqueue(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, int mode, SweepArgs& a, hipStream_t st, ShardSlot& s, bool host_vec,
+                    const double* harmonic = nullptr) {
   s.timed = timing_enabled();
   s.launched = false;
   auto body = [&]() -> int {
@@ -470,7 +471,7 @@ int sharded_enqueue(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, int m
       // the finalize kernel goes to the communicator's stream (behind the sweep's event): on the caller's stream the next window's sweep
       // follows this one directly
       const SweepBuffers bufs{s.part_f64, s.part_u64, s.out_f64, s.out_u64, c->stream, s.swept};
-      FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, nullptr, &s.launched));
+      FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, harmonic, &s.launched));
       if (!s.launched) {  // an empty slab still takes part in the collective, with zeros
         HIP_TRY(hipMemsetAsync(s.out_f64, 0, kMaxF64 * 8, st));
         HIP_TRY(hipMemsetAsync(s.out_u64, 0, kMaxU64 * 8, st));
@@ -598,6 +599,32 @@ extern "C" int fmh_hudson_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const 
                                         const fmh_hudson_sites* sites, fmh_hudson_totals* t, void* stream) {
   if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with their _end first");
   FMH_TRY(fmh_hudson_sweep_sharded_begin(c, m, g, row_begin, row_count, formula, sites, stream));
+  return fmh_hudson_sweep_sharded_end(c, t);
+}
+
+// ---- the fused region sweep (fmh_pair_region_sweep) over a slab: population summaries + Hudson totals in one vector --------------------
+extern "C" int fmh_pair_region_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula,
+                                                   int hudson_formula, const fmh_pair_diversity_sites* div, const fmh_hudson_sites* sites, void* stream) {
+  FMH_TRY(sharded_check(c, m, g, row_begin, row_count));
+  SweepArgs a{};
+  int mode = 0;
+  FMH_TRY(pair_region_args(g, row_begin, row_count, summary_formula, hudson_formula, div, sites, a, &mode));
+  FMH_TRY(use_device(c->device));
+  const double* harmonic = nullptr;
+  FMH_TRY(harmonic_table(c->device, (size_t)m->columns + 1, (hipStream_t)stream, &harmonic));
+  ShardSlot& s = c->slot[c->head % FMH_SHARDED_IN_FLIGHT];
+  s.kind = kShardHudson;
+  s.n_groups = 2;
+  s.sizes[0] = g->sizes[0];
+  s.sizes[1] = g->sizes[1];
+  s.row_count = row_count;
+  return sharded_enqueue(c, m, g, mode, a, (hipStream_t)stream, s, false, harmonic);
+}
+
+extern "C" int fmh_pair_region_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula,
+                                             int hudson_formula, const fmh_pair_diversity_sites* div, const fmh_hudson_sites* sites, fmh_hudson_totals* t, void* stream) {
+  if (c && c->head != c->tail) return fail(FMH_ERR_INVALID, "pipelined sharded sweeps are in flight: collect them with their _end first");
+  FMH_TRY(fmh_pair_region_sweep_sharded_begin(c, m, g, row_begin, row_count, summary_formula, hudson_formula, div, sites, stream));
   return fmh_hudson_sweep_sharded_end(c, t);
 }
 

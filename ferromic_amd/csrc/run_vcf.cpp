@@ -1147,7 +1147,33 @@ struct ShardState {
   vector<fmh_comm*> comms;
   size_t min_bytes = (size_t)256 << 20;  // FERROMIC_SHARD_MIN_BYTES: matrices smaller than this stay whole
   std::mutex region_mutex;               // one sharded region at a time (the communicators are shared)
+  std::atomic<bool> broken{false};       // a slab failed and the group was aborted: the communicators are re-created before the next sharded region
+  int inject_slab = -1;                  // FERROMIC_INJECT_SLAB_FAILURE=<slab>[:<nth on_slabs call>]: tests of the failure path
+  std::atomic<int> inject_countdown{0};
 } g_shard;
+
+// A slab that fails must not leave its peers inside a collective (they would wait for ever: the in-process rendezvous has no timeout, RCCL
+// neither, and the region holds g_shard.region_mutex).  The failing thread aborts EVERY communicator of the group - fmh_comm_abort wakes the
+// peers of the in-process transport with an error and calls ncclCommAbort, which also releases a peer blocked on its communicator's stream -
+// so the region ends with an error on every slab and is logged as dropped.  The communicators are unusable afterwards: restore_shard_group()
+// re-creates them before the next sharded region (or leaves later regions whole when that fails).
+void abort_shard_group() {
+  g_shard.broken = true;
+  for (fmh_comm* c : g_shard.comms) if (c) fmh_comm_abort(c);
+}
+void restore_shard_group() {  // called with region_mutex held
+  if (!g_shard.broken) return;
+  for (fmh_comm* c : g_shard.comms) fmh_comm_destroy(c);
+  g_shard.comms.assign(g_shard.devices.size(), nullptr);
+  const int rc = fmh_comm_init_all(g_shard.devices.data(), (int)g_shard.devices.size(), g_shard.comms.data());
+  if (rc != FMH_OK) {
+    logmsg("WARN", string("the communicators could not be re-created after a failed region; large regions stay whole from here on: ") + fmh_last_error());
+    g_shard.comms.clear();
+  } else {
+    logmsg("WARN", "the communicators of --devices were re-created after a failed region");
+  }
+  g_shard.broken = false;
+}
 
 bool want_shard(size_t rows, size_t n_samples) {
   if (g_shard.comms.size() < 2) return false;
@@ -1160,10 +1186,26 @@ template <class F> void on_slabs(const RegionMatrix& rm, F fn) {
   if (rm.slabs.size() <= 1) { if (!rm.slabs.empty()) fn(rm.slabs[0], (size_t)0); return; }
   vector<std::exception_ptr> errs(rm.slabs.size());
   vector<std::thread> pool;
+  const bool inject = g_shard.inject_slab >= 0 && g_shard.inject_countdown.fetch_sub(1) == 0;
   for (size_t k = 0; k < rm.slabs.size(); ++k)
-    pool.emplace_back([&, k]() { try { fn(rm.slabs[k], k); } catch (...) { errs[k] = std::current_exception(); } });
+    pool.emplace_back([&, k]() {
+      try {
+        if (inject && (size_t)g_shard.inject_slab == k) throw Error("injected failure of slab " + std::to_string(k) + " (FERROMIC_INJECT_SLAB_FAILURE)");
+        fn(rm.slabs[k], k);
+      } catch (...) {
+        errs[k] = std::current_exception();
+        abort_shard_group();  // the peers may be waiting for this slab inside a collective
+      }
+    });
   for (auto& t : pool) t.join();
-  for (auto& e : errs) if (e) std::rethrow_exception(e);
+  // the slab that failed FIRST carries the cause; its peers only report that the group was aborted
+  std::exception_ptr first;
+  for (auto& e : errs) {
+    if (!e) continue;
+    if (!first) first = e;
+    try { std::rethrow_exception(e); } catch (const std::exception& ex) { if (!strstr(ex.what(), "aborted")) { first = e; break; } } catch (...) {}
+  }
+  if (first) std::rethrow_exception(first);
 }
 
 // The common shape - every line diploid over all samples (what process_variant stores for `a|b` cells), alleles up to 7 - goes from the
@@ -1355,32 +1397,13 @@ vector<fmh_pop_totals> sharded_summaries(const RegionMatrix& rm, const vector<ve
     Groups grp(*sl.dm, masks);
     std::unique_ptr<DevBuf> dcalled;
     if (called0) dcalled.reset(new DevBuf(sl.device, 4 * G * std::max<size_t>(rows, 1)));
-    fmh_check(fmh_population_summaries(sl.dm->h, grp.h, 0, rows, formula, nullptr, dcalled ? (uint32_t*)dcalled->p : nullptr, per[k].data(), nullptr), "summaries");
+    // everything that can fail on this slab alone (groups, buffers) is done; the sharded call validates before it enqueues, then
+    // sweep -> finalise -> ncclAllReduce on the device -> one D2H (no host hop between the sweep and the reduce)
+    if (sl.comm) fmh_check(fmh_population_summaries_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, formula, nullptr, dcalled ? (uint32_t*)dcalled->p : nullptr, per[k].data(), nullptr), "sharded summaries");
+    else fmh_check(fmh_population_summaries(sl.dm->h, grp.h, 0, rows, formula, nullptr, dcalled ? (uint32_t*)dcalled->p : nullptr, per[k].data(), nullptr), "summaries");
     if (called0 && rows) { vector<uint32_t> c = dcalled->fetch<uint32_t>(rows); std::copy(c.begin(), c.end(), called0->begin() + (ptrdiff_t)sl.row0); }
-    if (sl.comm) {
-      vector<double> f(FMH_POP_PACK_F64(G));
-      vector<uint64_t> u(FMH_POP_PACK_U64(G));
-      fmh_check(fmh_pop_totals_pack(per[k].data(), (int)G, f.data(), u.data()), "pack");
-      fmh_check(fmh_allreduce_totals(sl.comm, f.data(), f.size(), u.data(), u.size()), "all-reduce of the population totals");
-      fmh_check(fmh_pop_totals_unpack(per[k].data(), (int)G, f.data(), u.data()), "unpack");
-    }
   });
   return per[0];
-}
-
-void sharded_diversity(const RegionMatrix& rm, const vector<uint8_t>& mask, vector<double>& pi_v, vector<double>& th_v) {
-  pi_v.assign(rm.variants, 0.0);
-  th_v.assign(rm.variants, 0.0);
-  on_slabs(rm, [&](const Slab& sl, size_t) {
-    const size_t rows = sl.dm->variants;
-    if (!rows) return;
-    Groups one(*sl.dm, {mask});
-    DevBuf dpi(sl.device, 8 * rows), dth(sl.device, 8 * rows);
-    fmh_check(fmh_diversity_sites(sl.dm->h, one.h, 0, rows, (double*)dpi.p, (double*)dth.p, nullptr, nullptr, nullptr, nullptr), "diversity");
-    vector<double> a = dpi.fetch<double>(rows), b = dth.fetch<double>(rows);
-    std::copy(a.begin(), a.end(), pi_v.begin() + (ptrdiff_t)sl.row0);
-    std::copy(b.begin(), b.end(), th_v.begin() + (ptrdiff_t)sl.row0);
-  });
 }
 
 // fused W&C sweep (2..8 groups); tracks [nw][S] when wanted
@@ -1393,7 +1416,8 @@ fmh_wc_totals sharded_wc(const RegionMatrix& rm, const vector<vector<uint8_t>>& 
     Groups grp(*sl.dm, masks);
     std::unique_ptr<DevBuf> da, db, ds;
     if (a && rows) { da.reset(new DevBuf(sl.device, 8 * nw * rows)); db.reset(new DevBuf(sl.device, 8 * nw * rows)); ds.reset(new DevBuf(sl.device, nw * rows)); }
-    fmh_check(fmh_wc_sweep(sl.dm->h, grp.h, 0, rows, da ? (double*)da->p : nullptr, db ? (double*)db->p : nullptr, ds ? (uint8_t*)ds->p : nullptr, nullptr, &per[k], nullptr), "wc sweep");
+    if (sl.comm) fmh_check(fmh_wc_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, da ? (double*)da->p : nullptr, db ? (double*)db->p : nullptr, ds ? (uint8_t*)ds->p : nullptr, nullptr, &per[k], nullptr), "sharded wc sweep");
+    else fmh_check(fmh_wc_sweep(sl.dm->h, grp.h, 0, rows, da ? (double*)da->p : nullptr, db ? (double*)db->p : nullptr, ds ? (uint8_t*)ds->p : nullptr, nullptr, &per[k], nullptr), "wc sweep");
     if (da) {
       vector<double> ha = da->fetch<double>(nw * rows), hb = db->fetch<double>(nw * rows);
       vector<uint8_t> hs = ds->fetch<uint8_t>(nw * rows);
@@ -1402,13 +1426,6 @@ fmh_wc_totals sharded_wc(const RegionMatrix& rm, const vector<vector<uint8_t>>& 
         std::copy(hb.begin() + (ptrdiff_t)(w * rows), hb.begin() + (ptrdiff_t)((w + 1) * rows), b->begin() + (ptrdiff_t)(w * S + sl.row0));
         std::copy(hs.begin() + (ptrdiff_t)(w * rows), hs.begin() + (ptrdiff_t)((w + 1) * rows), st->begin() + (ptrdiff_t)(w * S + sl.row0));
       }
-    }
-    if (sl.comm) {
-      vector<double> f(FMH_WC_PACK_F64(nw));
-      vector<uint64_t> u(FMH_WC_PACK_U64(nw));
-      fmh_check(fmh_wc_totals_pack(&per[k], (int)G, f.data(), u.data()), "pack");
-      fmh_check(fmh_allreduce_totals(sl.comm, f.data(), f.size(), u.data(), u.size()), "all-reduce of the W&C totals");
-      fmh_check(fmh_wc_totals_unpack(&per[k], (int)G, f.data(), u.data()), "unpack");
     }
   });
   return per[0];
@@ -1455,6 +1472,53 @@ fmh_hudson_totals sharded_hudson(const RegionMatrix& rm, const vector<uint8_t>& 
     std::copy(c.begin(), c.end(), den.begin() + (ptrdiff_t)sl.row0);
   });
   return per[0];
+}
+
+// The fused region sweep (fmh_pair_region_sweep): groups 0 and 1 of one region matrix in ONE read - both population summaries, both
+// groups' per-site diversity and, when asked, the Hudson pair (per-site fst / num / den + totals by the sparse formulas).  Round 2 read the
+// matrix once for the summaries, once per group for the diversity tracks and once more for Hudson.
+struct PairSweep {
+  fmh_hudson_totals tot{};         // pop[0..1]: the summaries; the Hudson fields when `hudson`
+  vector<double> pi[2], theta[2];  // per-site diversity of group 0 / 1
+  bool hudson = false;
+  vector<double> fst, num, den;
+};
+PairSweep sharded_pair_region(const RegionMatrix& rm, const vector<uint8_t>& m0, const vector<uint8_t>& m1, int summary_formula, bool hudson) {
+  PairSweep out;
+  out.hudson = hudson;
+  const size_t S = rm.variants;
+  for (int g = 0; g < 2; ++g) { out.pi[g].assign(S, 0.0); out.theta[g].assign(S, 0.0); }
+  if (hudson) { out.fst.assign(S, 0.0); out.num.assign(S, 0.0); out.den.assign(S, 0.0); }
+  vector<fmh_hudson_totals> per(rm.slabs.size());
+  on_slabs(rm, [&](const Slab& sl, size_t k) {
+    const size_t rows = sl.dm->variants, cap = std::max<size_t>(rows, 1);
+    Groups grp(*sl.dm, {m0, m1});
+    DevBuf dpi(sl.device, 8 * 2 * cap), dth(sl.device, 8 * 2 * cap);
+    std::unique_ptr<DevBuf> dfst, dnum, dden;
+    fmh_pair_diversity_sites div{(double*)dpi.p, (double*)dth.p};
+    fmh_hudson_sites sites{};
+    if (hudson) {
+      dfst.reset(new DevBuf(sl.device, 8 * cap)); dnum.reset(new DevBuf(sl.device, 8 * cap)); dden.reset(new DevBuf(sl.device, 8 * cap));
+      sites.d_fst = (double*)dfst->p; sites.d_num = (double*)dnum->p; sites.d_den = (double*)dden->p;
+    }
+    const int hf = hudson ? FMH_FORMULA_SPARSE : -1;
+    if (sl.comm) fmh_check(fmh_pair_region_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, summary_formula, hf, &div, hudson ? &sites : nullptr, &per[k], nullptr), "sharded region sweep");
+    else fmh_check(fmh_pair_region_sweep(sl.dm->h, grp.h, 0, rows, summary_formula, hf, &div, hudson ? &sites : nullptr, &per[k], nullptr), "region sweep");
+    if (!rows) return;
+    const vector<double> a = dpi.fetch<double>(2 * rows), b = dth.fetch<double>(2 * rows);
+    for (int g = 0; g < 2; ++g) {
+      std::copy(a.begin() + (ptrdiff_t)(g * rows), a.begin() + (ptrdiff_t)((g + 1) * rows), out.pi[g].begin() + (ptrdiff_t)sl.row0);
+      std::copy(b.begin() + (ptrdiff_t)(g * rows), b.begin() + (ptrdiff_t)((g + 1) * rows), out.theta[g].begin() + (ptrdiff_t)sl.row0);
+    }
+    if (hudson) {
+      const vector<double> f = dfst->fetch<double>(rows), n = dnum->fetch<double>(rows), d = dden->fetch<double>(rows);
+      std::copy(f.begin(), f.end(), out.fst.begin() + (ptrdiff_t)sl.row0);
+      std::copy(n.begin(), n.end(), out.num.begin() + (ptrdiff_t)sl.row0);
+      std::copy(d.begin(), d.end(), out.den.begin() + (ptrdiff_t)sl.row0);
+    }
+  });
+  out.tot = per[0];
+  return out;
 }
 
 // ---- statistics (host scalars are literal restatements; genotype work is on the GPU) ------------------
@@ -1532,9 +1596,10 @@ struct SiteDiv { int64_t pos1; double pi, theta; };
 struct GroupStats { bool present = false; size_t segsites = 0, n_hap = 0; double theta = 0.0, pi = 0.0; vector<SiteDiv> sites; };
 
 // process_variants (process.rs:821-1188), statistics only, for groups 0 and 1 of one (variant set, sample filter)
+// `hud`: when given, the same read also yields the Hudson pair of groups 0 / 1 (hudson_groups then takes it from there)
 void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
                            const SampleMap& filter, const Interval& interval, int64_t L, const vector<Interval>* mask_intervals,
-                           int device, GroupStats out[2]) {
+                           int device, GroupStats out[2], PairSweep* hud = nullptr) {
   const auto index = map_sample_names_to_indices(sample_names);
   HapList haps[2] = {haplotypes_for_group(0, filter, index), haplotypes_for_group(1, filter, index)};
   const size_t N = sample_names.size();
@@ -1552,7 +1617,12 @@ void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix&
   // only for a diploid dense matrix (stats.rs:4603-4608), calculate_pi otherwise.
   const bool dense_arm = rm.has_dense && rm.ploidy == 2;
   vector<vector<uint8_t>> masks = {mask_of(haps[0], N, dm.ploidy, true), mask_of(haps[1], N, dm.ploidy, true)};
-  const vector<fmh_pop_totals> tot = sharded_summaries(rm, masks, dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE);
+  // ONE read of the matrix: the summaries of both groups (regional pi by calculate_pi_dense's formulas on a diploid dense matrix, else the
+  // sparse ones), both groups' per-site diversity and - for the caller that wants it - the Hudson pair by the sparse per-site formulas
+  PairSweep local;
+  PairSweep& ps = hud ? *hud : local;
+  ps = sharded_pair_region(rm, masks[0], masks[1], dense_arm ? FMH_FORMULA_DENSE : FMH_FORMULA_SPARSE, hud != nullptr);
+  const fmh_pop_totals tot[2] = {ps.tot.pop[0], ps.tot.pop[1]};
   for (int g = 0; g < 2; ++g) {
     if (!out[g].present) continue;
     out[g].segsites = (size_t)tot[g].segregating_sites;
@@ -1560,8 +1630,7 @@ void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix&
     out[g].pi = pi_from_totals(rm, haps[g], masks[g], N, L, tot[g]);
     // calculate_per_site_diversity (stats.rs:4628-4806): needs >= 2 listed haplotypes
     if (haps[g].size() < 2 || hal_len(interval) <= 0) continue;
-    vector<double> pi_v, th_v;
-    sharded_diversity(rm, masks[g], pi_v, th_v);
+    const vector<double>&pi_v = ps.pi[g], &th_v = ps.theta[g];
     for (size_t i = 0; i < S; ++i) {
       const int64_t pos0 = vs[i]->position;
       if (!hal_contains(interval, pos0)) continue;
@@ -1776,7 +1845,7 @@ struct HudsonRegion {
 
 // calculate_hudson_fst_for_pair_with_sites (stats.rs:3619) for haplotype groups 0 / 1 of the filtered set
 HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
-                           const HapList& h0, const HapList& h1, int64_t L, const double pi_raw[2], int device) {
+                           const HapList& h0, const HapList& h1, int64_t L, const double pi_raw[2], int device, const PairSweep* pre = nullptr) {
   HudsonRegion out;
   if (L <= 0) return out;  // Err(InvalidRegion) -> logged, no outcome (process.rs:3261-3271)
   out.have_outcome = true;
@@ -1787,7 +1856,12 @@ HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix&
     const DeviceMatrix& dm = *rm.dm;
     const size_t S = rm.variants;
     vector<double> fst, num, den;
-    const fmh_hudson_totals tot = sharded_hudson(rm, mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false), FMH_FORMULA_SPARSE, fst, num, den);
+    fmh_hudson_totals tot;
+    if (pre && pre->hudson && pre->fst.size() == S) {  // the filtered process_variants sweep of the same two haplotype lists already read the matrix
+      tot = pre->tot; fst = pre->fst; num = pre->num; den = pre->den;
+    } else {
+      tot = sharded_hudson(rm, mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false), FMH_FORMULA_SPARSE, fst, num, den);
+    }
     num_sum = tot.site_num_sum; den_sum = tot.site_den_sum; dxy_sum = tot.site_dxy_sum; dxy_skipped = tot.site_dxy_skipped;
     size_t informative = 0;
     for (size_t i = 0; i < S; ++i) informative += (!std::isnan(den[i]) && std::isfinite(den[i]) && den[i] > 0.0);
@@ -2160,7 +2234,8 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
   // such region is in flight at a time (small regions keep flowing through the other workers)
   const bool shard = want_shard(std::max(unf.size(), fil.size()), N);
   std::unique_lock<std::mutex> shard_lock(g_shard.region_mutex, std::defer_lock);
-  if (shard) shard_lock.lock();
+  if (shard) { shard_lock.lock(); restore_shard_group(); }
+  // (want_shard is asked again: restore_shard_group may have had to give the communicators up)
   RegionMatrix m_unf = build_matrix(unf, N, args.device, shard && want_shard(unf.size(), N));
   RegionMatrix m_fil = fil == unf ? m_unf : build_matrix(fil, N, args.device, shard && want_shard(fil.size(), N));  // same variants -> one matrix in HBM
   tm.emplace("  region:gpu_sweeps_and_host_statistics");
@@ -2186,7 +2261,14 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
   const int64_t fil_adj = adj;  // FilteringStats.filtered_positions is never filled for the slice (process.rs:2568-2571, 2677-2708)
 
   GroupStats sf[2], su[2];
-  process_variants_pair(fil, m_fil, vcf.sample_names, entry.samples_filtered, entry.interval, fil_adj, mask_chr, args.device, sf);
+  // the filtered pair's sweep also carries the Hudson pair of haplotype groups 0 / 1 when --fst will ask for it (same matrix, same masks)
+  PairSweep fil_pair;
+  bool want_hudson_pair = false;
+  if (args.enable_fst && !fil.empty() && (uint64_t)entry.interval.second > (uint64_t)entry.interval.first && fil_adj > 0) {
+    const auto index0 = map_sample_names_to_indices(vcf.sample_names);
+    want_hudson_pair = haplotypes_for_group(0, entry.samples_filtered, index0).size() >= 2 && haplotypes_for_group(1, entry.samples_filtered, index0).size() >= 2;
+  }
+  process_variants_pair(fil, m_fil, vcf.sample_names, entry.samples_filtered, entry.interval, fil_adj, mask_chr, args.device, sf, want_hudson_pair ? &fil_pair : nullptr);
   process_variants_pair(unf, m_unf, vcf.sample_names, entry.samples_unfiltered, entry.interval, adj, mask_chr, args.device, su);
   if (!sf[0].present && !sf[1].present && !su[0].present && !su[1].present) return std::nullopt;
 
@@ -2204,7 +2286,7 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
     const bool region_valid = (uint64_t)entry.interval.second > (uint64_t)entry.interval.first;
     if (h0.size() >= 2 && h1.size() >= 2 && region_valid) {
       const double pis[2] = {sf[0].pi, sf[1].pi};
-      hud = hudson_groups(fil, m_fil, vcf.sample_names, h0, h1, fil_adj, pis, args.device);
+      hud = hudson_groups(fil, m_fil, vcf.sample_names, h0, h1, fil_adj, pis, args.device, want_hudson_pair ? &fil_pair : nullptr);
       if (hud.have_outcome) {
         out.hudson_rows.push_back({entry.seqname, std::to_string(entry.interval.first), std::to_string(entry.interval.second - 1),
                                    "HaplotypeGroup", "0", "HaplotypeGroup", "1", fmt_opt(hud.dxy), fmt_opt(hud.pi0), fmt_opt(hud.pi1),
@@ -2301,6 +2383,10 @@ struct ShardSetup {
   explicit ShardSetup(const Args& args) {
     if (args.devices.size() < 2 || args.ingest_only) return;
     if (const char* e = getenv("FERROMIC_SHARD_MIN_BYTES")) g_shard.min_bytes = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("FERROMIC_INJECT_SLAB_FAILURE")) {
+      g_shard.inject_slab = atoi(e);
+      if (const char* c = strchr(e, ':')) g_shard.inject_countdown = atoi(c + 1);
+    }
     g_shard.devices = args.devices;
     g_shard.comms.assign(args.devices.size(), nullptr);
     const int rc = fmh_comm_init_all(g_shard.devices.data(), (int)g_shard.devices.size(), g_shard.comms.data());

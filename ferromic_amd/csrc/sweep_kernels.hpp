@@ -83,6 +83,7 @@ struct SweepArgs {
   size_t row_begin;
   size_t row_count;
   int formula;
+  int hudson_formula_p1;  // fused region sweep: formula of the HUDSON part + 1 when it differs from `formula` (which the population totals use); 0 = the same
   int max_allele;         // matrix max allele (general kernel loop bound upper limit)
   // per-site outputs (nullable)
   uint32_t* alt;          // [P][row_count]
@@ -93,6 +94,7 @@ struct SweepArgs {
   double* wc_a; double* wc_b; uint8_t* wc_state;                                 // W&C [(1+npairs)][row_count]
   int8_t wc_slot[32];      // kernel slot k (padded-P pair order) -> caller slot, -1 = not reported
   WcShape wc_shape[kMaxWcSlots];  // kernel slot order; valid when the matrix has no missing data
+  uint32_t wc_live_mask, wc_s2ok_mask;  // bit k = wc_shape[k].live / .s2_ok (the kernels read the doubles from LDS and the flags from here)
   // optional per-allele counts of the GENERAL path (many-group W&C): acounts[(a * acounts_groups + acounts_group0 + p) * row_count + site],
   // pre-zeroed by the host (alleles a row does not iterate stay 0)
   uint32_t* acounts;
@@ -327,6 +329,52 @@ __device__ __forceinline__ void wc_rcp_init(const SweepArgs& A) {  // every thre
   }
 }
 
+// The slots' WcShape doubles in LDS (PRE only).  As kernel arguments they are 7 x 12 SGPRs for four groups, far beyond what the epilogue can
+// keep: hipcc spilled them into VGPR lanes and re-read them with 267 v_readlane per tile (14 % of the kernel's VALU instructions).  A
+// ds_read_b64 of a wave-uniform address costs no VALU slot.
+__device__ __forceinline__ double* wc_shape_table() {
+  __shared__ double table[5 * kMaxWcSlots];
+  return table;
+}
+template <int P>
+__device__ __forceinline__ void wc_shape_init(const SweepArgs& A) {  // every thread of the block, before a __syncthreads()
+  constexpr int NW = 1 + (P * (P - 1)) / 2;
+  double* table = wc_shape_table();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    if (wave == (k & 3)) {
+      table[5 * k + 0] = A.wc_shape[k].s2_den;
+      table[5 * k + 1] = A.wc_shape[k].rm1_over_r;
+      table[5 * k + 2] = A.wc_shape[k].nbar_m1;
+      table[5 * k + 3] = A.wc_shape[k].a_den;
+      table[5 * k + 4] = A.wc_shape[k].b_fac;
+    }
+  }
+}
+// slot k's shape for a PRE kernel
+__device__ __forceinline__ WcShape wc_shape_of(const SweepArgs& A, int k) {
+#ifdef FMH_X_WCLDS
+  WcShape sh;
+  const double* t = wc_shape_table() + 5 * k;
+  sh.s2_den = t[0]; sh.rm1_over_r = t[1]; sh.nbar_m1 = t[2]; sh.a_den = t[3]; sh.b_fac = t[4];
+  sh.live = (int)((A.wc_live_mask >> k) & 1u);
+  sh.s2_ok = (int)((A.wc_s2ok_mask >> k) & 1u);
+  return sh;
+#else
+  return A.wc_shape[k];
+#endif
+}
+// a count or a sum of counts as f64: every operand here fits 32 bits unless the groups overlap on rows of 2^29 columns and more; the
+// u64 -> f64 conversion is four VALU instructions, the u32 one is one, the value is the same
+__device__ __forceinline__ double count_to_f64(unsigned long long x) {
+#ifdef FMH_X_WCLDS
+  return x <= 0xFFFFFFFFull ? (double)(uint32_t)x : (double)x;
+#else
+  return (double)x;
+#endif
+}
+
 // numerator_s_squared = sum n_i (p_i - p)^2 is accumulated by the caller; this finishes a and b.  rcp3 = the slot's three shared
 // reciprocals (PRE) or null.
 template <bool PRE>
@@ -403,7 +451,7 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
     double wa = 0.0, wb = 0.0;
     if (valid >= 2) {  // stats.rs:1925-1930
       WcShape sh;
-      if constexpr (PRE) sh = A.wc_shape[0]; else sh = wc_shape<P>(n, use);
+      if constexpr (PRE) sh = wc_shape_of(A, 0); else sh = wc_shape<P>(n, use);
       if (sh.live) {
 #pragma unroll
         for (int al = 0; al < NA; ++al) {
@@ -411,7 +459,7 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
 #pragma unroll
           for (int i = 0; i < P; ++i) if (use[i]) total_target += c[al][i];
           double global_freq = 0.0;
-          if (total_called > 0) global_freq = PRE ? div_shared((double)total_target, (double)total_called, rcp[P]) : (double)total_target / (double)total_called;
+          if (total_called > 0) global_freq = PRE ? div_shared(count_to_f64(total_target), count_to_f64(total_called), rcp[P]) : (double)total_target / (double)total_called;
           double num = 0.0;
 #pragma unroll
           for (int i = 0; i < P; ++i) if (use[i]) { double diff_p = freq[al][i] - global_freq; num += nd[i] * diff_p * diff_p; }
@@ -435,7 +483,7 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
       if (both && valid >= 2) {
         WcShape sh;
         if constexpr (PRE) {
-          sh = A.wc_shape[k];
+          sh = wc_shape_of(A, k);
         } else {
           const uint32_t pn[2] = {n[i], n[j]};
           const bool pu[2] = {true, true};
@@ -447,8 +495,8 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
           for (int al = 0; al < NA; ++al) {
             double pair_global = 0.0;
             if (pair_total > 0) {
-              const double pair_target = (double)((unsigned long long)c[al][i] + c[al][j]);
-              pair_global = PRE ? div_shared(pair_target, (double)pair_total, rcp[P + 1 + 3 * NWS + (k - 1)]) : pair_target / (double)pair_total;
+              const double pair_target = PRE ? count_to_f64((unsigned long long)c[al][i] + c[al][j]) : (double)((unsigned long long)c[al][i] + c[al][j]);
+              pair_global = PRE ? div_shared(pair_target, count_to_f64(pair_total), rcp[P + 1 + 3 * NWS + (k - 1)]) : pair_target / (double)pair_total;
             }
             double num = 0.0;
             { double diff_p = freq[al][i] - pair_global; num += nd[i] * diff_p * diff_p; }
@@ -572,8 +620,21 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
 // the byte cores: U 16-byte vectors (128 columns each) per lane in flight, clamped addresses, zero-padded masks.
 // LPR lanes share a row: 16 (one DPP row, 256 B contiguous per load instruction) or 4 (one quad, 64 B per instruction and
 // a two-step reduction: packed rows are short - C4 is 40 vectors - and four lanes cover them with no idle slots).
+// acc + popcount(x) as ONE instruction: v_bcnt_u32_b32 adds its second operand.  Written as `acc + __builtin_popcount(x)` LLVM reassociates
+// the sums of a row into a tree for instruction-level parallelism - v_bcnt x, 0; v_bcnt y, 0; v_add3 acc, a, b: three instructions for two
+// popcounts (148 v_add3 per tile of the four-group kernels, 8 % of their VALU instructions) - which a VALU-bound kernel with four independent
+// chains per row (one per group) does not need.
+__device__ __forceinline__ uint32_t bcnt_add(uint32_t x, uint32_t acc) {
+#ifdef FMH_X_BCNT
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+#else
+  return acc + __builtin_popcount(x);
+#endif
+}
 __device__ __forceinline__ uint32_t popc128(const uint4& v, uint32_t acc) {
-  acc += __builtin_popcount(v.x); acc += __builtin_popcount(v.y); acc += __builtin_popcount(v.z); acc += __builtin_popcount(v.w);
+  acc = bcnt_add(v.x, acc); acc = bcnt_add(v.y, acc); acc = bcnt_add(v.z, acc); acc = bcnt_add(v.w, acc);
   return acc;
 }
 __device__ __forceinline__ uint4 and128(const uint4& a, const uint4& b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
@@ -882,28 +943,45 @@ template <int P, int MODE, bool MISSING, bool GENERAL>
 __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx, bool row_ok,
                                               const SiteTally<P>& t, double hud_dot, const WcSite<P>& wc,
                                               LaneTotals<P, MODE>& T, const uint32_t (*c4)[P] = nullptr) {
-  const bool dense = A.formula != kFormulaSparse;
   // the reference takes the no-missing biallelic arms only on a dense matrix without a mask whose
   // max_allele <= 1 (stats.rs:3191/3218, 4454/4485); build_dense_population_summary (1392, 1409)
   // always uses dense_pi_from_counts
-  const bool nomiss_arm = A.formula == kFormulaDense && !MISSING && !GENERAL;
+  auto pi_by = [&](int formula, int p) {
+    const double ssq = (double)t.ssq[p];
+    if (formula == kFormulaSparse) return pi_sparse(t.n[p], ssq);
+    if (formula == kFormulaDense && !MISSING && !GENERAL) return pi_dense_nomissing(t.n[p], t.alt[p], ssq);
+    return pi_dense(t.n[p], ssq);
+  };
+#ifdef FMH_X_SADDR
+  // Every per-site track of a tile is written at (a wave-uniform base) + lane: said so to the compiler - the index of the tile's first row is
+  // read back as a scalar - each store becomes scalar base + 32-bit lane offset (two SALU instructions) instead of a 64-bit VALU address per
+  // store (v_lshl_add_u64 / v_mad_u64_u32 per track: 84 per tile of the four-group W&C kernel).
+  {
+    const uint32_t lane_id = threadIdx.x & 63;
+    const unsigned long long b = (unsigned long long)out_idx - lane_id;
+    const size_t ub = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    out_idx = ub + lane_id;
+  }
+#endif
+  // the fused region sweep gives the population totals and the Hudson part their own formula sets (run_vcf: calculate_pi_dense for the
+  // regional pi, the sparse per-site path for Hudson); every other sweep has one formula for both (hf == A.formula)
+  const int hf = A.hudson_formula_p1 ? A.hudson_formula_p1 - 1 : A.formula;
+  const bool dense = hf != kFormulaSparse;
 
-  double pi[P];
+  double pi[P];   // by the HUDSON formula (what the Hudson records use)
   bool pi_ok[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const uint32_t n = t.n[p];
     pi_ok[p] = n >= 2;
-    double v = 0.0;
+    double v = 0.0, v_pop = 0.0;
     if (pi_ok[p]) {
-      const double ssq = (double)t.ssq[p];
-      if (!dense) v = pi_sparse(n, ssq);
-      else if (nomiss_arm) v = pi_dense_nomissing(n, t.alt[p], ssq);
-      else v = pi_dense(n, ssq);
+      v_pop = pi_by(A.formula, p);
+      v = hf == A.formula ? v_pop : pi_by(hf, p);
     }
     pi[p] = v;
     if (row_ok) {
-      if (pi_ok[p]) T.pop_pi[p] += v; else T.pop_unc[p] += 1;
+      if (pi_ok[p]) T.pop_pi[p] += v_pop; else T.pop_unc[p] += 1;
       if (t.distinct[p] >= 2) T.pop_seg[p] += 1;
       if (p < A.n_groups) {
         if (A.alt) site_store(A.alt + ((size_t)p * A.row_count + out_idx), t.alt[p]);
@@ -913,19 +991,24 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
   }
 
   if constexpr ((MODE & kModeDiversity) != 0) {
-    // calculate_per_site_diversity, stats.rs:4710-4725 (population 0)
-    const uint32_t n = t.n[0];
-    double pv, tv;
-    if (n < 2) { pv = f64_nan(); tv = f64_nan(); }
-    else {
-      if (t.distinct[0] > 1) { double denom = A.harmonic[n - 1]; tv = denom > 0.0 ? 1.0 / denom : 0.0; }
-      else tv = 0.0;
-      pv = pi_sparse(n, (double)t.ssq[0]);
-    }
-    if (row_ok) {
-      if (A.site_pi) site_store(A.site_pi + (out_idx), pv);
-      if (A.site_theta) site_store(A.site_theta + (out_idx), tv);
-      if (A.site_distinct) site_store(A.site_distinct + (out_idx), t.distinct[0]);
+    // calculate_per_site_diversity, stats.rs:4710-4725, for every group of the sweep (one for fmh_diversity_sites, both of the pair for
+    // the fused region sweep): tracks [P][row_count]
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t n = t.n[p];
+      double pv, tv;
+      if (n < 2) { pv = f64_nan(); tv = f64_nan(); }
+      else {
+        if (t.distinct[p] > 1) { double denom = A.harmonic[n - 1]; tv = denom > 0.0 ? 1.0 / denom : 0.0; }
+        else tv = 0.0;
+        pv = pi_sparse(n, (double)t.ssq[p]);
+      }
+      if (row_ok && p < A.n_groups) {
+        const size_t o = (size_t)p * A.row_count + out_idx;
+        if (A.site_pi) site_store(A.site_pi + o, pv);
+        if (A.site_theta) site_store(A.site_theta + o, tv);
+        if (A.site_distinct) site_store(A.site_distinct + o, t.distinct[p]);
+      }
     }
   }
 
@@ -1172,6 +1255,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
 
   if constexpr ((MODE & kModeWc) != 0 && !MISSING) {
     wc_rcp_init<P>(A);
+    wc_shape_init<P>(A);
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
@@ -1595,7 +1679,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel_pipe(const SweepArgs A) {
     staged[i] = v < nvec ? *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(A.mask_bits) + (size_t)p * (A.mask_pitch / 8) + (size_t)v * 16)
                          : make_uint4(0, 0, 0, 0);
   }
-  if constexpr ((MODE & kModeWc) != 0) wc_rcp_init<P>(A);
+  if constexpr ((MODE & kModeWc) != 0) { wc_rcp_init<P>(A); wc_shape_init<P>(A); }
   __syncthreads();
   LaneTotals<P, MODE> T;
   T.clear();

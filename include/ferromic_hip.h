@@ -241,6 +241,27 @@ int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, size_t row_beg
                         double* d_pi, double* d_theta, uint32_t* d_called, uint32_t* d_distinct,
                         fmh_pop_totals* h_totals, void* stream);
 
+/* ---- fused region sweep: summaries + per-site diversity of groups 0 and 1 (+ the Hudson pair) in ONE read ---------------------- */
+typedef struct { /* calculate_per_site_diversity's SiteDiversity (stats.rs:185-190) of BOTH groups; nullable */
+  double* d_pi;    /* [2][row_count] */
+  double* d_theta; /* [2][row_count] */
+} fmh_pair_diversity_sites;
+/*
+ * What the reference's region driver (process.rs:2468-3653) computes for haplotype groups 0 and 1 of one variant set in separate walks -
+ * process_variants per group (segregating sites, pi: calculate_pi_for_population 4599-4614; per-site diversity: 4628-4806) and the
+ * Hudson pair (calculate_hudson_fst_for_pair_with_sites 3619-3625) - from one pass over the matrix:
+ *   h_totals->pop[0..1]  the population summaries by `summary_formula`
+ *   diversity            per-site pi / theta of both groups (always the sparse formulas, as the reference)
+ *   hudson_formula >= 0  per-site Hudson records into `sites` and the Hudson totals by THAT formula set (the driver uses
+ *                        FMH_FORMULA_DENSE for the regional pi of a diploid dense matrix and FMH_FORMULA_SPARSE for Hudson);
+ *   hudson_formula  < 0  no Hudson part (h_totals' Hudson fields are zero; sites->d_alt / d_called are still written when given).
+ * Every value is the bits of the separate calls (same kernel code after the counts); fmh_population_summaries + 2 x fmh_diversity_sites +
+ * fmh_hudson_sweep read the matrix four times, this reads it once.
+ */
+int fmh_pair_region_sweep(const fmh_matrix* m, const fmh_groups* g /* exactly 2 groups */, size_t row_begin, size_t row_count,
+                          int summary_formula, int hudson_formula_or_negative, const fmh_pair_diversity_sites* diversity_or_null,
+                          const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_totals, void* stream);
+
 /* ---- Weir & Cockerham sweep -------------------------------------------------------------------- */
 enum fmh_wc_state { /* FstEstimate variants, stats.rs:37-126 */
   FMH_WC_CALCULABLE = 0,
@@ -377,6 +398,14 @@ int fmh_population_summaries_sharded_begin(fmh_comm* c, const fmh_matrix* m, con
 int fmh_population_summaries_sharded_end(fmh_comm* c, fmh_pop_totals* h_global_totals /*[n_groups]*/);
 int fmh_population_summaries_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int formula,
                                      uint32_t* d_alt, uint32_t* d_called, fmh_pop_totals* h_global_totals, void* stream);
+/* fmh_pair_region_sweep over this rank's slab, totals (population summaries + Hudson) summed over the ranks the same way; collected by
+ * fmh_hudson_sweep_sharded_end (the totals struct is the same) */
+int fmh_pair_region_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula,
+                                        int hudson_formula_or_negative, const fmh_pair_diversity_sites* diversity_or_null,
+                                        const fmh_hudson_sites* sites_or_null, void* stream);
+int fmh_pair_region_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count, int summary_formula,
+                                  int hudson_formula_or_negative, const fmh_pair_diversity_sites* diversity_or_null,
+                                  const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_global_totals, void* stream);
 
 /*
  * Packing of the totals structs into the f64 + u64 vectors a sum-reduce moves (fmh_allreduce_totals, or MPI / any other

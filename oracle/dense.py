@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle_dense.so")
+LIB_PATH = os.environ.get("FERROMIC_ORACLE_LIB") or os.path.join(_HERE, "liboracle_dense.so")  # the override: the sanitizer build (oracle/Makefile asan)
 
 
 class PopTotals(C.Structure):

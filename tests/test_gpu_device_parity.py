@@ -676,3 +676,64 @@ def test_upload_routes_agree(dev, S, N, max_allele, p_missing):
             assert got.totals == base.totals and got.pop == base.pop
     with pytest.raises(Exception, match="allele plane"):
         dev.DeviceMatrix.from_host_planes(planes[:1], called, S, N, 2, 3)
+
+
+@pytest.mark.parametrize("S,N,max_allele,p_missing", [(300, 37, 1, 0.0), (190, 61, 1, 0.07), (130, 45, 3, 0.0), (130, 45, 5, 0.1), (70, 2500, 1, 0.0),
+                                                      (5000, 450, 1, 0.0), (4097, 3000, 1, 0.02), (33, 70000, 1, 0.0), (64, 8, 2, 0.3), (1, 3, 1, 0.0)])
+@pytest.mark.parametrize("layout", ["packed", "bytes"])
+def test_fused_region_sweep_equals_the_separate_calls(dev, fmh_opts, S, N, max_allele, p_missing, layout):
+    """fmh_pair_region_sweep reads the matrix once for what fmh_population_summaries + 2 x fmh_diversity_sites + fmh_hudson_sweep read four
+    times: every per-site track must be the same bits, every integer total equal, the f64 totals equal to 1e-12 (another grid sums the
+    partials in another order) - with one formula for both parts and with the region driver's pair (dense summaries, sparse Hudson), with
+    and without the Hudson part, on a row range that starts inside the matrix."""
+    import ctypes as C
+
+    from ferromic_amd import _abi
+
+    lib = _abi.load()
+    rng = np.random.default_rng(S * 31 + N + max_allele)
+    m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
+    if layout == "bytes":
+        fmh_opts.setenv("FMH_LAYOUT", "bytes")
+    dm = upload(dev, m)
+    cut = max(1, N // 3)
+    lists = [H.haps_for_samples(range(0, cut)), H.haps_for_samples(range(cut, max(cut + 1, N - 1)))]
+    g2 = dev.Groups.from_haplotype_lists(dm, lists)
+    g1 = [dev.Groups.from_haplotype_lists(dm, lists[:1]), dev.Groups.from_haplotype_lists(dm, lists[1:])]
+    r0, rows = (0, S) if S < 20 else (7, S - 11)
+    for summary_formula, hudson_formula in ((dev.FORMULA_SPARSE, dev.FORMULA_SPARSE), (dev.FORMULA_DENSE, dev.FORMULA_SPARSE), (dev.FORMULA_DENSE, -1)):
+        bufs = {k: dev.DeviceBuffer(dm.device, 8 * 2 * max(rows, 1)) for k in ("pi", "theta")}
+        for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+            bufs[k] = dev.DeviceBuffer(dm.device, 8 * max(rows, 1))
+        for k in ("alt", "called"):
+            bufs[k] = dev.DeviceBuffer(dm.device, 4 * 2 * max(rows, 1))
+        div = _abi.PairDiversitySites(bufs["pi"].ptr, bufs["theta"].ptr)
+        sites = _abi.HudsonSites(*(bufs[k].ptr for k in ("fst", "dxy", "pi1", "pi2", "num", "den", "alt", "called")))
+        tot = _abi.HudsonTotals()
+        _abi.check(lib.fmh_pair_region_sweep(dm._h, g2._h, r0, rows, summary_formula, hudson_formula, C.byref(div), C.byref(sites), C.byref(tot), None))
+        what = f"{S}x{N} alleles<={max_allele} missing {p_missing} {layout} formulas {summary_formula}/{hudson_formula}"
+        ps = dev.population_summaries(dm, g2, summary_formula, r0, rows)
+        for p in range(2):
+            for k in ("haplotype_capacity", "segregating_sites", "uncallable_sites"):
+                assert getattr(tot.pop[p], k) == ps.totals[p][k], (what, p, k)
+            assert tot.pop[p].pi_sum == pytest.approx(ps.totals[p]["pi_sum"], rel=1e-12, abs=1e-300), what
+            dv = dev.diversity_sites(dm, g1[p], r0, rows)
+            H.assert_bits_equal(bufs["pi"].to_numpy(np.float64, 2 * rows).reshape(2, rows)[p], dv.pi, f"site pi group {p} {what}")
+            H.assert_bits_equal(bufs["theta"].to_numpy(np.float64, 2 * rows).reshape(2, rows)[p], dv.theta, f"site theta group {p} {what}")
+        assert np.array_equal(bufs["alt"].to_numpy(np.uint32, 2 * rows).reshape(2, rows), ps.alt) or max_allele > 1, what
+        assert np.array_equal(bufs["called"].to_numpy(np.uint32, 2 * rows).reshape(2, rows), ps.called), what
+        if hudson_formula >= 0:
+            hs = dev.hudson_sweep(dm, g2, hudson_formula, r0, rows)
+            for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+                H.assert_bits_equal(bufs[k].to_numpy(np.float64, rows), hs.sites[k], f"{k} {what}")
+            for k, v in hs.totals.items():
+                got = getattr(tot, k)
+                if isinstance(v, int):
+                    assert got == v, (what, k)
+                else:
+                    assert got == pytest.approx(v, rel=1e-12, abs=1e-300), (what, k)
+        else:
+            assert tot.sites_with_components == 0 and tot.numerator_sum == 0.0 and tot.site_num_sum == 0.0, what
+    one = dev.Groups.from_haplotype_lists(dm, lists[:1])
+    assert lib.fmh_pair_region_sweep(dm._h, one._h, 0, S, 0, 0, None, None, None, None) == _abi.FMH_ERR_INVALID
+    assert lib.fmh_pair_region_sweep(dm._h, g2._h, 0, S, 7, 0, None, None, None, None) == _abi.FMH_ERR_INVALID

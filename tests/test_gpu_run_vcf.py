@@ -16,7 +16,7 @@ from oracle import run_vcf_ref as V
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")
+BIN = os.environ.get("FERROMIC_RUN_VCF_BIN") or os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")  # the override: the sanitizer build (make asan)
 
 
 def run_binary(out_csv, **kw):
@@ -367,6 +367,33 @@ def test_large_region_split_into_site_slabs(tmp_path, devices):
     # the same command without the override leaves these small regions whole: identical to the single-worker files
     whole = run_binary(str(tmp_path / "whole" / "out.csv"), devices=devices, **kw)
     assert whole == one
+
+
+@pytest.mark.parametrize("nth", [0, 2, 5])
+def test_slab_failure_is_an_error_not_a_hang(tmp_path, nth):
+    """one slab failing before its collective left its peers blocked for ever (the in-process rendezvous and RCCL have no
+    timeout, and the region holds the shard lock).  FERROMIC_INJECT_SLAB_FAILURE=<slab>:<nth> makes slab 1 throw at the nth slab-parallel
+    step of the run (matrix upload, a summaries / W&C / Hudson sweep): the failing thread aborts the communicator group, the peers
+    return with an error, the region is logged as DROPPED and the run ENDS - and the regions after it are computed (the communicators
+    are re-created): their rows equal the clean run's."""
+    n_sites = 6_000
+    kw = make_big_cohort(tmp_path, 23, n_sites, 24, n_sites * 5)
+    clean = run_binary(str(tmp_path / "clean" / "out.csv"), devices="0,0,0", env={"FERROMIC_SHARD_MIN_BYTES": "1"}, **kw)
+    out_csv = str(tmp_path / "hurt" / "out.csv")
+    os.makedirs(os.path.dirname(out_csv), exist_ok=True)
+    cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--output_file", out_csv,
+           "--config_file", kw["config_file"], "--devices", "0,0,0", "--workers_per_device", "1"]
+    if kw.get("enable_fst"):
+        cmd += ["--fst"]
+    env = dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_SHARD_MIN_BYTES="1", FERROMIC_INJECT_SLAB_FAILURE=f"1:{nth}")
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)  # a hang ends here
+    log = res.stdout + res.stderr
+    assert "injected failure of slab 1" in log and "DROPPED" in log, log[-3000:]
+    assert res.returncode == 0, log[-3000:]
+    hurt_rows = open(out_csv).read().splitlines()
+    clean_rows = clean["out.csv"].splitlines()
+    assert hurt_rows[0] == clean_rows[0] and len(hurt_rows) == len(clean_rows) - 1  # exactly one region was dropped
+    assert set(hurt_rows[1:]) <= set(clean_rows[1:])  # every other region: the very rows of the clean run
 
 
 def test_single_chromosome_mode(tmp_path):
