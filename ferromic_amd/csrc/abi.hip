@@ -986,7 +986,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   // per CU their LDS (wide rows: the mask image takes it, and a tile of megabytes has nothing to gain from deferral anyway; measured: 200 000
   // columns fell from 3 to 2 workgroups per CU, 0.45 -> 0.69 ms, before the cap).  The deferring kernels have no other tile loop, so one tile's
   // room is always added.
-  if (!mfma && !general && lpr == 16 && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing)) {  // == defer_kernel<...>()
+  if (!mfma && defer_rule(P, mode, missing, general, lpr)) {  // the rule the kernel template is instantiated with
     const int e = (int)opt.defer_tiles.load();  // measurements (1 = the undeferred order); default -1 = by the launch size (launch_one)
     a.defer_tiles = e >= 1 && e <= kDeferTiles ? e : -1;
     smem = round_up(smem, 16);

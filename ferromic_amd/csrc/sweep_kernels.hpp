@@ -1192,12 +1192,19 @@ constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL 
 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
-template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
-constexpr bool defer_kernel() {
+// ONE rule for the kernel template and the host (enqueue_sweep sizes the parked counts' LDS with it): which kernels have the deferring tile loop
+constexpr bool defer_rule(int P, int mode, bool missing, bool general, int lpr) {
   // sixteen-lane rows only: on four-lane rows (at most 4 096 columns) deferral was level or behind at 1 000 haplotypes and 3-7 % ahead on long
   // launches at 2 500, while the restructured loop itself cost the C2 kernel (1 M x 1 000) 7 % - those kernels keep the plain tile loop
-  return !GENERAL && LPR == 16 && (P <= 2 ? (MODE & kModeWc) == 0 || !MISSING : P == 4 && !MISSING);
+#ifdef FMH_X_DEFER4
+  const bool lanes_ok = lpr == 16 || lpr == 4;
+#else
+  const bool lanes_ok = lpr == 16;
+#endif
+  return !general && lanes_ok && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing);
 }
+template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
+constexpr bool defer_kernel() { return defer_rule(P, MODE, MISSING, GENERAL, LPR); }
 template <int P, int MODE, bool MISSING>
 constexpr int defer_values() { return MISSING ? 2 * P + ((MODE & kModeWc) != 0 ? 1 : 0) : P; }
 template <int P, int MODE, bool MISSING>

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void sweep_mfma_kernel(const SweepArgs A) {
     const uint32_t p = i / mstride, v = i - p * mstride;
     staged[i] = v < nvec ? load_vec(A.masks + (size_t)p * A.mask_pitch + (size_t)v * 16) : make_uint4(0, 0, 0, 0);
   }
-  if constexpr ((MODE & kModeWc) != 0) wc_rcp_init<P>(A);  // nothing is missing on this route: shared-denominator divisions
+  if constexpr ((MODE & kModeWc) != 0) { wc_rcp_init<P>(A); wc_shape_init<P>(A); }  // nothing is missing on this route: shared-denominator divisions
   __syncthreads();
 
   const int lane = threadIdx.x & 63;

@@ -28,6 +28,8 @@ CONFIGS = {
     "C2x10": (10_000_000, 1_000, 2, "hudson", 0.0),  # C2 rows, 10x the sites: separates fixed launch cost from per-row efficiency
     "NARROW": (10_000_000, 640, 2, "hudson", 0.0),  # 40 vectors per row: the per-row instruction stream a bit-packed C4 row would have
     "NARROWm": (10_000_000, 640, 2, "hudson", 0.01),
+    "C4f": (10_000_000, 5_000, 2, "pair", 0.0),  # the fused region sweep (summaries + both groups' diversity + Hudson, one read) at C4's width
+    "C2f": (1_000_000, 1_000, 2, "pair", 0.0),
     "WIDE": (100_000, 200_000, 2, "hudson", 0.0),  # byte masks beyond the LDS budget: bit masks in LDS (FMH_MASK_MODE=1: global)
 }
 
@@ -74,6 +76,14 @@ def main():
 
             def step():
                 _abi.check(lib.fmh_hudson_sweep(dm._h, g._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), C.byref(tot), None))
+        elif kind == "pair":
+            sites = _abi.HudsonSites(buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S), buf(8 * S))
+            div = _abi.PairDiversitySites(buf(16 * S), buf(16 * S))
+            tot = _abi.HudsonTotals()
+            w_out = 64 + 32  # fst, dxy, pi1, pi2, num, den f64 + alt, called u32 x 2 groups; diversity pi, theta f64 x 2 groups
+
+            def step():
+                _abi.check(lib.fmh_pair_region_sweep(dm._h, g._h, 0, S, _abi.FORMULA_DENSE, _abi.FORMULA_SPARSE, C.byref(div), C.byref(sites), C.byref(tot), None))
         elif kind == "wc":
             nw = 1 + P * (P - 1) // 2
             pa, pb, ps, pn = buf(8 * nw * S), buf(8 * nw * S), buf(nw * S), buf(4 * P * S)
@@ -101,8 +111,13 @@ def main():
             def step():
                 _abi.check(lib.fmh_population_summaries(dm._h, g._h, 0, S, _abi.FORMULA_SUMMARY, pa, pc, tot, None))
 
-        for _ in range(2):
+        # warm-up by TIME, not by count: the first ~10 ms of launches after an idle period run 10-20 % slower (clocks / power state ramping:
+        # ab_env's first block of 20 C3 launches measured 0.50 ms, the following blocks 0.43), which is most of a short kernel's whole measurement
+        t_w = time.perf_counter()
+        n_w = 0
+        while n_w < 3 or (time.perf_counter() - t_w < float(os.environ.get("MEASURE_WARMUP_S", "0.05")) and n_w < 2000):
             step()
+            n_w += 1
         lib.fmh_timing_enable(1)
         lib.fmh_timing_reset()
         steps = 10
@@ -120,7 +135,7 @@ def main():
         print(json.dumps({"config": name, "layout": layout, "sites": S, "haplotypes": H, "populations": P, "kind": kind, "missing": miss,
                           "sites_per_s": S * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": k_s * 1e3,
                           "bytes_per_site": b_site, "achieved_GBs": b_site * S / k_s / 1e9,
-                          "frac_of_8TBs": b_site * S / k_s / 8e12, "u8_layout_equivalent_GBs": b_site_u8 * S / k_s / 1e9}), flush=True)
+                          "frac_of_8TBs": b_site * S / k_s / 8e12, "warmup_launches": n_w, "u8_layout_equivalent_GBs": b_site_u8 * S / k_s / 1e9}), flush=True)
         del bufs, g, dm
 
 
