@@ -257,6 +257,10 @@ def parse_args():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded path (communicator, device-side reduce, pipelining) even with one rank: measures its "
                          "software cost on a one-GPU box")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: run the pipelined steps on an explicit stream with FMH_GRAPH=1 - a repeated step is replayed from a captured hipGraph "
+                         "(sweep + finalize + D2H as one launch); measures the fixed cost per step against the eager path")
+    ap.add_argument("--explicit-stream", action="store_true", help="N = 1: the eager pipelined steps on the same explicit stream (the A side of --graph)")
     ap.add_argument("--no-verify-n1", action="store_true",
                     help="N > 1, strong scaling: skip rank 0's own sweep of the whole cohort after the timed region (parity_vs_n1.computed)")
     ap.add_argument("--sync-steps", action="store_true",
@@ -344,6 +348,13 @@ def main() -> int:
         # N > 1 run the same step structure - the next sweep is enqueued while the previous one's totals travel to the host
         comm = sharding.Comm.local(local_rank)
 
+    user_stream = None
+    if args.graph or args.explicit_stream:
+        user_stream = torch.cuda.Stream(device=local_rank)  # a non-blocking stream of the caller's own (the NULL stream cannot be captured)
+        if args.graph:
+            _abi.set_option("FMH_GRAPH", 1)
+    stream_ptr = C.c_void_p(user_stream.cuda_stream) if user_stream is not None else None
+
     def barrier():
         if dist is not None and world > 1:
             dist.barrier()
@@ -392,7 +403,7 @@ def main() -> int:
         def step():
             if comm is not None:
                 # enqueue this step's sweep + device-side reduce, then collect the previous step's region-wide totals
-                _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), None))
+                _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), stream_ptr))
                 state["in_flight"] += 1
                 if state["in_flight"] > 1:
                     _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(state["totals"])))
@@ -412,7 +423,7 @@ def main() -> int:
                     state["totals"] = merged
             barrier()
             torch.cuda.synchronize()
-            _abi.check(lib.fmh_stream_synchronize(local_rank, None))
+            _abi.check(lib.fmh_stream_synchronize(local_rank, stream_ptr))
 
         # the same sweep over the u8 rows (one byte per haplotype, the layout the reference and north_star name), timed while the
         # matrix still holds them: its HBM fraction is reported next to the headline; then the rows are released
@@ -538,6 +549,7 @@ def main() -> int:
             "parallelism": (f"region-sharded x{world}: one contiguous slab per GPU, per-site tracks stay on the owning GPU, the 128 regional "
                             f"accumulators summed by {reduce_name}, pipelined one step deep") if sharded else
                            ("one GPU, no collective; sweeps pipelined two deep (fmh_hudson_sweep_sharded_begin / _end on a local one-rank communicator)"
+                            + (", each step replayed from a captured hipGraph (FMH_GRAPH=1)" if args.graph else "") + (", explicit stream" if user_stream is not None else "")
                             if comm is not None else "one GPU, no collective, one blocking fmh_hudson_sweep per step"),
             "seed": first["seed"],
             "generate_s": first["gen_s"],

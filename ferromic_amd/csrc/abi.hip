@@ -73,8 +73,8 @@ const OptionRow kOptionRows[] = {
     {"FMH_PD_KCHUNK", &Options::pd_kchunk, 0, nullptr},
     {"FMH_PD_SB", &Options::pd_sb, 0, nullptr},
     {"FMH_PD_OCC", &Options::pd_occ, 0, nullptr},
-    {"FMH_WC_VARIANT", &Options::wc_variant, 0, nullptr},
-    {"FMH_GRAPH", &Options::graph, 1, nullptr},
+    {"FMH_PIPE", &Options::pipe, -1, nullptr},
+    {"FMH_GRAPH", &Options::graph, 0, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -124,6 +124,7 @@ extern "C" int fmh_set_option(const char* key, const char* value_or_null) {
     if (value_or_null && !parse_option(row, value_or_null, &x))
       return fail(FMH_ERR_INVALID, "option %s: cannot parse '%s'%s%s", key, value_or_null, row.words ? " (integers or " : "", row.words ? row.words : "");
     (o.*row.field).store(x);
+    o.generation.fetch_add(1);
     return FMH_OK;
   }
   return fail(FMH_ERR_INVALID, "unknown option '%s'", key);

@@ -67,8 +67,9 @@ struct Options {
   std::atomic<long long> comm_host{0};           // FMH_COMM_TRANSPORT = host: in-process rendezvous instead of RCCL (fmh_comm_init_all)
   std::atomic<long long> upload_threads{0};      // FMH_UPLOAD_THREADS: host packer threads; 0 = the CPU share
   std::atomic<long long> pd_two_planes{0}, pd_int8{0}, pd_planes_bytes{(long long)8 << 30}, pd_kchunk{0}, pd_sb{0}, pd_occ{0};  // FMH_PD_*: pairwise path
-  std::atomic<long long> wc_variant{0};          // FMH_WC_VARIANT: W&C four-lane kernel variant (measurements; 0 = default)
-  std::atomic<long long> graph{1};               // FMH_GRAPH: 0 = never replay sharded sweeps from a captured hipGraph
+  std::atomic<long long> pipe{-1};               // FMH_PIPE: the pipelined tile loop on four-lane rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead (one and two groups)
+  std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
+  std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };
 Options& options();
 

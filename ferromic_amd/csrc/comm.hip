@@ -167,6 +167,11 @@ struct ShardSlot {
   uint64_t sizes[FMH_MAX_GROUPS] = {0};
   size_t row_count = 0;
   unsigned long long* h_aux = nullptr;  // pinned: scalars added to the finalised vector before the reduce (W&C sites_attempted)
+  // FMH_GRAPH=1, local communicator: the slot's whole step (sweep, finalize, D2H) captured once and replayed while the call repeats
+  hipGraphExec_t graph = nullptr;
+  std::string graph_key;
+  hipEvent_t graph_done = nullptr;
+  bool via_graph = false;
 };
 enum ShardKind : int { kShardHudson = 0, kShardWc = 1, kShardPops = 2 };
 const char* kind_name(int k) { return k == kShardHudson ? "Hudson" : k == kShardWc ? "W&C" : "population-summaries"; }
@@ -222,6 +227,7 @@ int comm_alloc(fmh_comm* c) {
     HIP_TRY(hipEventCreate(&s.red0));
     HIP_TRY(hipEventCreate(&s.red1));
     HIP_TRY(hipHostMalloc((void**)&s.h_aux, 8 * 8, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&s.graph_done, hipEventDisableTiming));
   }
   return FMH_OK;
 }
@@ -237,6 +243,8 @@ void comm_free(fmh_comm* c) {
     (void)hipFree(s.part_f64); (void)hipFree(s.part_u64); (void)hipFree(s.out_f64); (void)hipFree(s.out_u64);
     (void)hipHostFree(s.h_f64); (void)hipHostFree(s.h_u64);
     (void)hipHostFree(s.h_aux);
+    if (s.graph) (void)hipGraphExecDestroy(s.graph);
+    if (s.graph_done) (void)hipEventDestroy(s.graph_done);
     for (hipEvent_t e : {s.swept, s.reduced, s.ev0, s.ev1, s.red0, s.red1}) if (e) (void)hipEventDestroy(e);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -496,6 +504,43 @@ int sharded_enqueue(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, int m
     HIP_TRY(hipEventRecord(s.reduced, c->stream));
     return FMH_OK;
   };
+  // FMH_GRAPH=1 (opt-in, measurement of the fixed cost per step): on a local communicator with an explicit stream, a call that repeats the
+  // previous one of this slot - same matrix and groups (pointers AND geometry), same rows, outputs, mode, stream and option generation - is
+  // replayed from the hipGraph captured the first time: one hipGraphLaunch instead of sweep + event + finalize + two copies + event.
+  s.via_graph = false;
+  if (options().graph.load() != 0 && c->transport == 2 && st != nullptr && !host_vec && !s.timed) {
+    std::string key;
+    auto put = [&](const void* p, size_t n) { key.append(reinterpret_cast<const char*>(p), n); };
+    const unsigned long long gen = options().generation.load();
+    const void* ptrs[8] = {m, g, st, harmonic, m->p0, m->data, g->masks, g->mask_bits};
+    put(ptrs, sizeof ptrs); put(&mode, sizeof mode); put(&gen, sizeof gen); put(&m->variants, sizeof m->variants); put(&m->columns, sizeof m->columns);
+    put(&m->plane_pitch, sizeof m->plane_pitch); put(&m->pitch, sizeof m->pitch); put(g->sizes, sizeof g->sizes); put(&s.kind, sizeof s.kind);
+    const void* outs[16] = {a.alt, a.called, a.fst, a.dxy, a.pi1, a.pi2, a.num, a.den, a.site_pi, a.site_theta, a.site_distinct, a.wc_a, a.wc_b, a.wc_state, a.acounts, nullptr};
+    put(outs, sizeof outs); put(&a.row_begin, sizeof a.row_begin); put(&a.row_count, sizeof a.row_count); put(&a.formula, sizeof a.formula);
+    put(&a.hudson_formula_p1, sizeof a.hudson_formula_p1);
+    if (!s.graph || s.graph_key != key) {
+      if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      int rc = e == hipSuccess ? body() : fail(FMH_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+      if (e == hipSuccess) {
+        if (rc == FMH_OK && hipStreamWaitEvent(st, s.reduced, 0) != hipSuccess) rc = fail(FMH_ERR_HIP, "joining the communicator's stream into the capture failed");
+        const hipError_t e2 = hipStreamEndCapture(st, &graph);  // always ended, also after a failure inside
+        if (rc == FMH_OK && e2 != hipSuccess) rc = fail(FMH_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e2));
+      }
+      if (rc == FMH_OK && hipGraphInstantiate(&s.graph, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(FMH_ERR_HIP, "hipGraphInstantiate failed");
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc != FMH_OK) { s.graph = nullptr; (void)hipGetLastError(); return rc; }  // nothing ran: a capture executes nothing
+      s.graph_key = key;
+    }
+    HIP_TRY(hipGraphLaunch(s.graph, st));
+    HIP_TRY(hipEventRecord(s.graph_done, st));
+    s.launched = a.row_count != 0;
+    s.via_graph = true;
+    s.busy = true;
+    ++c->head;
+    return FMH_OK;
+  }
   const int rc = body();
   if (rc != FMH_OK) { settle_after_failure(c, st); return rc; }  // the slot was never marked busy: nothing of it may still be in flight
   s.busy = true;
@@ -512,7 +557,7 @@ int sharded_collect(fmh_comm* c, int kind, ShardSlot** out) {
   ShardSlot& s = c->slot[c->tail % FMH_SHARDED_IN_FLIGHT];
   if (s.kind != kind) return fail(FMH_ERR_INVALID, "the oldest sharded sweep in flight is a %s sweep: collect it with its own _end", kind_name(s.kind));
   int rc = FMH_OK;
-  hipError_t e = hipEventSynchronize(s.reduced);
+  hipError_t e = hipEventSynchronize(s.via_graph ? s.graph_done : s.reduced);
   if (e != hipSuccess) {
     rc = fail(FMH_ERR_HIP, "hipEventSynchronize(reduced): %s", hipGetErrorString(e));
     (void)hipStreamSynchronize(c->stream);

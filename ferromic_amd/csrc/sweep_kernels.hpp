@@ -354,25 +354,17 @@ __device__ __forceinline__ void wc_shape_init(const SweepArgs& A) {  // every th
 }
 // slot k's shape for a PRE kernel
 __device__ __forceinline__ WcShape wc_shape_of(const SweepArgs& A, int k) {
-#ifdef FMH_X_WCLDS
   WcShape sh;
   const double* t = wc_shape_table() + 5 * k;
   sh.s2_den = t[0]; sh.rm1_over_r = t[1]; sh.nbar_m1 = t[2]; sh.a_den = t[3]; sh.b_fac = t[4];
   sh.live = (int)((A.wc_live_mask >> k) & 1u);
   sh.s2_ok = (int)((A.wc_s2ok_mask >> k) & 1u);
   return sh;
-#else
-  return A.wc_shape[k];
-#endif
 }
 // a count or a sum of counts as f64: every operand here fits 32 bits unless the groups overlap on rows of 2^29 columns and more; the
 // u64 -> f64 conversion is four VALU instructions, the u32 one is one, the value is the same
 __device__ __forceinline__ double count_to_f64(unsigned long long x) {
-#ifdef FMH_X_WCLDS
   return x <= 0xFFFFFFFFull ? (double)(uint32_t)x : (double)x;
-#else
-  return (double)x;
-#endif
 }
 
 // numerator_s_squared = sum n_i (p_i - p)^2 is accumulated by the caller; this finishes a and b.  rcp3 = the slot's three shared
@@ -624,14 +616,13 @@ __device__ __forceinline__ void count_row_biallelic(const MatrixView& mv, const 
 // the sums of a row into a tree for instruction-level parallelism - v_bcnt x, 0; v_bcnt y, 0; v_add3 acc, a, b: three instructions for two
 // popcounts (148 v_add3 per tile of the four-group kernels, 8 % of their VALU instructions) - which a VALU-bound kernel with four independent
 // chains per row (one per group) does not need.
+// The chain also keeps no partial sums alive: the two-group Hudson kernel went from 153 to 119 VGPRs, the four-group W&C kernel from 206 to
+// 166, the fused region kernel from 203 to a third wave per SIMD (1.51 -> 1.28 ms at C4's shape), and the eight-group kernels stopped
+// spilling into AGPRs.  Time is unchanged where registers were not the limit (profiles/r03/kernel_variants.jsonl).
 __device__ __forceinline__ uint32_t bcnt_add(uint32_t x, uint32_t acc) {
-#ifdef FMH_X_BCNT
   uint32_t r;
   asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
   return r;
-#else
-  return acc + __builtin_popcount(x);
-#endif
 }
 __device__ __forceinline__ uint32_t popc128(const uint4& v, uint32_t acc) {
   acc = bcnt_add(v.x, acc); acc = bcnt_add(v.y, acc); acc = bcnt_add(v.z, acc); acc = bcnt_add(v.w, acc);
@@ -952,17 +943,6 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
     if (formula == kFormulaDense && !MISSING && !GENERAL) return pi_dense_nomissing(t.n[p], t.alt[p], ssq);
     return pi_dense(t.n[p], ssq);
   };
-#ifdef FMH_X_SADDR
-  // Every per-site track of a tile is written at (a wave-uniform base) + lane: said so to the compiler - the index of the tile's first row is
-  // read back as a scalar - each store becomes scalar base + 32-bit lane offset (two SALU instructions) instead of a 64-bit VALU address per
-  // store (v_lshl_add_u64 / v_mad_u64_u32 per track: 84 per tile of the four-group W&C kernel).
-  {
-    const uint32_t lane_id = threadIdx.x & 63;
-    const unsigned long long b = (unsigned long long)out_idx - lane_id;
-    const size_t ub = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-    out_idx = ub + lane_id;
-  }
-#endif
   // the fused region sweep gives the population totals and the Hudson part their own formula sets (run_vcf: calculate_pi_dense for the
   // regional pi, the sparse per-site path for Hudson); every other sweep has one formula for both (hf == A.formula)
   const int hf = A.hudson_formula_p1 ? A.hudson_formula_p1 - 1 : A.formula;
@@ -1196,12 +1176,9 @@ constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL 
 constexpr bool defer_rule(int P, int mode, bool missing, bool general, int lpr) {
   // sixteen-lane rows only: on four-lane rows (at most 4 096 columns) deferral was level or behind at 1 000 haplotypes and 3-7 % ahead on long
   // launches at 2 500, while the restructured loop itself cost the C2 kernel (1 M x 1 000) 7 % - those kernels keep the plain tile loop
-#ifdef FMH_X_DEFER4
-  const bool lanes_ok = lpr == 16 || lpr == 4;
-#else
-  const bool lanes_ok = lpr == 16;
-#endif
-  return !general && lanes_ok && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing);
+  // (round 3 repeated the four-lane experiment with the old loop structure behind this rule: depths 2, 4, 8 against 1 on W&C, summaries
+  // and Hudson sweeps of 1 000 and 2 500 haplotypes all within +-2 %, profiles/r03/defer_four_lane_rows.jsonl)
+  return !general && lpr == 16 && (P <= 2 ? (mode & kModeWc) == 0 || !missing : P == 4 && !missing);
 }
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
 constexpr bool defer_kernel() { return defer_rule(P, MODE, MISSING, GENERAL, LPR); }

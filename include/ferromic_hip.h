@@ -74,7 +74,7 @@ int fmh_device_info(int device, char* h_name, size_t name_cap, int* h_compute_un
  *   FMH_LAYOUT (bytes | packed)   FMH_MASK_MODE (1 | 2)   FMH_DEFER_TILES (1..16)   FMH_PACKED_LPR (4 | 16)   FMH_PACKED_UNROLL
  *   FMH_PACKED_NO_PREFETCH   FMH_COUNTS_MFMA (1 | 2)   FMH_GRID_PER_CU   FMH_GRID_BLOCKS   FMH_MAX_OCC   FMH_UNROLL   FMH_PITCH_ALIGN
  *   FMH_COMM_TRANSPORT (host | rccl)   FMH_UPLOAD_THREADS   FMH_PD_TWO_PLANES   FMH_PD_INT8   FMH_PD_PLANES_BYTES   FMH_PD_KCHUNK
- *   FMH_PD_SB   FMH_PD_OCC   FMH_WC_VARIANT   FMH_GRAPH
+ *   FMH_PD_SB   FMH_PD_OCC   FMH_PIPE   FMH_GRAPH
  * Values are atomics: setting one while another thread launches is safe (that launch sees the old or the new value). */
 int fmh_set_option(const char* key, const char* value_or_null);
 int fmh_get_option(const char* key, long long* h_value);

@@ -10,9 +10,9 @@ for rep in 1 2; do
 for v in base b c d; do
   if [ $v = base ]; then L=ferromic_amd/lib/libferromic_hip.so; else L=build/variants/$v/libferromic_hip.so; fi
   for kind in wc4 sum4; do
-    FMH_LIB_PATH=$L AB_KIND=$kind timeout -k 10 120 python tools/ab_env.py FMH_WC_VARIANT=1 5000000x1250 2>/dev/null | grep '^{' | head -2 | sed "s/^{/{\"lib\": \"$v\", /" >> $O/variants.jsonl
+    FMH_LIB_PATH=$L AB_KIND=$kind timeout -k 10 120 python tools/ab_env.py FMH_PIPE=1 5000000x1250 2>/dev/null | grep '^{' | head -2 | sed "s/^{/{\"lib\": \"$v\", /" >> $O/variants.jsonl
   done
-  FMH_LIB_PATH=$L timeout -k 10 200 python tools/ab_env.py FMH_WC_VARIANT=1 10000000x2500 10000000x500 2>/dev/null | grep '^{' | grep -E '"sites": (10000000|1250000|1000000),' | sed "s/^{/{\"lib\": \"$v\", /" >> $O/variants.jsonl
+  FMH_LIB_PATH=$L timeout -k 10 200 python tools/ab_env.py FMH_PIPE=1 10000000x2500 10000000x500 2>/dev/null | grep '^{' | grep -E '"sites": (10000000|1250000|1000000),' | sed "s/^{/{\"lib\": \"$v\", /" >> $O/variants.jsonl
 done
 done
 cut -c1-230 $O/variants.jsonl

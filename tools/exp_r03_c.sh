@@ -15,7 +15,7 @@ cut -c1-200 $O/defer4.jsonl
 for v in base bd; do
   if [ $v = base ]; then L=ferromic_amd/lib/libferromic_hip.so; else L=build/variants/$v/libferromic_hip.so; fi
   for pv in 0 1; do
-    FMH_LIB_PATH=$L FMH_WC_VARIANT=$pv timeout -k 10 300 python tools/measure_configs.py C2 C3 C3h C2x10 C4 C4f C2f 2>/dev/null | grep '^{' | sed "s/^{/{\"lib\": \"$v\", \"pipe\": $pv, /" >> $O/configs_warm.jsonl
+    FMH_LIB_PATH=$L FMH_PIPE=$pv timeout -k 10 300 python tools/measure_configs.py C2 C3 C3h C2x10 C4 C4f C2f 2>/dev/null | grep '^{' | sed "s/^{/{\"lib\": \"$v\", \"pipe\": $pv, /" >> $O/configs_warm.jsonl
   done
 done
 cut -c1-330 $O/configs_warm.jsonl

@@ -101,7 +101,7 @@ def main():
             "nucleotide_diversity_population_2": pop2.nucleotide_diversity,
             "watterson_theta": lambda: fm.watterson_theta(pop.segregating_sites(), H, L),
             "hudson_fst": lambda: fm.hudson_fst(pop1, pop2).fst,
-            "hudson_dxy": lambda: fm.hudson_dxy(pop1, pop2),
+            "hudson_dxy": lambda: fm.hudson_dxy(pop1, pop2).d_xy,
         }
         for name, fn in metrics.items():
             value, stats = timed(fn, rounds)
