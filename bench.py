@@ -162,8 +162,8 @@ def recorded_traffic(sites: int, haplotypes: int, layout: str):
 # Recorded from N = 1 runs of the default cohort (10 M sites x 5 000 haplotypes, seed 10 002 500, profiles/r02/c4_bench.json and this round's):
 # the integer totals are exact whatever the sharding, so any N must reproduce them; the f64 ratio within the 1e-9 contract.
 N1_RECORDED = {
-    (10_000_000, 5000, 10_002_500): {"segregating_sites": [9949061, 9949159], "hudson_fst": 0.028471767808637662,
-                                     "pi_sum": [3068822.9373544613, 3069429.427405202]},
+    (10_000_000, 5000, 10_002_500): {"segregating_sites": [9949061, 9949159], "sites_with_components": 10_000_000, "dxy_uncallable_sites": 0,
+                                     "hudson_fst": 0.028471767808637662, "pi_sum": [3068822.9373544613, 3069429.427405202]},
 }
 
 

@@ -5,7 +5,7 @@
 # `python3 <script>` itself (no env / shell hop between rocprofv3 and the process that touches the GPU).
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp
@@ -54,19 +54,21 @@ for s in 10000000 5000000 2500000 1250000; do
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_pipelined_local.jsonl
   python3 $R/bench.py --sites $s --steps 50 --warmup 5 --no-cpu-baseline --u8-reference-steps 0 --force-collective 2>/dev/null | grep '^{' >> $O/strong_scaling_step_sizes_sharded_path.jsonl
 done
-step "what the per-site tracks cost next to the read stream: a do-nothing kernel with the sweep's access pattern (tools/microbench/store_bursts.hip)"
-mkdir -p $R/build/micro
-[ -x $R/build/micro/store_bursts ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $R/build/micro/store_bursts $R/tools/microbench/store_bursts.hip
-for wg in 3 4; do $R/build/micro/store_bursts 10000000 7 640 $wg >> $O/store_bursts_packed_row_width.jsonl; done
-$R/build/micro/store_bursts 10000000 7 5008 4 >> $O/store_bursts_u8_row_width.jsonl
-step "same-process A/B of the per-call switches at the C4 shape (tools/ab_env.py: unset vs set, one allocation, best of 3 x 20 launches)"
-for sw in FMH_DEFER_TILES=1 FMH_DEFER_TILES=2 FMH_DEFER_TILES=4 FMH_DEFER_TILES=8 FMH_DEFER_TILES=12 FMH_DEFER_TILES=16 FMH_PACKED_UNROLL=4 FMH_PACKED_UNROLL=2 FMH_PACKED_LPR=4 FMH_GRID_PER_CU=2 FMH_GRID_PER_CU=4 FMH_GRID_PER_CU=6; do
+step "same-process A/B of the library options at the C4 shape and on four-lane rows (tools/ab_env.py: unset vs set, one allocation, best of 3 x 20 launches)"
+for sw in FMH_DEFER_TILES=1 FMH_DEFER_TILES=8 FMH_GRID_PER_CU=2 FMH_GRID_PER_CU=4 FMH_PACKED_UNROLL=4; do
   python3 $R/tools/ab_env.py $sw 10000000x2500 2>/dev/null | grep '^{' >> $O/ab_switches_c4_shape.jsonl
 done
-python3 $R/tools/ab_env.py FMH_DEFER_TILES=1 10000000x500 5000000x1250 5000000x2500:packed:m 2000000x5000 2>/dev/null | grep '^{' >> $O/ab_deferred_epilogues_other_shapes.jsonl
-for k in wc4 sum4; do AB_KIND=$k python3 $R/tools/ab_env.py FMH_DEFER_TILES=1 5000000x1250 2>/dev/null | grep '^{' >> $O/ab_deferred_epilogues_other_shapes.jsonl; done
-python3 $R/tools/ab_env.py FMH_PACKED_NO_PREFETCH=1 5000000x1250 4000000x500 2>/dev/null | grep '^{' >> $O/ab_prefetch_four_lane_rows.jsonl
-step "other configs"; python3 $R/tools/measure_configs.py C2 C2x10 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs.jsonl
+python3 $R/tools/ab_env.py FMH_PIPE=0 10000000x500 5000000x1250 2>/dev/null | grep '^{' >> $O/ab_pipelined_tile_loop.jsonl
+for k in wc4 sum4; do AB_KIND=$k python3 $R/tools/ab_env.py FMH_PIPE=1 5000000x1250 2>/dev/null | grep '^{' >> $O/ab_pipelined_tile_loop.jsonl; done
+step "other configs (every kernel warmed for 50 ms before it is timed)"; python3 $R/tools/measure_configs.py C2 C2x10 C3 C3h C4 C4m C5 WIDE C4f C2f 2>/dev/null | grep '^{' > $O/other_configs.jsonl
+step "kernel trace of C2, C3, C3 summaries, C2x10 and the fused region sweep"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg_trace -o c -- python3 $R/tools/measure_configs.py C2 C3 C3h C2x10 C4f > $O/cfg_trace_lines.jsonl 2> $O/cfg_trace.log
+python3 $R/tools/summarize_rocprof.py trace $O/cfg_trace $O/c2_c3_kernel_stats.csv
+step "FETCH_SIZE / WRITE_SIZE of the C3 W&C kernel and the fused region sweep"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c3_fetch -o f -- python3 $R/tools/measure_configs.py C3 C4f > /dev/null 2> $O/c3_fetch.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c3_fetch $O/c3_c4f_pmc_fetch_summary.csv
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c3_write -o w -- python3 $R/tools/measure_configs.py C3 C4f > /dev/null 2> $O/c3_write.log
+python3 $R/tools/summarize_rocprof.py pmc $O/c3_write $O/c3_c4f_pmc_write_summary.csv
 MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4m C5 WIDE 2>/dev/null | grep '^{' > $O/other_configs_u8_layout.jsonl
 step "C5 counting routes on u8 rows: v_dot4 / int8 MFMA (4 and 2 K steps in flight)"
 for v in 0 1 2; do FMH_COUNTS_MFMA=$v MEASURE_LAYOUT=bytes python3 $R/tools/measure_configs.py C5 2>/dev/null | grep '^{' | sed "s/^{/{\"FMH_COUNTS_MFMA\": $v, /" >> $O/c5_counting_routes_u8.jsonl; done
@@ -83,9 +85,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CY
 python3 $R/tools/summarize_rocprof.py pmc $O/c5_pmc_dot4 $O/c5_dot4_pmc_summary.csv
 unset MEASURE_LAYOUT
 step "issue / wait counters of the C2, C3, C3-summaries and C4 kernels (two passes of 8 SQ counters)"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/cfg_pmc1 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 > /dev/null 2> $O/cfg_pmc1.log
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/cfg_pmc1 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4f > /dev/null 2> $O/cfg_pmc1.log
 python3 $R/tools/summarize_rocprof.py pmc $O/cfg_pmc1 $O/c2_c3_c4_pmc_issue_wait_summary.csv
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT --output-format csv -d $O/cfg_pmc2 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 > /dev/null 2> $O/cfg_pmc2.log
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT --output-format csv -d $O/cfg_pmc2 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4f > /dev/null 2> $O/cfg_pmc2.log
 python3 $R/tools/summarize_rocprof.py pmc $O/cfg_pmc2 $O/c2_c3_c4_pmc_inst_mix_summary.csv
 step "multi-allelic paths"; python3 $R/tools/measure_general.py 2>/dev/null | grep '^{' | grep hudson > $O/general_path.jsonl
 MEASURE_ALLELE7=1 python3 $R/tools/measure_wc_general.py 2>/dev/null | grep '^{' > $O/wc_general_5_8_groups.jsonl
@@ -94,8 +96,12 @@ step "pairwise"; python3 $R/tools/measure_pairwise.py 1000000x2500 200000x500 2>
 step "upload, API, run_vcf"
 python3 $R/tools/measure_h2d.py 2>/dev/null | grep '^{' > $O/h2d.json
 python3 $R/tools/measure_api_c2.py 2>/dev/null | grep '^{' > $O/api_c2.json
+python3 $R/tools/measure_api_pybench.py 2>/dev/null | grep '^{' > $O/api_pybench.jsonl
 python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 2>/dev/null | tail -1 > $O/run_vcf_scale_200k_x_2500.json
 python3 $R/tools/run_vcf_many_regions.py 2>/dev/null | tail -1 > $O/run_vcf_500_regions.json
 for c in gzip bgzf; do python3 $R/tools/run_vcf_scale.py --sites 50000 --samples 2500 --compress $c 2>/dev/null | tail -1 >> $O/run_vcf_compressed_inputs.jsonl; done
-rm -rf $O/c4_trace $O/c4_pmc_fetch $O/c4_pmc_write $O/c4_pmc_fetch8 $O/c4_pmc_write8 $O/c5_trace $O/c5_pmc $O/c5_pmc_fetch $O/c5_pmc_dot4 $O/cfg_pmc1 $O/cfg_pmc2
+step "bytes the sweeps of one run_vcf region read: round 2's binary (four sweeps per variant set) against round 3's (one fused sweep)"
+[ -x $R/build/variants/r02/run_vcf ] && python3 $R/tools/run_vcf_fetch.py r02=$R/build/variants/r02/run_vcf r03=$R/ferromic_amd/bin/run_vcf 2>/dev/null | grep '^{' > $O/run_vcf_region_fetch_size.jsonl
+python3 $R/tools/kernel_resources.py > $O/kernel_resources.txt || true
+rm -rf $O/cfg_trace $O/c3_fetch $O/c3_write $O/c4_trace $O/c4_pmc_fetch $O/c4_pmc_write $O/c4_pmc_fetch8 $O/c4_pmc_write8 $O/c5_trace $O/c5_pmc $O/c5_pmc_fetch $O/c5_pmc_dot4 $O/cfg_pmc1 $O/cfg_pmc2
 ls -la $O
