@@ -257,6 +257,10 @@ def parse_args():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded path (communicator, device-side reduce, pipelining) even with one rank: measures its "
                          "software cost on a one-GPU box")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="sharded / pipelined steps the host keeps enqueued before it collects the oldest (at most FMH_SHARDED_IN_FLIGHT - 1 = 3): 1 = the "
+                         "reduce of step k overlaps the sweep of step k + 1 only; 2 (default) also covers a reduce that has to wait for compute units "
+                         "held by the next sweep's persistent grid, or that takes longer than one 0.17 ms sweep")
     ap.add_argument("--graph", action="store_true",
                     help="N = 1: run the pipelined steps on an explicit stream with FMH_GRAPH=1 - a repeated step is replayed from a captured hipGraph "
                          "(sweep + finalize + D2H as one launch); measures the fixed cost per step against the eager path")
@@ -405,7 +409,7 @@ def main() -> int:
                 # enqueue this step's sweep + device-side reduce, then collect the previous step's region-wide totals
                 _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), stream_ptr))
                 state["in_flight"] += 1
-                if state["in_flight"] > 1:
+                if state["in_flight"] > args.pipeline_depth:
                     _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(state["totals"])))
                     state["in_flight"] -= 1
             elif pipeline is not None:
@@ -547,8 +551,8 @@ def main() -> int:
             "haplotypes": H,
             "populations": 2,
             "parallelism": (f"region-sharded x{world}: one contiguous slab per GPU, per-site tracks stay on the owning GPU, the 128 regional "
-                            f"accumulators summed by {reduce_name}, pipelined one step deep") if sharded else
-                           ("one GPU, no collective; sweeps pipelined two deep (fmh_hudson_sweep_sharded_begin / _end on a local one-rank communicator)"
+                            f"accumulators summed by {reduce_name}, the host {args.pipeline_depth} steps ahead of the oldest uncollected reduce") if sharded else
+                           (f"one GPU, no collective; sweeps pipelined {args.pipeline_depth + 1} deep (fmh_hudson_sweep_sharded_begin / _end on a local one-rank communicator)"
                             + (", each step replayed from a captured hipGraph (FMH_GRAPH=1)" if args.graph else "") + (", explicit stream" if user_stream is not None else "")
                             if comm is not None else "one GPU, no collective, one blocking fmh_hudson_sweep per step"),
             "seed": first["seed"],

@@ -370,9 +370,10 @@ int fmh_allreduce_totals_end(fmh_comm* c, double* h_f64, uint64_t* h_u64);
  * the OLDEST outstanding one and returns its region-wide totals (pop[].haplotype_capacity is the local mask popcount,
  * identical on every rank).  A loop `begin(k); if (k) end(k-1)` overlaps the reduce of one window with the sweep of the
  * next, which is what keeps small slabs (1.25 M sites x 5 000 haplotypes is 0.16 ms of kernel) from paying the
- * collective's latency.  fmh_hudson_sweep_sharded = _begin + _end.
+ * collective's latency; keeping two or three sweeps ahead (`begin(k); if (k >= 2) end(k-2)`) also covers a reduce that can only
+ * start once a persistent sweep grid frees compute units, or that takes longer than one sweep.  fmh_hudson_sweep_sharded = _begin + _end.
  */
-#define FMH_SHARDED_IN_FLIGHT 2
+#define FMH_SHARDED_IN_FLIGHT 4
 int fmh_hudson_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
                                    int formula, const fmh_hudson_sites* sites_or_null, void* stream);
 int fmh_hudson_sweep_sharded_end(fmh_comm* c, fmh_hudson_totals* h_global_totals);

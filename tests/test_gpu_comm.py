@@ -59,14 +59,19 @@ def test_rccl_one_rank_allreduce_and_sharded_sweep():
     got = _abi.HudsonTotals()
     _abi.check(lib.fmh_hudson_sweep_sharded(comm._h, dm._h, g._h, 0, S, _abi.FORMULA_DENSE, None, C.byref(got), None))
     _totals_equal(got, plain, 0.0)  # same kernel, same grid, one rank: the very same bits
-    # pipelined: two windows in flight, collected in order; a third begin without an end is refused
+    # pipelined: windows in flight up to FMH_SHARDED_IN_FLIGHT (4), collected in order; one more begin without an end is refused
     half = S // 2
     _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, g._h, 0, half, _abi.FORMULA_DENSE, None, None))
     _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, g._h, half, S - half, _abi.FORMULA_DENSE, None, None))
+    _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, g._h, 0, 100, _abi.FORMULA_DENSE, None, None))
+    _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, g._h, 100, 0, _abi.FORMULA_DENSE, None, None))
     assert lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, g._h, 0, S, _abi.FORMULA_DENSE, None, None) == _abi.FMH_ERR_INVALID
-    a, b = _abi.HudsonTotals(), _abi.HudsonTotals()
+    a, b, c3, c4 = _abi.HudsonTotals(), _abi.HudsonTotals(), _abi.HudsonTotals(), _abi.HudsonTotals()
     _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(a)))
     _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(b)))
+    _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(c3)))
+    _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(c4)))
+    assert c3.sites_with_components <= 100 and c4.sites_with_components == 0 and c4.numerator_sum == 0.0
     assert lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(b)) == _abi.FMH_ERR_INVALID
     assert a.sites_with_components + b.sites_with_components == plain.sites_with_components
     assert a.pop[0].segregating_sites + b.pop[0].segregating_sites == plain.pop[0].segregating_sites
@@ -186,7 +191,7 @@ def test_rccl_collective_path_with_one_rank():
     lib = _abi.load()
     comm = sharding.Comm.single(0)
     d = comm.describe()
-    assert d["transport"] == "rccl" and d["world"] == 1 and d["rank"] == 0 and d["device"] == 0 and d["in_flight"] == 2
+    assert d["transport"] == "rccl" and d["world"] == 1 and d["rank"] == 0 and d["device"] == 0 and d["in_flight"] == 4
     assert "rccl" in str(d["rccl_library"]).lower() and str(d["rccl_version"]).isdigit(), d
     S, N = 40_001, 130
     for (G, max_allele, missing) in ((4, 1, 0.0), (3, 1, 0.02), (2, 3, 0.01), (6, 1, 0.0)):
