@@ -628,6 +628,9 @@ def main() -> int:
         barrier()
         dist.destroy_process_group()
     # the line is out; a run whose RCCL communicator could not be created (summed through torch.distributed instead) is not a clean run
+    if transport_note and sharding.Comm.init_stuck:
+        sys.stdout.flush()
+        os._exit(3)  # a helper thread is still blocked inside ncclCommInitRank: no orderly teardown is possible
     return 3 if transport_note else 0
 
 

@@ -58,12 +58,35 @@ class Comm:
         _abi.check(_abi.load().fmh_comm_init_local(device, C.byref(h)))
         return cls(h.value)
 
+    init_stuck = False  # a communicator creation that outlived its timeout is still blocked in a helper thread: leave through os._exit
+
     @classmethod
-    def from_torch_distributed(cls, dist, device: int) -> "Comm":
+    def from_torch_distributed(cls, dist, device: int, timeout_s: float = 300.0) -> "Comm":
+        """Rank 0 makes the RCCL id, the process group ships it, every rank joins.  ncclCommInitRank blocks until ALL ranks have joined: if
+        one of them failed before it got there the others would wait for ever, so the join runs in a helper thread and is given up after
+        `timeout_s` (the caller then falls back to another transport and says so)."""
+        import threading
+
         rank, world = dist.get_rank(), dist.get_world_size()
         box = [cls.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        return cls.from_unique_id(box[0], world, rank, device)
+        out = {}
+
+        def join():
+            try:
+                out["comm"] = cls.from_unique_id(box[0], world, rank, device)
+            except BaseException as exc:  # noqa: BLE001 - re-raised on the caller's thread
+                out["error"] = exc
+
+        t = threading.Thread(target=join, daemon=True)
+        t.start()
+        t.join(timeout_s)
+        if t.is_alive():
+            Comm.init_stuck = True
+            raise TimeoutError(f"ncclCommInitRank(rank {rank} of {world}) did not return within {timeout_s:.0f} s: a peer never joined")
+        if "error" in out:
+            raise out["error"]
+        return out["comm"]
 
     @classmethod
     def init_all(cls, devices: Sequence[int]) -> List["Comm"]:
