@@ -646,8 +646,7 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
   n_all = 0;
   allele_or = 0;
   const uint32_t last = mv.nvec - 1;
-  for (uint32_t v0 = gl; v0 < nvec_pad; v0 += LPR * U) {
-    uint4 x[NPL][U], cb[U];
+  auto load_trip = [&](uint32_t v0, uint4 (&x)[NPL][U], uint4 (&cb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t v = v0 + LPR * u;
@@ -657,6 +656,8 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
       if constexpr (NPL >= 3) x[2][u] = load_stream(row2 + (size_t)vc * 16);
       if (MISSING) cb[u] = load_stream(called_ptr + (size_t)vc * 16);
     }
+  };
+  auto count_trip = [&](uint32_t v0, const uint4 (&x)[NPL][U], const uint4 (&cb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t v = v0 + LPR * u;
@@ -691,6 +692,29 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
         for (int k = 0; k < NS; ++k) s[p][k] = popc128(and128(sub[k], m), s[p][k]);
       }
     }
+  };
+  // Rows of many trips (200 000 columns: 25 trips of four vectors per lane) are bound by the latency of one batch of loads per trip.  With the
+  // popcounts written in C hipcc unrolled this loop by two by itself (eight loads in flight per lane); the inline-asm popcount chain stopped
+  // that (WIDE: 0.44 -> 0.63 ms) and `#pragma unroll 2` is refused for a loop with inline asm, so the biallelic no-missing cores pair the trips by
+  // hand.  (The others keep one trip in flight: up to four planes x U x 4 registers per trip.)
+  // nvec_pad is a multiple of LPR x U and every lane starts at its own gl < LPR: the trip count is the same for all lanes
+  const uint32_t trips = nvec_pad / (LPR * U);
+  uint32_t t = 0;
+  if constexpr (NPL == 1 && !MISSING) {
+    for (; t + 2 <= trips; t += 2) {  // two trips' loads in flight before the first popcount
+      uint4 xa[NPL][U], xb[NPL][U], ca[U], cc[U];
+      const uint32_t va = (uint32_t)gl + t * (LPR * U), vb = va + LPR * U;
+      load_trip(va, xa, ca);
+      load_trip(vb, xb, cc);
+      count_trip(va, xa, ca);
+      count_trip(vb, xb, cc);
+    }
+  }
+  for (; t < trips; ++t) {
+    uint4 x[NPL][U], cb[U];
+    const uint32_t v0 = (uint32_t)gl + t * (LPR * U);
+    load_trip(v0, x, cb);
+    count_trip(v0, x, cb);
   }
 #pragma unroll
   for (int p = 0; p < P; ++p) {

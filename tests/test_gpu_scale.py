@@ -317,3 +317,29 @@ def test_c4_full_size(dev):
     for p in range(2):
         assert got.pop[p]["segregating_sites"] == seg[p] and got.pop[p]["uncallable_sites"] == unc[p]
         assert H.rel_close(got.pop[p]["pi_sum"], pis[p])
+    # the fused region sweep (summaries + both groups' per-site diversity + the Hudson pair, ONE read) over the same 10 M sites: its Hudson
+    # tracks and counts must be the bits just checked against the oracle, its diversity tracks the bits of fmh_diversity_sites per group
+    import ctypes as C
+
+    from ferromic_amd import _abi
+
+    lib = _abi.load()
+    g2 = dev.Groups(dm, masks)
+    bufs = {k: dev.DeviceBuffer(dm.device, 8 * S) for k in ("fst", "dxy", "pi1", "pi2", "num", "den")}
+    bufs.update({k: dev.DeviceBuffer(dm.device, 8 * S) for k in ("alt", "called")})
+    bufs.update({k: dev.DeviceBuffer(dm.device, 16 * S) for k in ("site_pi", "site_theta")})
+    sites = _abi.HudsonSites(*(bufs[k].ptr for k in ("fst", "dxy", "pi1", "pi2", "num", "den", "alt", "called")))
+    div = _abi.PairDiversitySites(bufs["site_pi"].ptr, bufs["site_theta"].ptr)
+    tot = _abi.HudsonTotals()
+    _abi.check(lib.fmh_pair_region_sweep(dm._h, g2._h, 0, S, dev.FORMULA_DENSE, dev.FORMULA_DENSE, C.byref(div), C.byref(sites), C.byref(tot), None))
+    for name in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+        H.assert_bits_equal(bufs[name].to_numpy(np.float64, S), got.sites[name], f"fused {name}")
+    assert np.array_equal(bufs["alt"].to_numpy(np.uint32, 2 * S).reshape(2, S), got.sites["alt"])
+    assert tot.sites_with_components == got.totals["sites_with_components"] and tot.pop[0].segregating_sites == seg[0] and tot.pop[1].segregating_sites == seg[1]
+    assert H.rel_close(tot.numerator_sum, got.totals["numerator_sum"]) and H.rel_close(tot.pop[1].pi_sum, pis[1])
+    fused_pi = bufs["site_pi"].to_numpy(np.float64, 2 * S).reshape(2, S)
+    fused_theta = bufs["site_theta"].to_numpy(np.float64, 2 * S).reshape(2, S)
+    for p in range(2):
+        dv = dev.diversity_sites(dm, dev.Groups(dm, masks[p:p + 1]))
+        H.assert_bits_equal(fused_pi[p], dv.pi, f"fused site pi group {p}")
+        H.assert_bits_equal(fused_theta[p], dv.theta, f"fused site theta group {p}")
