@@ -8,6 +8,9 @@
 // data is computed by the HIP kernels behind the C-ABI (include/ferromic_hip.h); there is no CPU fallback —
 // without a GPU the calls raise.  The GIL is released around every device call (lib.rs `py.allow_threads`).
 #include <pybind11/numpy.h>
+#include <emmintrin.h>
+#include <sys/mman.h>
+
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -383,13 +386,39 @@ struct Store {
 
 // DenseGenotypeMatrix built by from_numpy (lib.rs:1208-1224): per-allele missing flags
 // byte array without vector's zero fill (a 1 GB matrix is written exactly once, by several threads)
+// The narrowed copy of a from_numpy array (contents unspecified after resize).  Buffers of 2 MiB and more are anonymous mappings advised to
+// transparent huge pages: first-touching a fresh 33 MB heap block in 4-KiB pages was most of from_numpy's time (8 192 page faults contending
+// on the address-space lock under the copy threads; 65 536 x 256 diploid samples: 23 ms for a plain memcpy's worth of work).
 struct ByteBuf {
-  std::unique_ptr<uint8_t[]> p;
-  size_t n = 0;
-  void resize(size_t k) { p.reset(k ? new uint8_t[k] : nullptr); n = k; }  // contents unspecified
-  uint8_t* data() { return p.get(); }
-  const uint8_t* data() const { return p.get(); }
+  uint8_t* p = nullptr;
+  size_t n = 0, mapped = 0;
+  ByteBuf() = default;
+  ByteBuf(const ByteBuf&) = delete;
+  ByteBuf& operator=(const ByteBuf&) = delete;
+  ~ByteBuf() { release(); }
+  void release() {
+    if (mapped) munmap(p, mapped); else delete[] p;
+    p = nullptr; n = 0; mapped = 0;
+  }
+  void resize(size_t k) {
+    release();
+    if (k >= ((size_t)2 << 20)) {
+      const size_t len = (k + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+      void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m != MAP_FAILED) {
+        (void)madvise(m, len, MADV_HUGEPAGE);
+        p = static_cast<uint8_t*>(m); mapped = len; n = k;
+        return;
+      }
+    }
+    p = k ? new uint8_t[k] : nullptr;
+    n = k;
+  }
+  uint8_t* data() { return p; }
+  const uint8_t* data() const { return p; }
   size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  void assign(size_t k, uint8_t v) { resize(k); if (k) memset(p, v, k); }
   uint8_t& operator[](size_t i) { return p[i]; }
   const uint8_t& operator[](size_t i) const { return p[i]; }
 };
@@ -413,7 +442,7 @@ void parallel_ranges(size_t total, F fn) {
 struct Dense {
   int64_t variants = 0, samples = 0, ploidy = 0;
   ByteBuf g;             // [S][N][P], negatives stored as 0
-  vector<uint8_t> neg;   // empty = nothing missing, else one flag per entry
+  ByteBuf neg;           // empty = nothing missing, else one flag per entry
   int max_allele = 0;
   shared_ptr<DevMatrix> device;
   shared_ptr<DevMatrix> device_matrix() {
@@ -562,7 +591,7 @@ vector<int64_t> extract_positions(const py::handle& obj, int64_t expected_len) {
 
 // build_variants_from_numpy + convert_numeric_array, lib.rs:1082-1227
 template <class T>
-void convert_block(const py::array& arr, ByteBuf& g, vector<uint8_t>& neg, bool* any_neg, int* max_allele) {
+void convert_block(const py::array& arr, ByteBuf& g, ByteBuf& neg, bool* any_neg, int* max_allele) {
   auto a = py::array_t<T, py::array::c_style | py::array::forcecast>(arr);
   const T* src = a.data();
   const size_t total = (size_t)a.size();
@@ -578,8 +607,52 @@ void convert_block(const py::array& arr, ByteBuf& g, vector<uint8_t>& neg, bool*
     if constexpr (std::is_same<T, uint8_t>::value) {
       memcpy(dst + b, src + b, e - b);
       for (size_t i = b; i < e; ++i) mx = src[i] > mx ? src[i] : mx;
+    } else if constexpr (std::is_same<T, int8_t>::value) {
+      // sixteen entries per step: a negative entry (sign bit) is missing and stored as 0, the rest is copied; byte maximum over the kept values
+      size_t i = b;
+      __m128i vmax = _mm_setzero_si128(), vneg = _mm_setzero_si128();
+      const __m128i zero = _mm_setzero_si128();
+      for (; i + 16 <= e; i += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+        const __m128i isneg = _mm_cmplt_epi8(v, zero);
+        const __m128i kept = _mm_andnot_si128(isneg, v);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), kept);
+        vmax = _mm_max_epu8(vmax, kept);
+        vneg = _mm_or_si128(vneg, isneg);
+      }
+      alignas(16) uint8_t lanes[16];
+      _mm_store_si128(reinterpret_cast<__m128i*>(lanes), vmax);
+      for (int k = 0; k < 16; ++k) mx = lanes[k] > mx ? lanes[k] : mx;
+      negs = _mm_movemask_epi8(vneg) != 0;
+      for (; i < e; ++i) {
+        const int8_t v = src[i];
+        if (v < 0) { negs = true; dst[i] = 0; } else { dst[i] = (uint8_t)v; mx = dst[i] > mx ? dst[i] : mx; }
+      }
     } else {
-      for (size_t i = b; i < e; ++i) {
+      size_t i = b;
+      if constexpr (sizeof(T) == 2) {
+        // sixteen 16-bit entries per step: beyond u8 -> error; negative (int16) -> missing, stored as 0; the rest narrowed (saturating pack)
+        __m128i vmax = _mm_setzero_si128(), vneg = _mm_setzero_si128(), vbig = _mm_setzero_si128();
+        const __m128i zero = _mm_setzero_si128(), hi = _mm_set1_epi16((short)0xFF00);
+        for (; i + 16 <= e; i += 16) {
+          const __m128i a0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i)), a1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 8));
+          __m128i n0 = zero, n1 = zero;
+          if constexpr (std::is_signed<T>::value) { n0 = _mm_cmplt_epi16(a0, zero); n1 = _mm_cmplt_epi16(a1, zero); }
+          // a high byte on a non-negative entry: the value exceeds 255
+          vbig = _mm_or_si128(vbig, _mm_or_si128(_mm_andnot_si128(n0, _mm_and_si128(a0, hi)), _mm_andnot_si128(n1, _mm_and_si128(a1, hi))));
+          const __m128i k0 = _mm_andnot_si128(n0, a0), k1 = _mm_andnot_si128(n1, a1);
+          const __m128i kept = _mm_packus_epi16(_mm_and_si128(k0, _mm_set1_epi16(0x00FF)), _mm_and_si128(k1, _mm_set1_epi16(0x00FF)));
+          _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), kept);
+          vmax = _mm_max_epu8(vmax, kept);
+          vneg = _mm_or_si128(vneg, _mm_or_si128(n0, n1));
+        }
+        alignas(16) uint8_t lanes[16];
+        _mm_store_si128(reinterpret_cast<__m128i*>(lanes), vmax);
+        for (int k = 0; k < 16; ++k) mx = lanes[k] > mx ? lanes[k] : mx;
+        negs = _mm_movemask_epi8(vneg) != 0;
+        big = _mm_movemask_epi8(_mm_cmpeq_epi8(vbig, zero)) != 0xFFFF;
+      }
+      for (; i < e; ++i) {
         const T v = src[i];
         if constexpr (sizeof(T) > 1) {
           if ((std::is_signed<T>::value ? (int64_t)v : (int64_t)(uint64_t)v) > 255) { big = true; dst[i] = 0; continue; }
@@ -598,10 +671,16 @@ void convert_block(const py::array& arr, ByteBuf& g, vector<uint8_t>& neg, bool*
     mx = std::max<int>(mx, w_max[w]);
   }
   if (negs) {
-    neg.resize(total);
+    neg.resize(total);  // every byte is written below
     uint8_t* flags = neg.data();
     parallel_ranges(total, [&](size_t b, size_t e, size_t) {
-      for (size_t i = b; i < e; ++i) flags[i] = std::is_signed<T>::value && src[i] < 0 ? 1 : 0;
+      size_t i = b;
+      if constexpr (std::is_same<T, int8_t>::value) {
+        const __m128i zero = _mm_setzero_si128(), one = _mm_set1_epi8(1);
+        for (; i + 16 <= e; i += 16)
+          _mm_storeu_si128(reinterpret_cast<__m128i*>(flags + i), _mm_and_si128(_mm_cmplt_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i)), zero), one));
+      }
+      for (; i < e; ++i) flags[i] = std::is_signed<T>::value && src[i] < 0 ? 1 : 0;
     });
   }
   *any_neg = negs;
