@@ -23,26 +23,31 @@ using namespace fmhi;
 
 namespace {
 
-constexpr size_t kStageBytes = (size_t)24 << 20;  // per pinned slab (two per device, kept between calls)
+constexpr size_t kStageBytes = (size_t)24 << 20;  // largest pinned slab (two per device, kept between calls and grown on demand: pinning the full
+                                                   // 48 MB took 6 ms, which a process that only ever uploads a 1 MB cohort paid on its first statistic)
 
 struct Staging {
   std::mutex mu;  // one upload at a time per device
   uint8_t* pinned[2] = {nullptr, nullptr};
   hipStream_t stream[2] = {nullptr, nullptr};
   hipEvent_t done[2] = {nullptr, nullptr};
+  size_t cap = 0;  // bytes per slab
   bool ready = false;
 };
 Staging g_staging[64];
 
 // Called with s.mu held (the uploader's lock, which upload_release takes too): `ready` is only ever read or written under it, so a
 // release cannot free the slabs between the check and their use.  A partial failure frees what was created.
-int ensure_staging(Staging& s) {
-  if (s.ready) return FMH_OK;
+int ensure_staging(Staging& s, size_t want) {
+  want = std::min(kStageBytes, std::max<size_t>(want, (size_t)1 << 20));
+  if (s.ready && s.cap >= want) return FMH_OK;
+  if (s.ready) want = std::min(kStageBytes, std::max(want, 2 * s.cap));  // grow geometrically
   hipError_t e = hipSuccess;
   for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-    e = hipHostMalloc((void**)&s.pinned[k], kStageBytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream[k], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming);
+    if (s.pinned[k]) { (void)hipHostFree(s.pinned[k]); s.pinned[k] = nullptr; }  // idle: the previous upload waited for its copies under this lock
+    e = hipHostMalloc((void**)&s.pinned[k], want, hipHostMallocDefault);
+    if (e == hipSuccess && !s.stream[k]) e = hipStreamCreateWithFlags(&s.stream[k], hipStreamNonBlocking);
+    if (e == hipSuccess && !s.done[k]) e = hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming);
   }
   if (e != hipSuccess) {
     for (int k = 0; k < 2; ++k) {
@@ -52,9 +57,12 @@ int ensure_staging(Staging& s) {
       s.pinned[k] = nullptr; s.stream[k] = nullptr; s.done[k] = nullptr;
     }
     (void)hipGetLastError();
+    s.ready = false;
+    s.cap = 0;
     return fail(e == hipErrorNoDevice ? FMH_ERR_NO_DEVICE : FMH_ERR_HIP, "pinned staging for uploads: %s", hipGetErrorString(e));
   }
   s.ready = true;
+  s.cap = want;
   return FMH_OK;
 }
 
@@ -75,11 +83,11 @@ int fmhi::upload_planes_from_bytes(fmh_matrix* m, const uint8_t* h_data, const u
   if (m->device < 0 || m->device >= 64) return fail(FMH_ERR_INVALID, "device index %d unsupported", m->device);
   Staging* st = &g_staging[m->device];
   std::lock_guard<std::mutex> lock(st->mu);
-  FMH_TRY(ensure_staging(*st));
   const int nplanes = m->p2 ? 3 : (m->p1 ? 2 : 1);
   const bool with_called = m->pc != nullptr;
   const size_t pitch = m->plane_pitch, per_row = (size_t)(nplanes + (with_called ? 1 : 0)) * pitch;
-  const size_t slab_rows = std::max<size_t>(1, std::min(m->variants, kStageBytes / per_row));
+  FMH_TRY(ensure_staging(*st, std::max(per_row, m->variants * per_row)));
+  const size_t slab_rows = std::max<size_t>(1, std::min(m->variants, st->cap / per_row));
   const size_t total_bits = m->variants * (size_t)m->columns;
   const unsigned T = host_threads(m->variants * (size_t)m->columns);
   uint8_t* d_planes[4] = {m->p0, m->p1, m->p2, m->pc};
@@ -144,4 +152,5 @@ void fmhi::upload_release(int device) {
     s.pinned[k] = nullptr; s.stream[k] = nullptr; s.done[k] = nullptr;
   }
   s.ready = false;
+  s.cap = 0;
 }
