@@ -1452,14 +1452,21 @@ void sharded_wc_many(const RegionMatrix& rm, const vector<uint8_t>& flat_masks, 
 }
 
 // Hudson pair sweep: the library's own sharded entry point (sweep, device-side finalise, RCCL reduce, one synchronisation)
+// (want_sites = false: the regional totals only - what the CSV-population pairs need, K (K - 1) / 2 sweeps per region: no per-site tracks are
+// written on the device and nothing but the totals comes back)
 fmh_hudson_totals sharded_hudson(const RegionMatrix& rm, const vector<uint8_t>& m0, const vector<uint8_t>& m1, int formula, vector<double>& fst,
-                                 vector<double>& num, vector<double>& den) {
+                                 vector<double>& num, vector<double>& den, bool want_sites = true) {
   const size_t S = rm.variants;
-  fst.assign(S, 0.0); num.assign(S, 0.0); den.assign(S, 0.0);
+  if (want_sites) { fst.assign(S, 0.0); num.assign(S, 0.0); den.assign(S, 0.0); }
   vector<fmh_hudson_totals> per(rm.slabs.size());
   on_slabs(rm, [&](const Slab& sl, size_t k) {
     const size_t rows = sl.dm->variants;
     Groups grp(*sl.dm, {m0, m1});
+    if (!want_sites) {
+      if (sl.comm) fmh_check(fmh_hudson_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, formula, nullptr, &per[k], nullptr), "sharded hudson sweep");
+      else fmh_check(fmh_hudson_sweep(sl.dm->h, grp.h, 0, rows, formula, nullptr, &per[k], nullptr), "hudson sweep");
+      return;
+    }
     DevBuf dfst(sl.device, 8 * std::max<size_t>(rows, 1)), dnum(sl.device, 8 * std::max<size_t>(rows, 1)), dden(sl.device, 8 * std::max<size_t>(rows, 1));
     fmh_hudson_sites sites{};
     sites.d_fst = (double*)dfst.p; sites.d_num = (double*)dnum.p; sites.d_den = (double*)dden.p;
@@ -1845,7 +1852,8 @@ struct HudsonRegion {
 
 // calculate_hudson_fst_for_pair_with_sites (stats.rs:3619) for haplotype groups 0 / 1 of the filtered set
 HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix& rm, const vector<string>& sample_names,
-                           const HapList& h0, const HapList& h1, int64_t L, const double pi_raw[2], int device, const PairSweep* pre = nullptr) {
+                           const HapList& h0, const HapList& h1, int64_t L, const double pi_raw[2], int device, const PairSweep* pre = nullptr,
+                           bool want_sites = true) {
   HudsonRegion out;
   if (L <= 0) return out;  // Err(InvalidRegion) -> logged, no outcome (process.rs:3261-3271)
   out.have_outcome = true;
@@ -1860,12 +1868,14 @@ HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix&
     if (pre && pre->hudson && pre->fst.size() == S) {  // the filtered process_variants sweep of the same two haplotype lists already read the matrix
       tot = pre->tot; fst = pre->fst; num = pre->num; den = pre->den;
     } else {
-      tot = sharded_hudson(rm, mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false), FMH_FORMULA_SPARSE, fst, num, den);
+      tot = sharded_hudson(rm, mask_of(h0, N, dm.ploidy, false), mask_of(h1, N, dm.ploidy, false), FMH_FORMULA_SPARSE, fst, num, den, want_sites);
     }
     num_sum = tot.site_num_sum; den_sum = tot.site_den_sum; dxy_sum = tot.site_dxy_sum; dxy_skipped = tot.site_dxy_skipped;
-    size_t informative = 0;
-    for (size_t i = 0; i < S; ++i) informative += (!std::isnan(den[i]) && std::isfinite(den[i]) && den[i] > 0.0);
-    if (informative > 0) for (size_t i = 0; i < S; ++i) out.sites.push_back({vs[i]->position + 1, fst[i], num[i], den[i]});
+    if (want_sites) {
+      size_t informative = 0;
+      for (size_t i = 0; i < S; ++i) informative += (!std::isnan(den[i]) && std::isfinite(den[i]) && den[i] > 0.0);
+      if (informative > 0) for (size_t i = 0; i < S; ++i) out.sites.push_back({vs[i]->position + 1, fst[i], num[i], den[i]});
+    }
   }
   if (den_sum > 1e-12) out.fst = num_sum / den_sum;
   // auxiliaries (stats.rs:3562-3565): calculate_pi_for_population x2 == the filtered process_variants pi of the same
@@ -2325,7 +2335,7 @@ std::optional<RegionOutput> process_single_config_entry(const ConfigEntry& entry
         const HapList &ha = pop_haps[names[i]], &hb = pop_haps[names[j]];
         if (ha.size() < 2 || hb.size() < 2 || !region_valid) continue;
         const double pis[2] = {pop_pi[names[i]], pop_pi[names[j]]};
-        HudsonRegion h = hudson_groups(fil, m_fil, vcf.sample_names, ha, hb, fil_adj, pis, args.device);
+        HudsonRegion h = hudson_groups(fil, m_fil, vcf.sample_names, ha, hb, fil_adj, pis, args.device, nullptr, /*want_sites=*/false);  // only the row is written for named pairs
         if (!h.have_outcome) continue;
         out.hudson_rows.push_back({entry.seqname, std::to_string(entry.interval.first), std::to_string(entry.interval.second - 1),
                                    "NamedPopulation", names[i], "NamedPopulation", names[j], fmt_opt(h.dxy), fmt_opt(h.pi0), fmt_opt(h.pi1),

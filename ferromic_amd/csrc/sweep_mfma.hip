@@ -27,7 +27,9 @@ int launch_mfma(const SweepArgs& args, size_t smem, hipStream_t st, const Launch
   }
   const size_t ntiles = (args.row_count + kTileRows - 1) / kTileRows;
   size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  const size_t cap = (size_t)ctx.cus * cached_occ[dev];
+  size_t cap = (size_t)ctx.cus * cached_occ[dev];
+  if (const long long v = options().grid_per_cu.load(); v > 0) cap = (size_t)ctx.cus * (size_t)v;  // the same grid options as the other routes
+  if (const long long v = options().grid_blocks.load(); v > 0) cap = (size_t)v;
   if (blocks > cap) blocks = cap;  // persistent grid (equalising the tile rounds per workgroup was measured: fewer resident waves, slower)
   if (blocks > (size_t)ctx.max_grid) blocks = ctx.max_grid;
   if (blocks < 1) blocks = 1;

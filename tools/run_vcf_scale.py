@@ -121,6 +121,9 @@ def main() -> int:
     ap.add_argument("--seed", type=int, default=202_500)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--compress", choices=["none", "gzip", "bgzf"], default="none", help="how the synthetic VCF is stored")
+    ap.add_argument("--populations", type=int, default=0, help="also pass --fst_populations with this many CSV-defined populations (equal contiguous blocks of samples): "
+                                                                 "one W&C sweep over all of them and one Hudson sweep per population PAIR")
+    ap.add_argument("--bin", default=BIN, help="the run_vcf binary to time")
     args = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="run_vcf_scale_")
     t0 = time.perf_counter()
@@ -128,8 +131,14 @@ def main() -> int:
     gen_s = time.perf_counter() - t0
 
     out_csv = os.path.join(tmp, "out", "results.csv")
-    cmd = [BIN, "--vcf_folder", os.path.join(tmp, "vcfs"), "--reference", os.path.join(tmp, "ref.fa"), "--gtf",
+    cmd = [args.bin, "--vcf_folder", os.path.join(tmp, "vcfs"), "--reference", os.path.join(tmp, "ref.fa"), "--gtf",
            os.path.join(tmp, "ann.gtf"), "--config_file", os.path.join(tmp, "config.tsv"), "--output_file", out_csv, "--fst"]
+    if args.populations:
+        names = [f"SYN{i:05d}" for i in range(args.samples)]
+        with open(os.path.join(tmp, "pops.csv"), "w") as fh:
+            for k in range(args.populations):
+                fh.write(f"pop{k:02d}," + ",".join(names[args.samples * k // args.populations:args.samples * (k + 1) // args.populations]) + "\n")
+        cmd += ["--fst_populations", os.path.join(tmp, "pops.csv")]
     t0 = time.perf_counter()
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_TIMING="1"))
     cli_s = time.perf_counter() - t0
@@ -170,6 +179,7 @@ def main() -> int:
     timing = [l for l in res.stderr.splitlines() if l.startswith("[TIMING]")]
     print(json.dumps({
         "sites": args.sites, "samples": args.samples, "haplotypes": 2 * args.samples, "vcf_bytes": vcf_bytes, "vcf_storage": args.compress,
+        "csv_populations": args.populations, "population_pairs": args.populations * (args.populations - 1) // 2, "binary": os.path.relpath(args.bin, ROOT),
         "generate_s": gen_s, "run_vcf_wall_s": cli_s, "vcf_MB_per_s": vcf_bytes / cli_s / 1e6,
         "sites_per_s_end_to_end": args.sites / cli_s, "api_from_numpy_s": api_s,
         "csv_matches_python_api": checks, "all_match": all(checks.values()), "run_vcf_timing": timing,
