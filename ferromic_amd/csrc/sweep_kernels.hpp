@@ -766,9 +766,6 @@ __device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, co
       dst[u] = load_stream(rp + (size_t)(v < last ? v : last) * 16);
     }
   };
-  // five to seven groups run the eight-group kernel: the padded groups' masks are zero, and counting against them is skipped (a wave-uniform
-  // branch per group and row step instead of U x 8 instructions)
-  const int live_groups = P == 8 ? A.n_groups : P;
   auto count_row = [&](const uint4 (&x)[U], int s) {
     // masks in LDS: keep their reads inside the row (hoisted out of the row loop they would be the P x U register image again)
     if constexpr (!MREG) asm volatile("" ::: "memory");
@@ -776,7 +773,6 @@ __device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, co
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       alt[p] = 0;
-      if (P == 8 && p >= live_groups) continue;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if constexpr (MREG) alt[p] = popc128(and128(x[u], m[p][u]), alt[p]);
