@@ -931,7 +931,9 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     // on short rows, a two-step reduction: C2 0.081 -> 0.042 ms, C3 0.94 -> 0.63 ms), wider ones by the sixteen lanes of a
     // DPP row (C4's 40 vectors: 1.32 vs 1.34 ms, 200 000 columns: 0.46 vs 0.66 ms); the batch depth U (vectors per lane in
     // flight per trip) is the one with the fewest padded slots, ties to the deeper batch.  (Eight lanes per row measured between
-    // the two everywhere - C4 1.37 ms - and is not built.)
+    // the two everywhere - C4 1.37 ms - and is not built.  Round 3 built it once more for the narrow rows, where eight lanes read whole
+    // 128-byte lines - 1 000 haplotypes: one contiguous KB per load instruction -: Hudson +4...+10 % at 1 000 haplotypes, +-1 % at 2 500; four-group
+    // W&C +3...+18 %, summaries -1...+8 % (profiles/r03/ab_eight_lanes_per_row.jsonl).  The 64-byte segments of the four-lane rows are not what holds them back.)
     const int env_punroll = (int)opt.packed_unroll.load();
     const int env_lpr = (int)opt.packed_lpr.load();
     lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
