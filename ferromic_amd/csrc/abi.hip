@@ -311,6 +311,8 @@ static size_t device_lds_per_cu(int device) {
   return v ? v : (size_t)160 * 1024;
 }
 static size_t sweep_lds_limit(int device) { return device_lds_limit(device); }
+// the eight-group W&C kernels keep their regional sums through a static LDS scratch (sweep_kernels.hpp, wc_xpose_scratch): that much less for masks
+static size_t wc_lds_limit(int device, int padded) { return sweep_lds_limit(device) - (padded == 8 ? fmh::kWcXposeLdsBytes + 1024 : 0); }
 static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 2; }
 
 static int check_dims(size_t variants, size_t samples, size_t ploidy) {
@@ -925,7 +927,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   size_t smem = (size_t)P * a.nvec_pad * 16;
   int mask_mode = kMaskLdsBytes;
   int lpr = 16;
-  const size_t lds_limit = sweep_lds_limit(m->device);
+  const size_t lds_limit = mode == kModeWc ? wc_lds_limit(m->device, P) : sweep_lds_limit(m->device);
   if (packed) {
     // 128 columns per vector.  Rows of up to 32 vectors (4 096 columns) are shared by FOUR lanes (no idle vector slots
     // on short rows, a two-step reduction: C2 0.081 -> 0.042 ms, C3 0.94 -> 0.63 ms), wider ones by the sixteen lanes of a
@@ -937,25 +939,32 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     const int env_punroll = (int)opt.packed_unroll.load();
     const int env_lpr = (int)opt.packed_lpr.load();
     lpr = env_lpr == 4 || env_lpr == 16 ? env_lpr : (m->pvec <= 32 ? 4 : 16);
-    // eight groups: only the shallow batches are built (deeper ones kept P x U mask vectors live and spilled)
-    const bool shallow = P == 8;
+    // eight groups: the row loop of many batches is built with the shallow batches only (deeper ones kept P x U mask vectors and subset sums live and
+    // spilled).  A biallelic row with nothing missing that ONE batch of loads per lane covers takes any depth: that loop (tile_rows_packed_prefetch,
+    // MREG = false) re-reads its masks from LDS per row, and a 2 500-haplotype row is then one batch of five loads per lane instead of five trips
+    // of one with a single vector in flight (five groups, which run the eight-group kernel: DESIGN.md section 3).
     const int us4[4] = {1, 2, 3, 5}, us16[3] = {2, 3, 4};
     const int* us = lpr != 16 ? us4 : us16;
-    const int nus = shallow ? (lpr != 16 ? 2 : 1) : (lpr != 16 ? 4 : 3);
-    int best_u = us[0];
-    size_t best = SIZE_MAX;
-    for (int k = 0; k < nus; ++k) {
-      const size_t slots = round_up(m->pvec, (size_t)lpr * us[k]);
-      if (slots <= best) { best = slots; best_u = us[k]; }
-    }
-    a.unroll = best_u;
-    for (int k = 0; k < nus; ++k) if (env_punroll == us[k]) a.unroll = env_punroll;
-    a.nvec_pad = (uint32_t)round_up(m->pvec, (size_t)lpr * a.unroll);
+    auto pick = [&](bool shallow) {
+      const int nus = shallow ? (lpr != 16 ? 2 : 1) : (lpr != 16 ? 4 : 3);
+      int best_u = us[0];
+      size_t best = SIZE_MAX;
+      for (int k = 0; k < nus; ++k) {
+        const size_t slots = round_up(m->pvec, (size_t)lpr * us[k]);
+        if (slots <= best) { best = slots; best_u = us[k]; }
+      }
+      a.unroll = best_u;
+      for (int k = 0; k < nus; ++k) if (env_punroll == us[k]) a.unroll = env_punroll;
+      a.nvec_pad = (uint32_t)round_up(m->pvec, (size_t)lpr * a.unroll);
+    };
+    const bool no_prefetch = opt.packed_no_prefetch.load() != 0;
+    pick(P == 8 && (general || missing || no_prefetch));
+    if (P == 8 && a.nvec_pad != (uint32_t)(lpr * a.unroll)) pick(true);  // not one batch per row: the shallow set
     // The prefetching row loop (tile_rows_packed_prefetch) is taken when one batch of loads covers a row.  Same-process A/Bs (tools/ab_env.py
     // FMH_PACKED_NO_PREFETCH=1): on four-lane rows (1 000 and 2 500 haplotypes) it is level or 1-6 % ahead at every launch size; on sixteen-lane
     // rows with two groups (5 000 haplotypes) it was 2.4-2.9 % ahead at 625 k sites, level at 1 M and 0.6-2.4 % behind from 1.25 M to 10 M sites -
     // those kernels (one and two groups, sixteen lanes) have since dropped it altogether for the deferred-epilogue loop (sweep_kernel, defer_kernel()).
-    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && opt.packed_no_prefetch.load() == 0;
+    a.single_trip = a.nvec_pad == (uint32_t)(lpr * a.unroll) && !no_prefetch;
     smem = (size_t)P * a.nvec_pad * 16;
     mask_mode = kMaskPacked;
     if (smem > lds_limit)
@@ -1267,12 +1276,12 @@ void fmhi::wc_slot_map(const fmh_groups* g, SweepArgs& a, int (&slot_of)[32]) {
       }
     }
 }
-// true when fmh_wc_sweep runs ONE fused kernel that keeps the regional sums per lane (2..4 groups, masks in LDS): the route the
-// pipelined sharded sweep can finalise and reduce on the device; everything else (5..8 groups, alleles beyond 3 with eight groups,
-// rows too wide for all masks) sums its per-site tracks or goes through the counts route
+// true when fmh_wc_sweep runs ONE fused kernel that keeps the regional sums itself (2..8 groups, masks in LDS; registers up to four groups,
+// the per-wave LDS transposition beyond): the route the pipelined sharded sweep can finalise and reduce on the device; everything else
+// (alleles beyond 3 with five to eight groups, rows too wide for all masks) goes through the counts route
 bool fmhi::wc_fused_lane_totals(const fmh_matrix* m, const fmh_groups* g) {
-  if (!m || !g || g->padded >= 8) return false;
-  return sweep_lds_bytes(g->padded, m->nvec) <= sweep_lds_limit(m->device);
+  if (!m || !g || (g->padded == 8 && m->max_allele > 3)) return false;
+  return sweep_lds_bytes(g->padded, m->nvec) <= wc_lds_limit(m->device, g->padded);
 }
 bool fmhi::summaries_single_sweep(const fmh_matrix* m, const fmh_groups* g) {
   return m && g && !(sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(m->device) && g->n_groups > 2);
@@ -1294,7 +1303,7 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   wc_slot_map(g, a, slot_of);
   // the fused kernel for 5..8 groups keeps the counts of alleles 0..3 per site; cohorts with alleles beyond 3 take the counts route
   const bool many_alleles8 = m && g && g->padded == 8 && m->max_allele > 3;
-  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > sweep_lds_limit(m->device))) {
+  if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > wc_lds_limit(m->device, g->padded))) {
     // (or: rows too wide for all groups' masks to sit in LDS at once) count in smaller batches, components from the count tables
     const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
     std::vector<double> sa(nslots), sb(nslots);
@@ -1306,33 +1315,6 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
       h_totals->sites_attempted = row_count;
       for (size_t k = 0; k < nslots; ++k) { h_totals->sum_a[k] = sa[k]; h_totals->sum_b[k] = sb[k]; h_totals->informative_sites[k] = si[k]; }
     }
-    return FMH_OK;
-  }
-  if (g && g->padded == 8 && m && row_count > 0) {
-    // 5..8 groups: the kernel keeps no per-lane regional accumulators (29 slots would be 174 registers); the regional
-    // sums come from the per-site tracks, which therefore must exist
-    DeviceScratch scratch;
-    scratch.device = m->device;
-    scratch.stream = (hipStream_t)stream;
-    const size_t nslots = 1 + (size_t)g->n_groups * (g->n_groups - 1) / 2;
-    if (!a.wc_a) FMH_TRY(scratch.get(&a.wc_a, nslots * row_count));
-    if (!a.wc_b) FMH_TRY(scratch.get(&a.wc_b, nslots * row_count));
-    if (!a.wc_state) FMH_TRY(scratch.get(&a.wc_state, nslots * row_count));
-    SweepResult r8;
-    FMH_TRY(run_sweep(m, g, kModeWc, a, stream, &r8));
-    double *sa = nullptr, *sb = nullptr;
-    unsigned long long* si = nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    FMH_TRY(wc_slot_sums(scratch, st, nslots, row_count, a.wc_a, a.wc_b, a.wc_state, &sa, &sb, &si));
-    if (h_totals) {
-      memset(h_totals, 0, sizeof *h_totals);
-      h_totals->sites_attempted = row_count;
-      HIP_TRY(hipMemcpyAsync(h_totals->sum_a, sa, nslots * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h_totals->sum_b, sb, nslots * 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h_totals->informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    scratch.settled = true;
     return FMH_OK;
   }
   SweepResult r;

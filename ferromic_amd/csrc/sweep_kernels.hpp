@@ -193,6 +193,24 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// per-wave LDS scratch of the eight-group W&C kernels' regional sums (LaneTotals::kWcLdsTotals, wc_xpose_put): sixteen rows of 64 lanes
+constexpr int kWcXRows = 16;
+constexpr int kWcXStride = 65;
+constexpr int kWcXAcc = 6 * kWcXRows;                     // running sums: 87 rows in six batches of sixteen
+constexpr int kWcXWave = kWcXRows * kWcXStride + kWcXAcc;  // doubles per wave
+constexpr size_t kWcXposeLdsBytes = (size_t)4 /* kWavesPerBlock */ * kWcXWave * 8;  // the host subtracts it from the masks' LDS budget
+__device__ __forceinline__ double* wc_xpose_scratch() {
+  __shared__ double scratch[4 * kWcXWave];
+  return scratch;
+}
+
 __device__ __forceinline__ double f64_nan() { return __longlong_as_double(0x7FF8000000000000LL); }
 
 // ------------------------------------------------------------------------------------------------
@@ -749,6 +767,7 @@ __device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, co
                                                           uint32_t nvec_pad, size_t tile_row0, int grp, int gl, uint32_t (&alt_mine)[P]) {
   constexpr bool MREG = P * U <= 12;
   const uint32_t last = mv.nvec - 1;
+  const int live_groups = P == 8 ? A.n_groups : P;
   uint4 m[MREG ? P : 1][MREG ? U : 1];
   if constexpr (MREG) {
 #pragma unroll
@@ -773,6 +792,7 @@ __device__ __forceinline__ void tile_rows_packed_prefetch(const SweepArgs& A, co
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       alt[p] = 0;
+      if (P == 8 && p >= live_groups) continue;  // five to seven groups run the eight-group kernel: nothing to count for the padding (its masks are zero)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if constexpr (MREG) alt[p] = popc128(and128(x[u], m[p][u]), alt[p]);
@@ -910,10 +930,16 @@ struct LaneTotals {
   unsigned long long pop_unc[P];
   double hud[kHudF64];
   unsigned long long hud_u[kHudU64];
-  // W&C regional sums per slot; for P = 8 (29 slots = 174 registers of accumulators) they are NOT kept per lane: the
-  // host sums the per-site tracks with wc_slot_reduce_kernel instead (kWcLaneTotals)
+  // W&C regional sums per slot.  Up to four groups: three registers pairs per slot and lane (kWcLaneTotals).  Eight groups (29 slots = 174
+  // registers of accumulators) cannot: there the 87 values of a site (a, b, informative as 0.0 / 1.0 per slot) go through a per-wave LDS
+  // transposition sixteen rows at a time - every lane writes its value of a row, lane (r, q) adds up a quarter of row r, the quad adds the
+  // quarters - and one double per row behind the wave's scratch accumulates over the tiles (kWcLdsTotals, wc_xpose_put).  (Until round 3 the
+  // host summed the per-site tracks in a second pass, wc_slot_reduce_kernel: half as long again as the sweep, and it needed the tracks.)
   static constexpr bool kWcLaneTotals = (MODE & kModeWc) != 0 && P < 8;
+  static constexpr bool kWcLdsTotals = (MODE & kModeWc) != 0 && P == 8;
   static constexpr int kWcRegSlots = kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1;
+  static constexpr int kWcXposeRows = 3 * (1 + (P * (P - 1)) / 2);
+  static constexpr int kWcBatches = kWcLdsTotals ? (kWcXposeRows + kWcXRows - 1) / kWcXRows : 1;
   double wc_a[kWcRegSlots];
   double wc_b[kWcRegSlots];
   unsigned long long wc_inf[kWcRegSlots];
@@ -927,8 +953,45 @@ struct LaneTotals {
     for (int i = 0; i < kHudU64; ++i) hud_u[i] = 0;
 #pragma unroll
     for (int i = 0; i < kWcRegSlots; ++i) { wc_a[i] = 0.0; wc_b[i] = 0.0; wc_inf[i] = 0; }
+    if constexpr (kWcLdsTotals) {  // the wave's running sums in LDS (only this wave touches them)
+      static_assert(kWcBatches * kWcXRows <= kWcXAcc, "running sums of the transposition");
+      double* acc = wc_xpose_scratch() + (threadIdx.x >> 6) * kWcXWave + kWcXRows * kWcXStride;
+      for (int i = threadIdx.x & 63; i < kWcXAcc; i += 64) acc[i] = 0.0;
+    }
   }
 };
+
+// One value per lane of transposition row `row` (a compile-time constant once the slot loops are unrolled; rows 3k, 3k + 1, 3k + 2 = a, b,
+// informative of kernel slot k).  EVERY lane of the wave calls this for every row, in row order.  After the last row of a batch of sixteen
+// (or the very last row) the batch is summed: lane (r, q) = (lane / 4, lane % 4) adds entries 16 q ... 16 q + 15 of row r in ascending order,
+// then the quad adds its four quarters (xor 1, xor 2: the same bits in all four lanes).  LDS operations of one wave execute in order, so the
+// wave needs no barrier - only the compiler has to be kept from moving the reads above the writes (wavefront-scope fences).  Rows of 65
+// doubles: the sixteen rows a read instruction touches then start in sixteen different bank pairs.
+template <int P, int MODE>
+__device__ __forceinline__ void wc_xpose_put(LaneTotals<P, MODE>& T, int row, double v) {
+  constexpr int kRows = LaneTotals<P, MODE>::kWcXposeRows;
+  const int lane = threadIdx.x & 63;
+  double* s = wc_xpose_scratch() + (threadIdx.x >> 6) * kWcXWave;
+  s[(row % kWcXRows) * kWcXStride + lane] = v;
+  if ((row % kWcXRows) == kWcXRows - 1 || row == kRows - 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* mine = s + (lane >> 2) * kWcXStride + (lane & 3) * 16;  // (rows past the last one of a short batch hold older values: summed, never read)
+    double x = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);  // four reads in flight, not sixteen: this sits at the epilogue's register peak
+      x += mine[i];
+    }
+    x += dpp_f64<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E>(x);  // quad_perm [2,3,0,1]
+    // the running sums of the wave live behind its rows (one double per transposition row; as registers they were twelve more VGPRs over the
+    // whole kernel, which cost several instantiations a wave per SIMD)
+    if ((lane & 3) == 0) s[kWcXRows * kWcXStride + (row / kWcXRows) * kWcXRows + (lane >> 2)] += x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next batch's writes stay below these reads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
 
 // layout of the per-block partial vectors (also used by the host to unpack)
 //   f64: [p*1 + 0] pop pi_sum (p < P) | [8 + i] Hudson f64 i | [16 + k] wc_a[k] | [16 + 29 + k] ... too big
@@ -1093,6 +1156,12 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
           if (st != 3) { T.wc_a[k] += oa; T.wc_b[k] += ob; T.wc_inf[k] += 1; }  // 2172-2203
         }
       }
+      if constexpr (LaneTotals<P, MODE>::kWcLdsTotals) {  // every lane, whatever its row: the wave sums these across its lanes
+        const bool counts = row_ok && st != 3;
+        wc_xpose_put<P, MODE>(T, 3 * k + 0, counts ? oa : 0.0);
+        wc_xpose_put<P, MODE>(T, 3 * k + 1, counts ? ob : 0.0);
+        wc_xpose_put<P, MODE>(T, 3 * k + 2, counts ? 1.0 : 0.0);
+      }
     };
     if constexpr (!GENERAL) {
       // biallelic: allele 0 count = n - alt, allele 1 count = alt; every slot is computed and finished in turn
@@ -1161,6 +1230,19 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
 #pragma unroll
       for (int k = 0; k < NW; ++k) { put_f64(kOffWcA + k, T.wc_a[k]); put_f64(kOffWcB + k, T.wc_b[k]); put_u64(kOffWcInf + k, T.wc_inf[k]); }
     }
+    if constexpr (LaneTotals<P, MODE>::kWcLdsTotals) {  // lane (r, 0) holds this wave's sum of transposition row 16 B + r
+#pragma unroll
+      for (int B = 0; B < LaneTotals<P, MODE>::kWcBatches; ++B) {
+        const int row = B * kWcXRows + (lane >> 2);
+        if ((lane & 3) == 0 && row < LaneTotals<P, MODE>::kWcXposeRows) {
+          const double v = wc_xpose_scratch()[wave * kWcXWave + kWcXRows * kWcXStride + row];
+          const int k = row / 3, c = row - 3 * k;
+          if (c == 0) s_f64[wave][kOffWcA + k] = v;
+          else if (c == 1) s_f64[wave][kOffWcB + k] = v;
+          else s_u64[wave][kOffWcInf + k] = (unsigned long long)v;  // a count of sites as a sum of 1.0s: exact
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int p = 0; p < P; ++p) { put_f64(kOffPopF64 + p, T.pop_pi[p]); put_u64(kOffPopSeg + p, T.pop_seg[p]); put_u64(kOffPopUnc + p, T.pop_unc[p]); }
@@ -1193,6 +1275,10 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
 // invariants of the epilogue loop alive across the counting loop (233 VGPRs, two waves), and occupancy is worth more than that (2 -> 3 waves: 16 %)
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
 constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL && !MISSING && P <= 2 && LPR == 16 && (MODE & kModeWc) == 0) ? 3 : 1; }
+// __launch_bounds__' second argument (workgroups of four waves per CU = waves per SIMD): the eight-group W&C kernels of a biallelic packed
+// matrix end one register above 256 when left alone - one wave per SIMD instead of two
+template <int P, int MODE, bool GENERAL, int MM>
+constexpr int sweep_min_blocks() { return (MM == 3 /* kMaskPacked */ && !GENERAL && P == 8 && (MODE & kModeWc) != 0) ? 2 : 1; }
 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
@@ -1220,7 +1306,7 @@ inline size_t defer_lds_bytes(int P, int mode, bool missing, int depth) {
 }
 
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
-__global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
+__global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM>())) void sweep_kernel(const SweepArgs A) {
   static_assert(NPL == 2 || (NPL == 3 && GENERAL && MM == kMaskPacked), "a third plane exists on packed multi-allelic matrices only");
   static_assert(LPR == 16 || ((LPR == 4 || LPR == 8) && MM == kMaskPacked), "four / eight lanes per row exist for the packed cores only");
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1411,10 +1497,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
         uint32_t alt_mine[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) alt_mine[p] = 0;
-        if constexpr (P == 8) {  // eight groups: the shallow batches only (see kShallow below)
-          if (LPR != 16 && A.unroll == 1) tile_rows_packed_prefetch<P, 1, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
-          else tile_rows_packed_prefetch<P, 2, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
-        } else if constexpr (LPR != 16) {
+        if constexpr (LPR != 16) {
           if (A.unroll == 5) tile_rows_packed_prefetch<P, 5, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
           else if (A.unroll == 3) tile_rows_packed_prefetch<P, 3, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
           else if (A.unroll == 2) tile_rows_packed_prefetch<P, 2, LPR>(A, mv, lm, nvec_pad, tile_row0, grp, gl, alt_mine);
@@ -1439,8 +1522,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs A) {
     for (int p = 0; p < P; ++p)
 #pragma unroll
       for (int k = 0; k < NS; ++k) my_s[p][k] = 0;
-    // packed cores: the batch depth U is the launch's (A.unroll); with eight groups on the general path only the shallow batches are
-    // built - deeper ones kept P x U mask vectors live and spilled to scratch
+    // packed cores: the batch depth U is the launch's (A.unroll); with eight groups only the shallow batches are built in this row loop -
+    // deeper ones kept P x U mask vectors live and spilled to scratch (the one-batch-per-row loop above takes any depth: its masks stay in LDS)
     constexpr bool kShallow = P == 8;
     for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
