@@ -1363,11 +1363,34 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   } else {
     FMH_TRY(scratch.get(&alt, G * row_count));
   }
-  if (!d_a) FMH_TRY(scratch.get(&d_a, nslots * row_count));
-  if (!d_b) FMH_TRY(scratch.get(&d_b, nslots * row_count));
-  if (!d_state) FMH_TRY(scratch.get(&d_state, nslots * row_count));
+  // no per-site track asked for: the regional sums straight from the count tables (wc_pair_totals_kernel), nothing per site and slot in memory
+  const size_t tot_lds = ((size_t)(1 + (general ? n_alleles : 1)) * G * kWcTotTile + kWcTotTile) * sizeof(uint32_t);
+  const size_t tot_cells = (size_t)(1 + (general ? n_alleles : 1)) * G * kWcTotTile;
+  const bool totals_only = !d_a && !d_b && !d_state && tot_cells <= (size_t)kWcTotCellsMax * 256;
+  if (!totals_only) {
+    if (!d_a) FMH_TRY(scratch.get(&d_a, nslots * row_count));
+    if (!d_b) FMH_TRY(scratch.get(&d_b, nslots * row_count));
+    if (!d_state) FMH_TRY(scratch.get(&d_state, nslots * row_count));
+  }
+  // A matrix with nothing missing: every group's called count is its size at every site, so each slot's shape and denominators are launch
+  // constants (wc_many_pre_kernel) and the all-columns sweep (1) is not needed
+  WcSlotPre* pre = nullptr;
+  double* grcp = nullptr;
+  uint32_t* gsize = nullptr;
+  if (!m->has_missing) {
+    std::vector<uint32_t> sizes(G, 0);
+    for (size_t gi = 0; gi < G; ++gi)
+      for (size_t col = 0; col < m->columns; ++col) sizes[gi] += h_column_mask[gi * m->columns + col] != 0;
+    FMH_TRY(scratch.get(&pre, nslots));
+    FMH_TRY(scratch.get(&grcp, G));
+    FMH_TRY(scratch.get(&gsize, G));
+    HIP_TRY(hipMemcpyAsync(gsize, sizes.data(), G * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // `sizes` leaves scope; the table is tiny
+    hipLaunchKernelGGL(wc_many_pre_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, n_groups, (const uint32_t*)gsize, pre, grcp);
+    HIP_TRY(hipGetLastError());
+  }
   // (1) called entries over ALL columns: pop_sizes_populated (stats.rs:1987)
-  {
+  if (!pre) {
     std::vector<uint8_t> ones(m->columns, 1);
     fmh_groups* g = nullptr;
     FMH_TRY(fmh_groups_create(m, ones.data(), 1, &g));
@@ -1396,13 +1419,45 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
     fmh_groups_destroy(g);
     FMH_TRY(rc);
   }
-  // (3) per-site components from the count tables, (4) regional sums per slot
-  hipLaunchKernelGGL(wc_from_counts_kernel, dim3((unsigned)((row_count + 255) / 256)), dim3(256), 0, st, n_groups, n_alleles, row_count,
-                     (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, d_a, d_b, d_state);
-  HIP_TRY(hipGetLastError());
   double *sa = nullptr, *sb = nullptr;
   unsigned long long* si = nullptr;
-  FMH_TRY(wc_slot_sums(scratch, st, nslots, row_count, d_a, d_b, d_state, &sa, &sb, &si));
+  if (totals_only) {
+    // chunks of whole tiles of sixteen sites; enough of them to fill the chip with the pairs' workgroups, at most 1 024 (the partials are
+    // nslots x chunks x 24 B), at least one tile each
+    const size_t pair_blocks = (nslots - 1 + 255) / 256;
+    // (about 8 000 workgroups: a CU holds five or so at a time and a launch of only eight per CU ran in two uneven rounds; the partials stay below 4 M entries)
+    size_t chunks = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8192, ((size_t)4 << 20) / nslots), (8192 + pair_blocks - 1) / pair_blocks));
+    size_t chunk_rows = round_up((row_count + chunks - 1) / chunks, (size_t)kWcTotTile);
+    chunks = (row_count + chunk_rows - 1) / chunk_rows;
+    double *pa = nullptr, *pb = nullptr;
+    unsigned long long* pi = nullptr;
+    FMH_TRY(scratch.get(&pa, nslots * chunks));
+    FMH_TRY(scratch.get(&pb, nslots * chunks));
+    FMH_TRY(scratch.get(&pi, nslots * chunks));
+    FMH_TRY(scratch.get(&sa, nslots));
+    FMH_TRY(scratch.get(&sb, nslots));
+    FMH_TRY(scratch.get(&si, nslots));
+    hipLaunchKernelGGL(wc_overall_totals_kernel, dim3((unsigned)chunks), dim3(256), 0, st, n_groups, n_alleles, row_count, chunk_rows, chunks,
+                       (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, pa, pb, pi,
+                       (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
+    HIP_TRY(hipGetLastError());
+    auto* pair_kernel = tot_cells <= 4 * 256 ? wc_pair_totals_kernel<4> : wc_pair_totals_kernel<kWcTotCellsMax>;
+    if (tot_lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot_lds));
+    hipLaunchKernelGGL(pair_kernel, dim3((unsigned)pair_blocks, (unsigned)chunks), dim3(256), tot_lds, st, n_groups, n_alleles, row_count,
+                       chunk_rows, chunks, (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, pa, pb, pi,
+                       (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(wc_slot_finalize_wave_kernel, dim3((unsigned)nslots), dim3(64), 0, st, chunks, (const double*)pa, (const double*)pb,
+                       (const unsigned long long*)pi, sa, sb, si);
+    HIP_TRY(hipGetLastError());
+  } else {
+    // (3) per-site components from the count tables, (4) regional sums per slot
+    hipLaunchKernelGGL(wc_from_counts_kernel, dim3((unsigned)((row_count + 255) / 256)), dim3(256), 0, st, n_groups, n_alleles, row_count,
+                       (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, d_a, d_b, d_state,
+                       (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
+    HIP_TRY(hipGetLastError());
+    FMH_TRY(wc_slot_sums(scratch, st, nslots, row_count, d_a, d_b, d_state, &sa, &sb, &si));
+  }
   if (h_sum_a) HIP_TRY(hipMemcpyAsync(h_sum_a, sa, nslots * 8, hipMemcpyDeviceToHost, st));
   if (h_sum_b) HIP_TRY(hipMemcpyAsync(h_sum_b, sb, nslots * 8, hipMemcpyDeviceToHost, st));
   if (h_informative_sites) HIP_TRY(hipMemcpyAsync(h_informative_sites, si, nslots * 8, hipMemcpyDeviceToHost, st));

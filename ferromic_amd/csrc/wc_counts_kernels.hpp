@@ -16,14 +16,16 @@ namespace fmh {
 struct WcManyShape {
   WcShape sh;
   __device__ void from(const uint32_t* __restrict__ called, size_t rows, size_t site, int gi, int gj, int G) {
+    if (gi >= 0) from_visit([&](auto&& fn) { fn(called[(size_t)gi * rows + site]); fn(called[(size_t)gj * rows + site]); });
+    else from_visit([&](auto&& fn) { for (int g = 0; g < G; ++g) { const uint32_t v = called[(size_t)g * rows + site]; if (v != 0) fn(v); } });
+  }
+  __device__ void from_pair(uint32_t ni, uint32_t nj) { from_visit([&](auto&& fn) { fn(ni); fn(nj); }); }
+  template <class Visit>
+  __device__ void from_visit(Visit&& visit) {
     // r groups with data, visited in group order (overall: all groups; pair: gi, gj)
     sh.s2_den = 0.0; sh.rm1_over_r = 0.0; sh.nbar_m1 = 0.0; sh.a_den = 1.0; sh.b_fac = 0.0; sh.live = 0; sh.s2_ok = 0;
     int r_i = 0;
     unsigned long long total_h = 0;
-    auto visit = [&](auto&& fn) {
-      if (gi >= 0) { fn(called[(size_t)gi * rows + site]); fn(called[(size_t)gj * rows + site]); }
-      else for (int g = 0; g < G; ++g) { const uint32_t v = called[(size_t)g * rows + site]; if (v != 0) fn(v); }
-    };
     visit([&](uint32_t v) { ++r_i; total_h += v; });
     const double r = (double)r_i;
     if (r < 2.0) return;
@@ -42,13 +44,187 @@ struct WcManyShape {
   }
 };
 
+// the overall components of one site (stats.rs:1893-1946); count_of(a, g) = calls of allele a in group g
+template <class CountOf>
+__device__ __forceinline__ void wc_overall_site(int G, int n_alleles, size_t rows, size_t site, const uint32_t* __restrict__ called, CountOf&& count_of,
+                                                double& wa, double& wb) {
+  wa = 0.0; wb = 0.0;
+  int valid = 0;
+  unsigned long long total_called = 0;
+  for (int g = 0; g < G; ++g) { const uint32_t v = called[(size_t)g * rows + site]; if (v != 0) { ++valid; total_called += v; } }
+  if (valid < 2) return;
+  WcManyShape ms;
+  ms.from(called, rows, site, -1, -1, G);
+  if (!ms.sh.live) return;
+  for (int a = 0; a < n_alleles; ++a) {
+    unsigned long long total_target = 0;
+    for (int g = 0; g < G; ++g) if (called[(size_t)g * rows + site] != 0) total_target += count_of(a, g);
+    const double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
+    double num = 0.0;
+    for (int g = 0; g < G; ++g) {
+      const uint32_t v = called[(size_t)g * rows + site];
+      if (v == 0) continue;
+      const double nd = (double)v;
+      const double diff_p = (double)count_of(a, g) / nd - global_freq;
+      num += nd * diff_p * diff_p;
+    }
+    double ca, cb;
+    wc_apply<false>(ms.sh, num, global_freq, ca, cb, nullptr);
+    wa += ca;
+    wb += cb;
+  }
+}
+// one pair of groups with ni, nj > 0 called haplotypes at one site (stats.rs:1948-1985); ci(a), cj(a) = calls of allele a in either group
+template <class Ci, class Cj>
+__device__ __forceinline__ void wc_pair_site(uint32_t ni, uint32_t nj, int n_alleles, Ci&& ci_of, Cj&& cj_of, double& wa, double& wb) {
+  wa = 0.0; wb = 0.0;
+  WcManyShape ms;
+  ms.from_pair(ni, nj);
+  if (!ms.sh.live) return;
+  const unsigned long long pair_total = (unsigned long long)ni + nj;
+  const double ndi = (double)ni, ndj = (double)nj;
+  for (int a = 0; a < n_alleles; ++a) {
+    const uint32_t ci = ci_of(a), cj = cj_of(a);
+    const double pair_global = pair_total > 0 ? (double)((unsigned long long)ci + cj) / (double)pair_total : 0.0;
+    double num = 0.0;
+    { const double diff_p = (double)ci / ndi - pair_global; num += ndi * diff_p * diff_p; }
+    { const double diff_p = (double)cj / ndj - pair_global; num += ndj * diff_p * diff_p; }
+    double pa, pb;
+    wc_apply<false>(ms.sh, num, pair_global, pa, pb, nullptr);
+    wa += pa;
+    wb += pb;
+  }
+}
+
+// ---- a matrix without missing calls: every group's called count is its size at every site ------------------------------------
+// Then the shape of a slot and every denominator are LAUNCH constants, exactly as in the fused kernels (sweep_kernels.hpp, "divisions that
+// share a denominator"): wc_many_pre_kernel computes them once per slot - with the very functions the per-site path would call at every
+// site, so the values are those - and a division becomes div_shared's three operations.  A true f64 division is ~35 instructions and the
+// per-site path makes 17 of them per pair and site: 26 groups x 2 M sites spent 10 ms in them.
+struct WcSlotPre {
+  double s2_den, rm1_over_r, nbar_m1, a_den, b_fac;  // WcShape
+  double rcp[3];                                     // refined reciprocals of s2_den, nbar_m1, a_den (wc_apply<true>)
+  double total, rcp_total;                           // called haplotypes of the slot's groups and the reciprocal
+  int live, s2_ok, has_data, pad;                    // has_data: overall = at least two groups with members; pair = both have members
+};
+__device__ __forceinline__ void wc_pair_of_slot(size_t pair, int G, int& gi, int& gj) {  // pairs in (0,1), (0,2), ... order
+  gi = 0;
+  size_t rem = pair;
+  while (rem >= (size_t)(G - 1 - gi)) { rem -= (size_t)(G - 1 - gi); ++gi; }
+  gj = gi + 1 + (int)rem;
+}
+__global__ __launch_bounds__(256) void wc_many_pre_kernel(int G, const uint32_t* __restrict__ gsize, WcSlotPre* __restrict__ pre, double* __restrict__ grcp) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nslots = 1 + (size_t)G * (G - 1) / 2;
+  if (k < (size_t)G) grcp[k] = gsize[k] ? refined_rcp((double)gsize[k]) : 0.0;
+  if (k >= nslots) return;
+  WcManyShape ms;
+  WcSlotPre o;
+  unsigned long long total = 0;
+  if (k == 0) {
+    int valid = 0;
+    for (int g = 0; g < G; ++g) if (gsize[g]) { ++valid; total += gsize[g]; }
+    ms.from_visit([&](auto&& fn) { for (int g = 0; g < G; ++g) if (gsize[g]) fn(gsize[g]); });
+    o.has_data = valid >= 2;
+  } else {
+    int gi, gj;
+    wc_pair_of_slot(k - 1, G, gi, gj);
+    const uint32_t ni = gsize[gi], nj = gsize[gj];
+    total = (unsigned long long)ni + nj;
+    ms.from_pair(ni, nj);
+    o.has_data = ni != 0 && nj != 0;
+  }
+  o.s2_den = ms.sh.s2_den; o.rm1_over_r = ms.sh.rm1_over_r; o.nbar_m1 = ms.sh.nbar_m1; o.a_den = ms.sh.a_den; o.b_fac = ms.sh.b_fac;
+  o.live = ms.sh.live; o.s2_ok = ms.sh.s2_ok; o.pad = 0;
+  o.rcp[0] = refined_rcp(ms.sh.s2_den); o.rcp[1] = refined_rcp(ms.sh.nbar_m1); o.rcp[2] = refined_rcp(ms.sh.a_den);
+  o.total = (double)total;
+  o.rcp_total = total ? refined_rcp((double)total) : 0.0;
+  pre[k] = o;
+}
+__device__ __forceinline__ WcShape wc_shape_of_pre(const WcSlotPre& o) {
+  WcShape sh;
+  sh.s2_den = o.s2_den; sh.rm1_over_r = o.rm1_over_r; sh.nbar_m1 = o.nbar_m1; sh.a_den = o.a_den; sh.b_fac = o.b_fac; sh.live = o.live; sh.s2_ok = o.s2_ok;
+  return sh;
+}
+// wc_overall_site / wc_pair_site with the launch constants: the same operands in the same order, div_shared for every division
+template <class CountOf>
+__device__ __forceinline__ void wc_overall_site_pre(int G, int n_alleles, const uint32_t* __restrict__ gsize, const double* __restrict__ grcp,
+                                                    const WcSlotPre& o, CountOf&& count_of, double& wa, double& wb) {
+  wa = 0.0; wb = 0.0;
+  if (!o.has_data || !o.live) return;
+  const WcShape sh = wc_shape_of_pre(o);
+  for (int a = 0; a < n_alleles; ++a) {
+    unsigned long long total_target = 0;
+    for (int g = 0; g < G; ++g) if (gsize[g] != 0) total_target += count_of(a, g);
+    const double global_freq = o.total > 0.0 ? div_shared((double)total_target, o.total, o.rcp_total) : 0.0;
+    double num = 0.0;
+    for (int g = 0; g < G; ++g) {
+      if (gsize[g] == 0) continue;
+      const double nd = (double)gsize[g];
+      const double diff_p = div_shared((double)count_of(a, g), nd, grcp[g]) - global_freq;
+      num += nd * diff_p * diff_p;
+    }
+    double ca, cb;
+    wc_apply<true>(sh, num, global_freq, ca, cb, o.rcp);
+    wa += ca;
+    wb += cb;
+  }
+}
+template <class Ci, class Cj>
+__device__ __forceinline__ void wc_pair_site_pre(double ndi, double ndj, double rcpi, double rcpj, const WcSlotPre& o, int n_alleles, Ci&& ci_of,
+                                                 Cj&& cj_of, double& wa, double& wb) {
+  wa = 0.0; wb = 0.0;
+  if (!o.live) return;
+  const WcShape sh = wc_shape_of_pre(o);
+  for (int a = 0; a < n_alleles; ++a) {
+    const uint32_t ci = ci_of(a), cj = cj_of(a);
+    const double pair_global = o.total > 0.0 ? div_shared((double)((unsigned long long)ci + cj), o.total, o.rcp_total) : 0.0;
+    double num = 0.0;
+    { const double diff_p = div_shared((double)ci, ndi, rcpi) - pair_global; num += ndi * diff_p * diff_p; }
+    { const double diff_p = div_shared((double)cj, ndj, rcpj) - pair_global; num += ndj * diff_p * diff_p; }
+    double pa, pb;
+    wc_apply<true>(sh, num, pair_global, pa, pb, o.rcp);
+    wa += pa;
+    wb += pb;
+  }
+}
+
 __global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_alleles, size_t rows, const uint32_t* __restrict__ called,
                                                              const uint32_t* __restrict__ alt, const uint32_t* __restrict__ acounts,
                                                              const uint32_t* __restrict__ n_all, double* __restrict__ out_a,
-                                                             double* __restrict__ out_b, uint8_t* __restrict__ out_state) {
+                                                             double* __restrict__ out_b, uint8_t* __restrict__ out_state,
+                                                             const WcSlotPre* __restrict__ pre, const double* __restrict__ grcp,
+                                                             const uint32_t* __restrict__ gsize) {
   const size_t site = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (site >= rows) return;
   const size_t nslots = 1 + (size_t)G * (G - 1) / 2;
+  if (pre) {  // nothing missing: called counts are the group sizes, every slot's shape and denominators are launch constants (wave-uniform loads)
+    auto count_of = [&](int a, int g) -> uint32_t {
+      if (acounts) return acounts[((size_t)a * G + g) * rows + site];
+      const uint32_t c1 = alt[(size_t)g * rows + site];
+      return a == 1 ? c1 : gsize[g] - c1;
+    };
+    {
+      double wa, wb;
+      wc_overall_site_pre(G, n_alleles, gsize, grcp, pre[0], count_of, wa, wb);
+      out_a[site] = wa;
+      out_b[site] = wb;
+      out_state[site] = wc_classify(wa, wb);
+    }
+    size_t k = 1;
+    for (int i = 0; i < G; ++i) {
+      const double ndi = (double)gsize[i], rcpi = grcp[i];
+      for (int j = i + 1; j < G; ++j, ++k) {
+        if (!pre[k].has_data) { out_a[k * rows + site] = 0.0; out_b[k * rows + site] = 0.0; out_state[k * rows + site] = 3; continue; }
+        double wa, wb;
+        wc_pair_site_pre(ndi, (double)gsize[j], rcpi, grcp[j], pre[k], n_alleles, [&](int a) { return count_of(a, i); }, [&](int a) { return count_of(a, j); }, wa, wb);
+        out_a[k * rows + site] = wa;
+        out_b[k * rows + site] = wb;
+        out_state[k * rows + site] = wc_classify(wa, wb);
+      }
+    }
+    return;
+  }
   auto count_of = [&](int a, int g) -> uint32_t {
     if (acounts) return acounts[((size_t)a * G + g) * rows + site];
     const uint32_t c1 = alt[(size_t)g * rows + site];
@@ -58,35 +234,10 @@ __global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_allele
     for (size_t k = 0; k < nslots; ++k) { out_a[k * rows + site] = 0.0; out_b[k * rows + site] = 0.0; out_state[k * rows + site] = 3; }
     return;
   }
-  WcManyShape ms;
   // ---- overall (stats.rs:1893-1946) ----
   {
-    double wa = 0.0, wb = 0.0;
-    int valid = 0;
-    unsigned long long total_called = 0;
-    for (int g = 0; g < G; ++g) { const uint32_t v = called[(size_t)g * rows + site]; if (v != 0) { ++valid; total_called += v; } }
-    if (valid >= 2) {
-      ms.from(called, rows, site, -1, -1, G);
-      if (ms.sh.live) {
-        for (int a = 0; a < n_alleles; ++a) {
-          unsigned long long total_target = 0;
-          for (int g = 0; g < G; ++g) if (called[(size_t)g * rows + site] != 0) total_target += count_of(a, g);
-          const double global_freq = total_called > 0 ? (double)total_target / (double)total_called : 0.0;
-          double num = 0.0;
-          for (int g = 0; g < G; ++g) {
-            const uint32_t v = called[(size_t)g * rows + site];
-            if (v == 0) continue;
-            const double nd = (double)v;
-            const double diff_p = (double)count_of(a, g) / nd - global_freq;
-            num += nd * diff_p * diff_p;
-          }
-          double ca, cb;
-          wc_apply<false>(ms.sh, num, global_freq, ca, cb, nullptr);
-          wa += ca;
-          wb += cb;
-        }
-      }
-    }
+    double wa, wb;
+    wc_overall_site(G, n_alleles, rows, site, called, count_of, wa, wb);
     out_a[site] = wa;
     out_b[site] = wb;
     out_state[site] = wc_classify(wa, wb);
@@ -98,23 +249,8 @@ __global__ __launch_bounds__(256) void wc_from_counts_kernel(int G, int n_allele
     for (int j = i + 1; j < G; ++j, ++k) {
       const uint32_t nj = called[(size_t)j * rows + site];
       if (ni == 0 || nj == 0) { out_a[k * rows + site] = 0.0; out_b[k * rows + site] = 0.0; out_state[k * rows + site] = 3; continue; }
-      double wa = 0.0, wb = 0.0;
-      ms.from(called, rows, site, i, j, G);
-      if (ms.sh.live) {
-        const unsigned long long pair_total = (unsigned long long)ni + nj;
-        const double ndi = (double)ni, ndj = (double)nj;
-        for (int a = 0; a < n_alleles; ++a) {
-          const uint32_t ci = count_of(a, i), cj = count_of(a, j);
-          const double pair_global = pair_total > 0 ? (double)((unsigned long long)ci + cj) / (double)pair_total : 0.0;
-          double num = 0.0;
-          { const double diff_p = (double)ci / ndi - pair_global; num += ndi * diff_p * diff_p; }
-          { const double diff_p = (double)cj / ndj - pair_global; num += ndj * diff_p * diff_p; }
-          double pa, pb;
-          wc_apply<false>(ms.sh, num, pair_global, pa, pb, nullptr);
-          wa += pa;
-          wb += pb;
-        }
-      }
+      double wa, wb;
+      wc_pair_site(ni, nj, n_alleles, [&](int a) { return count_of(a, i); }, [&](int a) { return count_of(a, j); }, wa, wb);
       out_a[k * rows + site] = wa;
       out_b[k * rows + site] = wb;
       out_state[k * rows + site] = wc_classify(wa, wb);
@@ -155,6 +291,172 @@ __global__ void wc_slot_finalize_kernel(size_t nslots, size_t chunks, const doub
   unsigned long long vi = 0;
   for (size_t c = 0; c < chunks; ++c) { va += part_a[k * chunks + c]; vb += part_b[k * chunks + c]; vi += part_inf[k * chunks + c]; }
   sum_a[k] = va; sum_b[k] = vb; informative[k] = vi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Regional sums ONLY, from the count tables (fmh_wc_sweep_many without per-site tracks: run_vcf's CSV populations ask for nothing else).
+// The per-site route above writes and re-reads (1 + G(G-1)/2) x 17 B per site - 26 populations: 5.5 KB per site, 11 GB of scratch per
+// 2 M sites.  Here nothing per site and slot leaves the chip:
+//  * pairs: one THREAD per pair walks the sites of a chunk in ascending order with its sums in registers; the workgroup's 256 pairs share
+//    the count tables of sixteen sites at a time through LDS ([called | alt or the alleles' counts][G][16]);
+//  * overall: one thread per site (G-long loops), summed like wc_slot_reduce_kernel.
+// Both write partial[slot][chunk]; wc_slot_finalize_kernel adds the chunks in ascending order.  The per-site arithmetic is wc_pair_site /
+// wc_overall_site, i.e. the bits of the per-site route; only the order of the regional additions differs (as it does between any two routes).
+// ------------------------------------------------------------------------------------------------
+constexpr int kWcTotTile = 16;
+constexpr int kWcTotCellsMax = 64;  // cells of a tile per thread (256 threads) at most: tables of up to 64 KB
+template <int CPT>  // cells of a tile per thread: (1 + NAr) x G x 16 <= 256 CPT
+__global__ __launch_bounds__(256) void wc_pair_totals_kernel(int G, int n_alleles, size_t rows, size_t chunk_rows, size_t chunks,
+                                                             const uint32_t* __restrict__ called, const uint32_t* __restrict__ alt,
+                                                             const uint32_t* __restrict__ acounts, const uint32_t* __restrict__ n_all,
+                                                             double* __restrict__ part_a, double* __restrict__ part_b,
+                                                             unsigned long long* __restrict__ part_inf, const WcSlotPre* __restrict__ pre,
+                                                             const double* __restrict__ grcp, const uint32_t* __restrict__ gsize) {
+  extern __shared__ uint32_t wc_tot_lds[];  // [1 + NAr][G][16] counts, then [16] n_all
+  const int NAr = acounts ? n_alleles : 1;
+  const size_t npairs = (size_t)G * (G - 1) / 2;
+  const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool active = pair < npairs;
+  int gi = 0, gj = 1;
+  if (active) wc_pair_of_slot(pair, G, gi, gj);
+  // nothing missing (pre != null): this pair's launch constants in registers; the `called` plane of the tile is then the group sizes
+  WcSlotPre mine{};
+  double ndi = 0.0, ndj = 0.0, rcpi = 0.0, rcpj = 0.0;
+  uint32_t size_i = 0, size_j = 0;
+  if (pre && active) { mine = pre[1 + pair]; size_i = gsize[gi]; size_j = gsize[gj]; ndi = (double)size_i; ndj = (double)size_j; rcpi = grcp[gi]; rcpj = grcp[gj]; }
+  const size_t c = blockIdx.y;
+  const size_t s0 = c * chunk_rows, s1 = s0 + chunk_rows < rows ? s0 + chunk_rows : rows;
+  uint32_t* tile_nall = wc_tot_lds + (size_t)(1 + NAr) * G * kWcTotTile;
+  double va = 0.0, vb = 0.0;
+  unsigned long long vi = 0;
+  // the tile after the current one travels in registers while the current one is worked on (a tile is sixteen sites of every table:
+  // (1 + NAr) x G x 16 cells over 256 threads, CPT per thread)
+  const uint32_t cells = (uint32_t)(1 + NAr) * (uint32_t)G * kWcTotTile;
+  auto fetch = [&](size_t t0, uint32_t (&v)[CPT]) {
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const uint32_t idx = threadIdx.x + 256u * q;
+      v[q] = 0;
+      if (idx >= cells) continue;
+      const uint32_t t = idx % kWcTotTile, g = (idx / kWcTotTile) % (uint32_t)G, arr = idx / (kWcTotTile * (uint32_t)G);
+      const size_t site = t0 + t;
+      if (site >= s1) continue;
+      if (arr == 0) v[q] = pre ? 0u : called[(size_t)g * rows + site];  // (not read when the sizes are launch constants)
+      else if (acounts) v[q] = acounts[((size_t)(arr - 1) * G + g) * rows + site];
+      else v[q] = alt[(size_t)g * rows + site];
+    }
+  };
+  constexpr bool kAhead = CPT <= 4;  // larger tables are staged directly (their cells' addresses alone would take the register file)
+  uint32_t next[CPT];
+  if (kAhead && s0 < s1) fetch(s0, next);
+  for (size_t t0 = s0; t0 < s1; t0 += kWcTotTile) {
+    __syncthreads();
+    if constexpr (kAhead) {
+#pragma unroll
+      for (int q = 0; q < CPT; ++q) { const uint32_t idx = threadIdx.x + 256u * q; if (idx < cells) wc_tot_lds[idx] = next[q]; }
+    } else {
+      for (uint32_t idx = threadIdx.x; idx < cells; idx += 256) {
+        const uint32_t t = idx % kWcTotTile, g = (idx / kWcTotTile) % (uint32_t)G, arr = idx / (kWcTotTile * (uint32_t)G);
+        const size_t site = t0 + t;
+        uint32_t v = 0;
+        if (site < s1) {
+          if (arr == 0) v = pre ? 0u : called[(size_t)g * rows + site];
+          else if (acounts) v = acounts[((size_t)(arr - 1) * G + g) * rows + site];
+          else v = alt[(size_t)g * rows + site];
+        }
+        wc_tot_lds[idx] = v;
+      }
+    }
+    if (threadIdx.x < kWcTotTile) tile_nall[threadIdx.x] = t0 + threadIdx.x < s1 ? (pre ? 1u : n_all[t0 + threadIdx.x]) : 0;
+    __syncthreads();
+    if (kAhead && t0 + kWcTotTile < s1) fetch(t0 + kWcTotTile, next);
+    if (!active) continue;
+    if (pre) {
+      if (!mine.has_data) continue;
+      for (int t = 0; t < kWcTotTile; ++t) {
+        if (tile_nall[t] == 0) continue;  // past the chunk
+        auto count_of = [&](int a, int g, uint32_t n) -> uint32_t {
+          if (acounts) return wc_tot_lds[((size_t)(1 + a) * G + g) * kWcTotTile + t];
+          const uint32_t c1 = wc_tot_lds[((size_t)G + g) * kWcTotTile + t];
+          return a == 1 ? c1 : n - c1;
+        };
+        double wa, wb;
+        wc_pair_site_pre(ndi, ndj, rcpi, rcpj, mine, n_alleles, [&](int a) { return count_of(a, gi, size_i); }, [&](int a) { return count_of(a, gj, size_j); }, wa, wb);
+        va += wa; vb += wb; ++vi;
+      }
+      continue;
+    }
+    for (int t = 0; t < kWcTotTile; ++t) {
+      if (tile_nall[t] == 0) continue;  // no allele among all samples (or past the chunk): InsufficientData, not summed
+      const uint32_t ni = wc_tot_lds[(size_t)gi * kWcTotTile + t], nj = wc_tot_lds[(size_t)gj * kWcTotTile + t];
+      if (ni == 0 || nj == 0) continue;
+      auto count_of = [&](int a, int g, uint32_t n) -> uint32_t {
+        if (acounts) return wc_tot_lds[((size_t)(1 + a) * G + g) * kWcTotTile + t];
+        const uint32_t c1 = wc_tot_lds[((size_t)G + g) * kWcTotTile + t];
+        return a == 1 ? c1 : n - c1;
+      };
+      double wa, wb;
+      wc_pair_site(ni, nj, n_alleles, [&](int a) { return count_of(a, gi, ni); }, [&](int a) { return count_of(a, gj, nj); }, wa, wb);
+      va += wa; vb += wb; ++vi;  // every state but InsufficientData is summed (stats.rs:2172-2203)
+    }
+  }
+  if (active) { part_a[(1 + pair) * chunks + c] = va; part_b[(1 + pair) * chunks + c] = vb; part_inf[(1 + pair) * chunks + c] = vi; }
+}
+
+__global__ __launch_bounds__(256) void wc_overall_totals_kernel(int G, int n_alleles, size_t rows, size_t chunk_rows, size_t chunks,
+                                                                const uint32_t* __restrict__ called, const uint32_t* __restrict__ alt,
+                                                                const uint32_t* __restrict__ acounts, const uint32_t* __restrict__ n_all,
+                                                                double* __restrict__ part_a, double* __restrict__ part_b,
+                                                                unsigned long long* __restrict__ part_inf, const WcSlotPre* __restrict__ pre,
+                                                                const double* __restrict__ grcp, const uint32_t* __restrict__ gsize) {
+  const size_t c = blockIdx.x;
+  const size_t s0 = c * chunk_rows, s1 = s0 + chunk_rows < rows ? s0 + chunk_rows : rows;
+  double va = 0.0, vb = 0.0;
+  unsigned long long vi = 0;
+  for (size_t site = s0 + threadIdx.x; site < s1; site += 256) {
+    if (pre) {
+      auto count_of = [&](int a, int g) -> uint32_t {
+        if (acounts) return acounts[((size_t)a * G + g) * rows + site];
+        const uint32_t c1 = alt[(size_t)g * rows + site];
+        return a == 1 ? c1 : gsize[g] - c1;
+      };
+      double wa, wb;
+      wc_overall_site_pre(G, n_alleles, gsize, grcp, pre[0], count_of, wa, wb);
+      va += wa; vb += wb; ++vi;
+      continue;
+    }
+    if (n_all[site] == 0) continue;
+    auto count_of = [&](int a, int g) -> uint32_t {
+      if (acounts) return acounts[((size_t)a * G + g) * rows + site];
+      const uint32_t c1 = alt[(size_t)g * rows + site];
+      return a == 1 ? c1 : called[(size_t)g * rows + site] - c1;
+    };
+    double wa, wb;
+    wc_overall_site(G, n_alleles, rows, site, called, count_of, wa, wb);
+    va += wa; vb += wb; ++vi;
+  }
+  __shared__ double la[256], lb[256];
+  __shared__ unsigned long long li[256];
+  la[threadIdx.x] = va; lb[threadIdx.x] = vb; li[threadIdx.x] = vi;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { la[threadIdx.x] += la[threadIdx.x + w]; lb[threadIdx.x] += lb[threadIdx.x + w]; li[threadIdx.x] += li[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_a[c] = la[0]; part_b[c] = lb[0]; part_inf[c] = li[0]; }
+}
+
+// the chunks of one slot added by one wave: lane l takes chunks l, l + 64, ... in ascending order, then a fixed xor tree over the lanes
+// (the totals route has thousands of chunks per slot; wc_slot_finalize_kernel's one thread per slot would walk them one by one)
+__global__ __launch_bounds__(64) void wc_slot_finalize_wave_kernel(size_t chunks, const double* __restrict__ part_a, const double* __restrict__ part_b,
+                                                                   const unsigned long long* __restrict__ part_inf, double* __restrict__ sum_a,
+                                                                   double* __restrict__ sum_b, unsigned long long* __restrict__ informative) {
+  const size_t k = blockIdx.x;
+  double va = 0.0, vb = 0.0;
+  unsigned long long vi = 0;
+  for (size_t c = threadIdx.x; c < chunks; c += 64) { va += part_a[k * chunks + c]; vb += part_b[k * chunks + c]; vi += part_inf[k * chunks + c]; }
+  va = wave_sum(va); vb = wave_sum(vb); vi = wave_sum(vi);
+  if (threadIdx.x == 0) { sum_a[k] = va; sum_b[k] = vb; informative[k] = vi; }
 }
 
 }  // namespace fmh

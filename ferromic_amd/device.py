@@ -302,12 +302,18 @@ def wc_sweep(m: DeviceMatrix, g: Groups, row_begin: int = 0, row_count: Optional
                     d_n.to_numpy(np.uint32, P * rows).reshape(P, rows))
 
 
-def wc_sweep_many(m: DeviceMatrix, masks: np.ndarray, row_begin: int = 0, row_count: Optional[int] = None) -> WcResult:
-    """fmh_wc_sweep_many: W&C for any number of groups (counting in batches of 8, arithmetic from count tables)."""
+def wc_sweep_many(m: DeviceMatrix, masks: np.ndarray, row_begin: int = 0, row_count: Optional[int] = None, sites: bool = True) -> WcResult:
+    """fmh_wc_sweep_many: W&C for any number of groups (counting in batches of 8, arithmetic from count tables).
+    sites=False: no per-site track is asked for - the regional sums come straight from the count tables (a, b, state, group_called = None)."""
     rows = m.variants - row_begin if row_count is None else row_count
     masks = np.ascontiguousarray(masks, dtype=np.uint8)
     G = int(masks.shape[0])
     nw = 1 + G * (G - 1) // 2
+    if not sites:
+        sum_a, sum_b = np.zeros(nw, dtype=np.float64), np.zeros(nw, dtype=np.float64)
+        inf = np.zeros(nw, dtype=np.uint64)
+        _abi.check(_abi.load().fmh_wc_sweep_many(m._h, _ptr(masks), G, row_begin, rows, None, None, None, None, _ptr(sum_a), _ptr(sum_b), _ptr(inf), None))
+        return WcResult(sum_a, sum_b, inf, int(rows), None, None, None, None)
     d_a, d_b = DeviceBuffer(m.device, 8 * nw * rows), DeviceBuffer(m.device, 8 * nw * rows)
     d_s, d_n = DeviceBuffer(m.device, nw * rows), DeviceBuffer(m.device, 4 * G * rows)
     sum_a, sum_b = np.zeros(nw, dtype=np.float64), np.zeros(nw, dtype=np.float64)

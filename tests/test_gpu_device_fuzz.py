@@ -79,6 +79,9 @@ def test_random_geometry_counts(dev, seed):
                 k += 1
         wm = dev.wc_sweep_many(dm, masks, r0, r1 - r0)   # counts path: same per-site bits as the fused kernel
         assert np.array_equal(wm.a, w.a) and np.array_equal(wm.b, w.b) and np.array_equal(wm.state, w.state)
+        wt = dev.wc_sweep_many(dm, masks, r0, r1 - r0, sites=False)   # no track asked for: regional sums straight from the count tables
+        assert np.array_equal(wt.informative_sites, wm.informative_sites)
+        assert np.allclose(wt.sum_a, wm.sum_a, rtol=1e-11, atol=1e-11) and np.allclose(wt.sum_b, wm.sum_b, rtol=1e-11, atol=1e-11)
 
 
 @pytest.mark.parametrize("seed", range(CASES))

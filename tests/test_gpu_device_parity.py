@@ -330,6 +330,31 @@ def test_rows_wider_than_lds_for_all_masks(dev):
             k4 += 1
 
 
+@pytest.mark.parametrize("G,max_allele,p_missing,S", [(9, 1, 0.0, 3000), (12, 1, 0.02, 5000), (26, 1, 0.0, 40_000), (26, 3, 0.01, 2500), (40, 6, 0.0, 700), (70, 1, 0.3, 900)])
+def test_many_groups_totals_without_tracks(dev, G, max_allele, p_missing, S):
+    """fmh_wc_sweep_many with no per-site track asked for (run_vcf's CSV populations): the regional sums come straight from the count
+    tables (one thread per pair over the sites of a chunk) and equal the sums of the per-site route's tracks - informative sites exactly,
+    sum a / sum b to the order of the additions."""
+    rng = np.random.default_rng(1000 * G + max_allele)
+    N = 180
+    m = H.random_dense_matrix(rng, S, N, 2, max_allele, p_missing)
+    dm = upload(dev, m)
+    pop_of_sample = rng.integers(0, G, size=N)
+    pop_of_sample[:G] = np.arange(G)  # no empty group
+    masks = np.stack([dev.Groups.mask_from_haplotypes(dm, H.haps_for_samples(np.nonzero(pop_of_sample == g)[0].tolist())) for g in range(G)])
+    for (r0, rows) in ((0, S), (S // 3, S // 2 + 5)):
+        full = dev.wc_sweep_many(dm, masks, r0, rows)
+        tot = dev.wc_sweep_many(dm, masks, r0, rows, sites=False)
+        assert tot.a is None and tot.sites_attempted == rows
+        assert np.array_equal(tot.informative_sites, full.informative_sites)
+        counted = full.state != 3
+        assert np.array_equal(tot.informative_sites, counted.sum(axis=1).astype(np.uint64))
+        exp_a = np.where(counted, full.a, 0.0).sum(axis=1)
+        exp_b = np.where(counted, full.b, 0.0).sum(axis=1)
+        assert np.allclose(tot.sum_a, exp_a, rtol=1e-10, atol=1e-10) and np.allclose(tot.sum_b, exp_b, rtol=1e-10, atol=1e-10)
+        assert np.allclose(tot.sum_a, full.sum_a, rtol=1e-10, atol=1e-10) and np.allclose(tot.sum_b, full.sum_b, rtol=1e-10, atol=1e-10)
+
+
 def test_mask_routes_agree(dev, fmh_opts):
     """The sweep keeps the group masks as bytes in LDS, as bits in LDS (rows too wide for bytes) or as bytes in global
     memory (rows too wide for bits); FMH_MASK_MODE forces the slower routes on rows that do not need them.  All three

@@ -41,7 +41,13 @@ def main():
         many = lambda: _abi.check(lib.fmh_wc_sweep_many(dm._h, device._ptr(masks), G, 0, S, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr,
                                                         device._ptr(sa), device._ptr(sb), device._ptr(si), None))
         many(); t0 = time.perf_counter(); [many() for _ in range(3)]; out["counts_path_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+        ta, tb, ti = np.zeros(nw), np.zeros(nw), np.zeros(nw, dtype=np.uint64)
+        totals = lambda: _abi.check(lib.fmh_wc_sweep_many(dm._h, device._ptr(masks), G, 0, S, None, None, None, None, device._ptr(ta), device._ptr(tb), device._ptr(ti), None))
+        totals(); t0 = time.perf_counter(); [totals() for _ in range(3)]; out["counts_path_totals_only_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+        out["totals_only_agrees"] = bool(np.allclose(ta, sa, rtol=1e-9, atol=1e-9) and np.array_equal(ti, si))
         if G <= 8:
+            fused_tot = lambda: _abi.check(lib.fmh_wc_sweep(dm._h, g._h, 0, S, None, None, None, None, C.byref(tot), None))
+            fused_tot(); t0 = time.perf_counter(); [fused_tot() for _ in range(5)]; out["fused_totals_only_ms"] = (time.perf_counter() - t0) / 5 * 1e3
             out["sums_agree"] = bool(np.allclose(sa[:nw], np.array(tot.sum_a[:nw]), rtol=1e-9, atol=1e-9))
         print(json.dumps(out), flush=True)
         del bufs
