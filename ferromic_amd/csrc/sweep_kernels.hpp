@@ -653,7 +653,8 @@ template <int P, bool MISSING, bool NEED_ALL, int NPL, int U, int LPR>
 __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uint4* __restrict__ lds_mask, uint32_t nvec_pad,
                                                  const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1,
                                                  const uint8_t* __restrict__ row2, const uint8_t* __restrict__ called_ptr, int gl,
-                                                 uint32_t (&n)[P], uint32_t& n_all, uint32_t& allele_or, uint32_t (&s)[P][(1 << NPL) - 1]) {
+                                                 uint32_t (&n)[P], uint32_t& n_all, uint32_t& allele_or, uint32_t (&s)[P][(1 << NPL) - 1],
+                                                 int live_groups = P) {
   constexpr int NS = (1 << NPL) - 1;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -704,6 +705,7 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
       }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
+        if (P == 8 && p >= live_groups) continue;  // five to seven groups run the eight-group kernel: the padding's masks are zero, nothing to count
         uint4 m = lds_mask[(uint32_t)p * nvec_pad + v];  // zero beyond the row
         if (MISSING) { m = and128(m, cb[u]); n[p] = popc128(m, n[p]); }
 #pragma unroll
@@ -1538,7 +1540,7 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM>()))
         const uint8_t* row_ptr1 = NPLK >= 2 ? mv.data1 + row * mv.pitch : nullptr;
         const uint8_t* row_ptr2 = NPLK >= 3 ? mv.data2 + row * mv.pitch : nullptr;
         constexpr bool NA_ALL = GENERAL || NEED_ALL;
-#define FMH_COUNT_PACKED(UV) count_row_packed<P, MISSING, NA_ALL, NPLK, UV, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, row_ptr2, bits_ptr, gl, n, n_all, aor, sp)
+#define FMH_COUNT_PACKED(UV) count_row_packed<P, MISSING, NA_ALL, NPLK, UV, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, row_ptr2, bits_ptr, gl, n, n_all, aor, sp, P == 8 ? A.n_groups : P)
         if constexpr (LPR != 16) {
           if constexpr (kShallow) { if (A.unroll == 2) FMH_COUNT_PACKED(2); else FMH_COUNT_PACKED(1); }
           else if (A.unroll == 5) FMH_COUNT_PACKED(5);
