@@ -519,7 +519,7 @@ __device__ __forceinline__ void wc_for_each_slot(const SweepArgs& A, const uint3
         }
       }
       emit(k, wa, wb, both);
-      FMH_SLOT_FENCE();
+      FMH_SLOT_FENCE();  // (eight groups: a fence after every second or fourth slot only changed nothing, 0.36 / 0.52 ms either way)
       ++k;
     }
   }
