@@ -133,6 +133,7 @@ SYMBOLS = {
     "fmh_groups_sizes": (_i, [_vp, _P(_i), _P(_u64)]),
     "fmh_population_summaries": (_i, [_vp, _vp, _sz, _sz, _i, _vp, _vp, _P(PopTotals), _vp]),
     "fmh_hudson_sweep": (_i, [_vp, _vp, _sz, _sz, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
+    "fmh_hudson_from_counts": (_i, [_i, _vp, _vp, _u64, _vp, _vp, _u64, _sz, _i, _i, _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_diversity_sites": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(PopTotals), _vp]),
     "fmh_pair_region_sweep": (_i, [_vp, _vp, _sz, _sz, _i, _i, _P(PairDiversitySites), _P(HudsonSites), _P(HudsonTotals), _vp]),
     "fmh_wc_sweep": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp, _P(WcTotals), _vp]),

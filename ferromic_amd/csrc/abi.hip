@@ -1172,6 +1172,53 @@ extern "C" int fmh_hudson_sweep(const fmh_matrix* m, const fmh_groups* g, size_t
   return FMH_OK;
 }
 
+// Hudson totals (and per-site records) of two populations from their count tables - populations of different matrices included
+extern "C" int fmh_hudson_from_counts(int device, const uint32_t* d_called1, const uint32_t* d_alt1, uint64_t capacity1, const uint32_t* d_called2,
+                                      const uint32_t* d_alt2, uint64_t capacity2, size_t row_count, int formula, int any_missing,
+                                      const fmh_hudson_sites* sites, fmh_hudson_totals* h_totals, void* stream) {
+  FMH_TRY(check_formula(formula));
+  if (row_count && (!d_called1 || !d_alt1 || !d_called2 || !d_alt2)) return fail(FMH_ERR_INVALID, "NULL count table");
+  if (h_totals) { memset(h_totals, 0, sizeof *h_totals); h_totals->pop[0].haplotype_capacity = capacity1; h_totals->pop[1].haplotype_capacity = capacity2; }
+  if (row_count == 0) return FMH_OK;
+  FMH_TRY(use_device(device));
+  Workspace* w = nullptr;
+  FMH_TRY(workspace(device, &w));
+  LeaseHolder hold;
+  hold.w = w;
+  FMH_TRY(lease_acquire(w, &hold.l));
+  SweepLease* l = hold.l;
+  hipStream_t st = stream ? (hipStream_t)stream : l->stream;
+  SweepArgs a{};
+  a.row_begin = 0;
+  a.row_count = row_count;
+  a.formula = formula;
+  a.n_groups = 2;
+  if (sites) {
+    a.fst = sites->d_fst; a.dxy = sites->d_dxy; a.pi1 = sites->d_pi1; a.pi2 = sites->d_pi2;
+    a.num = sites->d_num; a.den = sites->d_den; a.alt = sites->d_alt; a.called = sites->d_called;
+  }
+  a.part_f64 = l->part_f64;
+  a.part_u64 = l->part_u64;
+  const int grid = (int)std::min<size_t>((size_t)w->max_grid, (row_count + kBlock - 1) / kBlock);
+  if (any_missing) hipLaunchKernelGGL(hudson_from_counts_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, d_called1, d_alt1, d_called2, d_alt2);
+  else hipLaunchKernelGGL(hudson_from_counts_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, d_called1, d_alt1, d_called2, d_alt2);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, l->part_f64, l->part_u64, grid, l->out_f64, l->out_u64);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(l->h_f64, l->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(l->h_u64, l->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h_totals) {
+    SweepResult r;
+    memcpy(r.f64, l->h_f64, sizeof r.f64);
+    memcpy(r.u64, l->h_u64, sizeof r.u64);
+    fmh_groups caps;
+    caps.sizes[0] = capacity1; caps.sizes[1] = capacity2;
+    fill_hudson_totals(&caps, r, h_totals);
+  }
+  return FMH_OK;
+}
+
 extern "C" int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, size_t row_begin, size_t row_count,
                                    double* d_pi, double* d_theta, uint32_t* d_called, uint32_t* d_distinct,
                                    fmh_pop_totals* h_totals, void* stream) {

@@ -446,6 +446,35 @@ __global__ __launch_bounds__(256) void wc_overall_totals_kernel(int G, int n_all
   if (threadIdx.x == 0) { part_a[c] = la[0]; part_b[c] = lb[0]; part_inf[c] = li[0]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Hudson pair of two populations from their per-site count tables (aggregate_hudson_components_from_summaries, stats.rs:1554-1623,
+// and the per-site records of dense_hudson_sites_biallelic): what the reference computes from two DensePopulationSummary objects, which
+// may come from DIFFERENT matrices.  Same per-site code as the sweep after its counting (finish_biallelic_site, site_epilogue), one site
+// per thread, the block / grid reduction of the sweep.
+// ------------------------------------------------------------------------------------------------
+template <bool MISSING>
+__global__ __launch_bounds__(kBlock) void hudson_from_counts_kernel(const SweepArgs A, const uint32_t* __restrict__ called1, const uint32_t* __restrict__ alt1,
+                                                                    const uint32_t* __restrict__ called2, const uint32_t* __restrict__ alt2) {
+  constexpr int MODE = kModeSummary | kModeHudson;
+  LaneTotals<2, MODE> T;
+  T.clear();
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  const size_t rounds = (A.row_count + stride - 1) / stride;
+  for (size_t r = 0; r < rounds; ++r) {
+    const size_t site = r * stride + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool row_ok = site < A.row_count;
+    SiteTally<2> mine;
+    mine.n[0] = row_ok ? called1[site] : 0; mine.alt[0] = row_ok ? alt1[site] : 0;
+    mine.n[1] = row_ok ? called2[site] : 0; mine.alt[1] = row_ok ? alt2[site] : 0;
+    mine.n_all = mine.n[0] + mine.n[1];
+    double hud_dot = 0.0;
+    finish_biallelic_site<2, MODE>(mine, hud_dot);
+    WcSite<2> wc;
+    site_epilogue<2, MODE, MISSING, false>(A, site, row_ok, mine, hud_dot, wc, T);
+  }
+  reduce_block_totals<2, MODE>(A, T);
+}
+
 // the chunks of one slot added by one wave: lane l takes chunks l, l + 64, ... in ascending order, then a fixed xor tree over the lanes
 // (the totals route has thousands of chunks per slot; wc_slot_finalize_kernel's one thread per slot would walk them one by one)
 __global__ __launch_bounds__(64) void wc_slot_finalize_wave_kernel(size_t chunks, const double* __restrict__ part_a, const double* __restrict__ part_b,

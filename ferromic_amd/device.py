@@ -36,6 +36,14 @@ class DeviceBuffer:
             _abi.check(_abi.load().fmh_copy_to_host(self.device, _ptr(out), self.ptr, out.nbytes, None))
         return out
 
+    @classmethod
+    def from_numpy(cls, device: int, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(device, max(a.nbytes, 1))
+        if a.nbytes:
+            _abi.check(_abi.load().fmh_copy_to_device(device, buf.ptr, _ptr(a), a.nbytes, None))
+        return buf
+
     def free(self):
         if getattr(self, "ptr", None):
             _abi.load().fmh_device_free(self.device, self.ptr)
@@ -245,6 +253,28 @@ def hudson_sweep(m: DeviceMatrix, g: Groups, formula: int, row_begin: int = 0, r
     totals = _abi.HudsonTotals()
     _abi.check(_abi.load().fmh_hudson_sweep(m._h, g._h, row_begin, rows, formula,
                                             C.byref(sites) if sites is not None else None, C.byref(totals), None))
+    out_sites = None
+    if want_sites:
+        out_sites = {n: bufs[n].to_numpy(np.float64, rows) for n in ("fst", "dxy", "pi1", "pi2", "num", "den")}
+        out_sites["alt"] = bufs["alt"].to_numpy(np.uint32, 2 * rows).reshape(2, rows)
+        out_sites["called"] = bufs["called"].to_numpy(np.uint32, 2 * rows).reshape(2, rows)
+    return HudsonResult(hudson_totals_dict(totals), [_pop_totals(totals.pop[0]), _pop_totals(totals.pop[1])], out_sites)
+
+
+def hudson_from_counts(device: int, called1: "DeviceBuffer", alt1: "DeviceBuffer", capacity1: int, called2: "DeviceBuffer", alt2: "DeviceBuffer",
+                       capacity2: int, rows: int, formula: int, any_missing: bool = False, want_sites: bool = True) -> HudsonResult:
+    """fmh_hudson_from_counts: the Hudson pair of two populations from their per-site count tables (u32 device arrays of `rows` entries)."""
+    bufs = {}
+    sites = None
+    if want_sites:
+        for name in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+            bufs[name] = DeviceBuffer(device, 8 * rows)
+        bufs["alt"] = DeviceBuffer(device, 4 * 2 * rows)
+        bufs["called"] = DeviceBuffer(device, 4 * 2 * rows)
+        sites = _abi.HudsonSites(*(bufs[n].ptr for n in ("fst", "dxy", "pi1", "pi2", "num", "den", "alt", "called")))
+    totals = _abi.HudsonTotals()
+    _abi.check(_abi.load().fmh_hudson_from_counts(device, called1.ptr, alt1.ptr, capacity1, called2.ptr, alt2.ptr, capacity2, rows, formula,
+                                                  1 if any_missing else 0, C.byref(sites) if sites is not None else None, C.byref(totals), None))
     out_sites = None
     if want_sites:
         out_sites = {n: bufs[n].to_numpy(np.float64, rows) for n in ("fst", "dxy", "pi1", "pi2", "num", "den")}

@@ -230,6 +230,18 @@ int fmh_hudson_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row_begin,
                      int formula, const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_totals,
                      void* stream);
 
+/*
+ * The same Hudson totals and per-site records from the two populations' per-site COUNT TABLES (d_called / d_alt as fmh_population_summaries
+ * writes them, biallelic) instead of a matrix: aggregate_hudson_components_from_summaries (stats.rs:1554-1623) takes two
+ * DensePopulationSummary objects that need not come from one matrix - ferromic.hudson_fst / hudson_dxy of two Population.from_numpy
+ * objects.  capacity1/2 = haplotype_capacity of the two populations (copied into h_totals->pop[]); any_missing != 0 when either matrix
+ * has missing calls (selects the kernel twin the fused sweep would have taken; it matters to FMH_FORMULA_DENSE only).  Same per-site code as
+ * fmh_hudson_sweep after the counting: the per-site values are its bits, the regional sums differ in the order of their additions.
+ */
+int fmh_hudson_from_counts(int device, const uint32_t* d_called1, const uint32_t* d_alt1, uint64_t capacity1, const uint32_t* d_called2,
+                           const uint32_t* d_alt2, uint64_t capacity2, size_t row_count, int formula, int any_missing,
+                           const fmh_hudson_sites* sites_or_null, fmh_hudson_totals* h_totals, void* stream);
+
 /* ---- per-site diversity (population 0 of `g`) ------------------------------------------------- */
 /*
  * Replaces the loop of calculate_per_site_diversity (stats.rs:4693-4750): d_pi / d_theta per site;

@@ -330,6 +330,41 @@ def test_rows_wider_than_lds_for_all_masks(dev):
             k4 += 1
 
 
+@pytest.mark.parametrize("p_missing", [0.0, 0.04])
+@pytest.mark.parametrize("formula", ["FORMULA_SUMMARY", "FORMULA_DENSE", "FORMULA_SPARSE"])
+def test_hudson_pair_from_count_tables(dev, p_missing, formula):
+    """fmh_hudson_from_counts (two populations' per-site count tables instead of a matrix: the reference's aggregate over two
+    DensePopulationSummary objects, stats.rs:1554-1623) against fmh_hudson_sweep on the matrix both tables came from: every per-site
+    record bit for bit, integer totals exactly, f64 totals to the order of their additions.  (Tables of two DIFFERENT matrices: the API
+    fuzz, test_two_separately_built_numpy_populations, against the oracle.)"""
+    rng = np.random.default_rng(31 + int(p_missing * 100))
+    S, N = 5000, 70
+    f = getattr(dev, formula)
+    m = H.random_dense_matrix(rng, S, N, 2, 1, p_missing)
+    dm = upload(dev, m)
+    lists = [H.haps_for_samples(range(0, 30)), H.haps_for_samples(range(25, N))]
+    g = dev.Groups.from_haplotype_lists(dm, lists)
+    ref = dev.hudson_sweep(dm, g, f)
+    summ = dev.population_summaries(dm, g, dev.FORMULA_SUMMARY)
+    caps = [2 * 30, 2 * (N - 25)]
+    tabs = [dev.DeviceBuffer.from_numpy(dm.device, x) for x in (summ.called[0], summ.alt[0], summ.called[1], summ.alt[1])]
+    for (r0, rows) in ((0, S), (0, 1), (0, 777)):
+        want = ref if rows == S else dev.hudson_sweep(dm, g, f, 0, rows)
+        got = dev.hudson_from_counts(dm.device, tabs[0], tabs[1], caps[0], tabs[2], tabs[3], caps[1], rows, f, any_missing=p_missing > 0)
+        for k in ("fst", "dxy", "pi1", "pi2", "num", "den"):
+            H.assert_bits_equal(got.sites[k], want.sites[k], k)
+        assert np.array_equal(got.sites["called"], want.sites["called"]) and np.array_equal(got.sites["alt"], want.sites["alt"])
+        for k, v in want.totals.items():
+            if isinstance(v, int): assert got.totals[k] == v, k
+            else: assert H.rel_close(got.totals[k], v, 1e-11), k
+        for p in range(2):
+            for k, v in want.pop[p].items():
+                if isinstance(v, int): assert got.pop[p][k] == v, (p, k)
+                else: assert H.rel_close(got.pop[p][k], v, 1e-11), (p, k)
+    empty = dev.hudson_from_counts(dm.device, tabs[0], tabs[1], caps[0], tabs[2], tabs[3], caps[1], 0, f, want_sites=False)
+    assert empty.totals["sites_with_components"] == 0 and empty.pop[0]["haplotype_capacity"] == caps[0]
+
+
 @pytest.mark.parametrize("G,max_allele,p_missing,S", [(9, 1, 0.0, 3000), (12, 1, 0.02, 5000), (26, 1, 0.0, 40_000), (26, 3, 0.01, 2500), (40, 6, 0.0, 700), (70, 1, 0.3, 900)])
 def test_many_groups_totals_without_tracks(dev, G, max_allele, p_missing, S):
     """fmh_wc_sweep_many with no per-site track asked for (run_vcf's CSV populations): the regional sums come straight from the count
