@@ -1093,14 +1093,14 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   return FMH_OK;
 }
 
-static void fill_pop_totals(const fmh_groups* g, const SweepResult& r, int p, fmh_pop_totals* t) {
-  t->haplotype_capacity = g->sizes[p];
+static void fill_pop_totals(const uint64_t* capacity, const SweepResult& r, int p, fmh_pop_totals* t) {
+  t->haplotype_capacity = capacity[p];
   t->segregating_sites = r.u64[kOffPopSeg + p];
   t->uncallable_sites = r.u64[kOffPopUnc + p];
   t->pi_sum = r.f64[kOffPopF64 + p];
 }
 
-static void fill_hudson_totals(const fmh_groups* g, const SweepResult& r, fmh_hudson_totals* t) {
+static void fill_hudson_totals(const uint64_t* capacity, const SweepResult& r, fmh_hudson_totals* t) {
   memset(t, 0, sizeof *t);
   t->numerator_sum = r.f64[kOffHudF64 + 0];
   t->denominator_sum = r.f64[kOffHudF64 + 1];
@@ -1113,8 +1113,8 @@ static void fill_hudson_totals(const fmh_groups* g, const SweepResult& r, fmh_hu
   t->dxy_uncallable_sites = r.u64[kOffHudU64 + 0];
   t->sites_with_components = r.u64[kOffHudU64 + 1];
   t->site_dxy_skipped = r.u64[kOffHudU64 + 2];
-  fill_pop_totals(g, r, 0, &t->pop[0]);
-  fill_pop_totals(g, r, 1, &t->pop[1]);
+  fill_pop_totals(capacity, r, 0, &t->pop[0]);
+  fill_pop_totals(capacity, r, 1, &t->pop[1]);
 }
 
 static int check_formula(int formula) {
@@ -1150,7 +1150,7 @@ extern "C" int fmh_population_summaries(const fmh_matrix* m, const fmh_groups* g
   }
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeSummary, a, stream, &r));
-  if (h_totals) for (int p = 0; p < g->n_groups; ++p) fill_pop_totals(g, r, p, &h_totals[p]);
+  if (h_totals) for (int p = 0; p < g->n_groups; ++p) fill_pop_totals(g->sizes, r, p, &h_totals[p]);
   return FMH_OK;
 }
 
@@ -1168,7 +1168,7 @@ extern "C" int fmh_hudson_sweep(const fmh_matrix* m, const fmh_groups* g, size_t
   }
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeSummary | kModeHudson, a, stream, &r));
-  if (h_totals) fill_hudson_totals(g, r, h_totals);
+  if (h_totals) fill_hudson_totals(g->sizes, r, h_totals);
   return FMH_OK;
 }
 
@@ -1212,9 +1212,8 @@ extern "C" int fmh_hudson_from_counts(int device, const uint32_t* d_called1, con
     SweepResult r;
     memcpy(r.f64, l->h_f64, sizeof r.f64);
     memcpy(r.u64, l->h_u64, sizeof r.u64);
-    fmh_groups caps;
-    caps.sizes[0] = capacity1; caps.sizes[1] = capacity2;
-    fill_hudson_totals(&caps, r, h_totals);
+    const uint64_t caps[2] = {capacity1, capacity2};
+    fill_hudson_totals(caps, r, h_totals);
   }
   return FMH_OK;
 }
@@ -1233,7 +1232,7 @@ extern "C" int fmh_diversity_sites(const fmh_matrix* m, const fmh_groups* g, siz
   a.site_distinct = d_distinct;
   SweepResult r;
   FMH_TRY(run_sweep(m, g, kModeSummary | kModeDiversity, a, stream, &r));
-  if (h_totals) fill_pop_totals(g, r, 0, h_totals);
+  if (h_totals) fill_pop_totals(g->sizes, r, 0, h_totals);
   return FMH_OK;
 }
 
@@ -1269,7 +1268,7 @@ extern "C" int fmh_pair_region_sweep(const fmh_matrix* m, const fmh_groups* g, s
   FMH_TRY(pair_region_args(g, row_begin, row_count, summary_formula, hudson_formula, diversity_or_null, sites_or_null, a, &mode));
   SweepResult r;
   FMH_TRY(run_sweep(m, g, mode, a, stream, &r));
-  if (h_totals) fill_hudson_totals(g, r, h_totals);
+  if (h_totals) fill_hudson_totals(g->sizes, r, h_totals);
   return FMH_OK;
 }
 

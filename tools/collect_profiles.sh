@@ -97,6 +97,7 @@ step "upload, API, run_vcf"
 python3 $R/tools/measure_h2d.py 2>/dev/null | grep '^{' > $O/h2d.json
 python3 $R/tools/measure_api_c2.py 2>/dev/null | grep '^{' > $O/api_c2.json
 python3 $R/tools/measure_api_pybench.py 2>/dev/null | grep '^{' > $O/api_pybench.jsonl
+for c in "1000000 250" "65536 128"; do python3 $R/tools/measure_api_two_matrices.py $c 2>/dev/null | grep '^{' >> $O/api_two_matrices.jsonl; done
 python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 2>/dev/null | tail -1 > $O/run_vcf_scale_200k_x_2500.json
 python3 $R/tools/run_vcf_many_regions.py 2>/dev/null | tail -1 > $O/run_vcf_500_regions.json
 for c in gzip bgzf; do python3 $R/tools/run_vcf_scale.py --sites 50000 --samples 2500 --compress $c 2>/dev/null | tail -1 >> $O/run_vcf_compressed_inputs.jsonl; done

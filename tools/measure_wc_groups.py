@@ -17,7 +17,7 @@ from ferromic_amd import _abi, device  # noqa: E402
 
 def main():
     lib = _abi.load()
-    S, H = 2_000_000, 2_500
+    S, H = int(os.environ.get("MEASURE_SITES", "2000000")), int(os.environ.get("MEASURE_HAPLOTYPES", "2500"))
     N = H // 2
     for G in (int(x) for x in (sys.argv[1:] or ["2", "4", "5", "8", "12", "26"])):
         pop_of_sample = np.minimum(np.arange(N) * G // N, G - 1).astype(np.uint8)
