@@ -701,30 +701,29 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
   g->mask_pitch = round_up(m->pitch, 2048);
   g->columns = m->columns;
   g->host_mask.assign(h_mask, h_mask + (size_t)n_groups * m->columns);
-  std::vector<uint8_t> staged((size_t)g->padded * g->mask_pitch, 0);
+  // byte masks and, behind them, the same masks as one bit per column: ONE device block and ONE copy (every statistic of the Python module
+  // makes its groups per call; two blocking copies were 24 us of a 50-us call, tools/measure_call_overheads.py)
+  const size_t bytes_len = (size_t)g->padded * g->mask_pitch, bits_len = (size_t)g->padded * (g->mask_pitch / 16) * 2;
+  std::vector<uint8_t> staged(bytes_len + bits_len, 0);
+  uint16_t* bits = reinterpret_cast<uint16_t*>(staged.data() + bytes_len);  // bytes_len is a multiple of 2048
   for (int p = 0; p < n_groups; ++p) {
     uint64_t cnt = 0;
     for (uint32_t h = 0; h < m->columns; ++h) {
       const uint8_t v = h_mask[(size_t)p * m->columns + h] ? 1 : 0;
       staged[(size_t)p * g->mask_pitch + h] = v;
+      if (v) bits[(size_t)p * (g->mask_pitch / 16) + (h >> 4)] |= (uint16_t)(1u << (h & 15));
       cnt += v;
     }
     g->sizes[p] = cnt;
   }
-  std::vector<uint16_t> bits((size_t)g->padded * (g->mask_pitch / 16), 0);
-  for (int p = 0; p < n_groups; ++p)
-    for (uint32_t h = 0; h < m->columns; ++h)
-      if (staged[(size_t)p * g->mask_pitch + h]) bits[(size_t)p * (g->mask_pitch / 16) + (h >> 4)] |= (uint16_t)(1u << (h & 15));
   hipError_t e = pool_malloc(g->device, (void**)&g->masks, staged.size());
   if (e == hipSuccess) e = hipMemcpy(g->masks, staged.data(), staged.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = pool_malloc(g->device, (void**)&g->mask_bits, bits.size() * 2);
-  if (e == hipSuccess) e = hipMemcpy(g->mask_bits, bits.data(), bits.size() * 2, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     pool_free(g->device, g->masks);
-    pool_free(g->device, g->mask_bits);
     delete g;
     return fail(FMH_ERR_HIP, "group mask upload failed: %s", hipGetErrorString(e));
   }
+  g->mask_bits = reinterpret_cast<uint16_t*>(g->masks + bytes_len);
   *out = g;
   return FMH_OK;
 }
@@ -732,8 +731,7 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
 extern "C" int fmh_groups_destroy(fmh_groups* g) {
   if (!g) return FMH_OK;
   (void)hipSetDevice(g->device);
-  pool_free(g->device, g->masks);
-  pool_free(g->device, g->mask_bits);
+  pool_free(g->device, g->masks);  // (mask_bits lives in the same block)
   delete g;
   return FMH_OK;
 }
@@ -1076,12 +1074,13 @@ static int run_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, SweepAr
   }
   memset(res, 0, sizeof *res);
   const LaunchCtx ctx{w->cus, w->max_grid, l->ev0, l->ev1, timing};
-  const SweepBuffers bufs{l->part_f64, l->part_u64, l->out_f64, l->out_u64};
+  // finalize_kernel writes the 64 + 64 totals straight into the lease's PINNED host vectors (device-visible): a blocking sweep is then two
+  // launches and one stream synchronisation.  (Two hipMemcpyAsync of 512 B behind the kernels cost more than the kernels on a small cohort:
+  // a lone 512-byte copy_to_host is 22 us on the GPU box, tools/measure_call_overheads.py.)
+  const SweepBuffers bufs{l->part_f64, l->part_u64, l->h_f64, l->h_u64};
   bool launched = false;
   FMH_TRY(enqueue_sweep(m, g, mode, a, st, ctx, bufs, harmonic, &launched));
   if (!launched) return FMH_OK;
-  HIP_TRY(hipMemcpyAsync(l->h_f64, l->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(l->h_u64, l->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   memcpy(res->f64, l->h_f64, sizeof res->f64);
   memcpy(res->u64, l->h_u64, sizeof res->u64);
@@ -1203,10 +1202,8 @@ extern "C" int fmh_hudson_from_counts(int device, const uint32_t* d_called1, con
   if (any_missing) hipLaunchKernelGGL(hudson_from_counts_kernel<true>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, d_called1, d_alt1, d_called2, d_alt2);
   else hipLaunchKernelGGL(hudson_from_counts_kernel<false>, dim3((unsigned)grid), dim3(kBlock), 0, st, a, d_called1, d_alt1, d_called2, d_alt2);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, l->part_f64, l->part_u64, grid, l->out_f64, l->out_u64);
+  hipLaunchKernelGGL(finalize_kernel, dim3(kMaxF64 + kMaxU64), dim3(256), 0, st, l->part_f64, l->part_u64, grid, l->h_f64, l->h_u64);  // pinned, as run_sweep
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(l->h_f64, l->out_f64, kMaxF64 * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(l->h_u64, l->out_u64, kMaxU64 * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (h_totals) {
     SweepResult r;

@@ -90,11 +90,15 @@ int current_device() {
   return d;
 }
 
+struct Groups;
 struct DevMatrix {
   fmh_matrix* h = nullptr;
   int device = 0;
   size_t variants = 0, samples = 0, ploidy = 0;
-  ~DevMatrix() { if (h) fmh_matrix_destroy(h); }
+  // the last few group-mask sets swept over this matrix, with their device handles: a Population asks for the same masks at every call, and
+  // making a handle is a device allocation and a blocking copy (15 us of a 45-us hudson_fst on a small cohort).  Callers hold the GIL.
+  mutable vector<std::pair<vector<uint8_t>, shared_ptr<Groups>>> recent_groups;
+  ~DevMatrix();
   size_t columns() const { return samples * ploidy; }
 };
 
@@ -134,6 +138,30 @@ struct Groups {
   Groups(const Groups&) = delete;
   ~Groups() { if (h) fmh_groups_destroy(h); }
 };
+DevMatrix::~DevMatrix() {
+  recent_groups.clear();  // the handles go before the matrix they were made for
+  if (h) fmh_matrix_destroy(h);
+}
+// the device handle of `masks` over `m`: one of the last eight asked for, or a new one
+shared_ptr<Groups> groups_for(const DevMatrix& m, const vector<vector<uint8_t>>& masks) {
+  size_t total = 0;
+  for (auto& k : masks) total += k.size();
+  vector<uint8_t> flat;
+  flat.reserve(total + 1);
+  flat.push_back((uint8_t)masks.size());
+  for (auto& k : masks) flat.insert(flat.end(), k.begin(), k.end());
+  auto& cache = m.recent_groups;
+  for (size_t i = 0; i < cache.size(); ++i) {
+    if (cache[i].first.size() == flat.size() && memcmp(cache[i].first.data(), flat.data(), flat.size()) == 0) {
+      if (i != 0) std::rotate(cache.begin(), cache.begin() + (std::ptrdiff_t)i, cache.begin() + (std::ptrdiff_t)i + 1);  // most recent first
+      return cache[0].second;
+    }
+  }
+  auto g = std::make_shared<Groups>(m, masks);
+  if (cache.size() >= 8) cache.pop_back();
+  cache.insert(cache.begin(), {std::move(flat), g});
+  return g;
+}
 
 struct DevBuf {
   void* p = nullptr;
