@@ -268,6 +268,11 @@ extern "C" int fmh_device_free(int device, void* d_ptr) {
   pool_free(device, d_ptr);
   return FMH_OK;
 }
+// FMH_STREAM_PER_THREAD (include/ferromic_hip.h) is HIP's per-thread stream handle
+[[maybe_unused]] static const bool kStreamPerThreadChecked = [] {
+  if ((void*)hipStreamPerThread != FMH_STREAM_PER_THREAD) { fprintf(stderr, "libferromic_hip: FMH_STREAM_PER_THREAD is not hipStreamPerThread\n"); abort(); }
+  return true;
+}();
 extern "C" int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream) {
   FMH_TRY(use_device(device));
   HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -717,7 +722,10 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
     g->sizes[p] = cnt;
   }
   hipError_t e = pool_malloc(g->device, (void**)&g->masks, staged.size());
-  if (e == hipSuccess) e = hipMemcpy(g->masks, staged.data(), staged.size(), hipMemcpyHostToDevice);
+  // (on the calling thread's own stream: a plain hipMemcpy runs on the legacy default stream, which waits for - and holds up - every blocking
+  // stream of the device, i.e. the sweeps of all other host threads; the block is a fresh allocation)
+  if (e == hipSuccess) e = hipMemcpyAsync(g->masks, staged.data(), staged.size(), hipMemcpyHostToDevice, hipStreamPerThread);
+  if (e == hipSuccess) e = hipStreamSynchronize(hipStreamPerThread);
   if (e != hipSuccess) {
     pool_free(g->device, g->masks);
     delete g;

@@ -1102,10 +1102,14 @@ HapList haplotypes_for_group(uint8_t group, const SampleMap& filter, const std::
 }
 
 // ---- device side --------------------------------------------------------------------------------------
+struct GroupsHandle;
 struct DeviceMatrix {
   fmh_matrix* h = nullptr;
   size_t variants = 0, samples = 0, ploidy = 0;
-  ~DeviceMatrix() { if (h) fmh_matrix_destroy(h); }
+  // the group-mask sets already uploaded for this matrix (a region sweeps haplotype groups 0 / 1 twice: the fused pair sweep and W&C).  One
+  // worker owns a region's matrices, so no lock.
+  mutable vector<std::pair<vector<uint8_t>, std::shared_ptr<GroupsHandle>>> recent_groups;
+  ~DeviceMatrix();
   size_t columns() const { return samples * ploidy; }
 };
 
@@ -1116,7 +1120,8 @@ struct DevBuf {
   ~DevBuf() { if (p) fmh_device_free(device, p); }
   template <class T> vector<T> fetch(size_t n) const {
     vector<T> out(n);
-    if (n) fmh_check(fmh_copy_to_host(device, out.data(), p, n * sizeof(T), nullptr), "copy to host");
+    // (the thread's own stream: the sweep that wrote the block has completed, and the legacy default stream would wait for every other region worker)
+    if (n) fmh_check(fmh_copy_to_host(device, out.data(), p, n * sizeof(T), FMH_STREAM_PER_THREAD), "copy to host");
     return out;
   }
 };
@@ -1375,14 +1380,29 @@ size_t membership_total(const HapList& haps, size_t sample_count) {
   return seen.size();
 }
 
+struct GroupsHandle {
+  fmh_groups* h = nullptr;
+  ~GroupsHandle() { if (h) fmh_groups_destroy(h); }
+};
+DeviceMatrix::~DeviceMatrix() {
+  recent_groups.clear();  // the group handles go before the matrix they were made for
+  if (h) fmh_matrix_destroy(h);
+}
+// the device handle of `masks` over `dm`: made once per matrix and mask set (every handle is a device allocation and a blocking copy)
 struct Groups {
   fmh_groups* h = nullptr;
+  std::shared_ptr<GroupsHandle> keep;
   Groups(const DeviceMatrix& dm, const vector<vector<uint8_t>>& masks) {
     vector<uint8_t> flat;
+    flat.push_back((uint8_t)masks.size());
     for (auto& m : masks) flat.insert(flat.end(), m.begin(), m.end());
-    fmh_check(fmh_groups_create(dm.h, flat.data(), (int)masks.size(), &h), "groups");
+    for (auto& e : dm.recent_groups)
+      if (e.first == flat) { keep = e.second; h = keep->h; return; }
+    keep = std::make_shared<GroupsHandle>();
+    fmh_check(fmh_groups_create(dm.h, flat.data() + 1, (int)masks.size(), &keep->h), "groups");
+    h = keep->h;
+    if (dm.recent_groups.size() < 8) dm.recent_groups.emplace_back(std::move(flat), keep);
   }
-  ~Groups() { if (h) fmh_groups_destroy(h); }
 };
 
 // ---- sweeps over a (possibly sharded) region matrix -------------------------------------------------------------
@@ -1414,17 +1434,26 @@ fmh_wc_totals sharded_wc(const RegionMatrix& rm, const vector<vector<uint8_t>>& 
   on_slabs(rm, [&](const Slab& sl, size_t k) {
     const size_t rows = sl.dm->variants;
     Groups grp(*sl.dm, masks);
-    std::unique_ptr<DevBuf> da, db, ds;
-    if (a && rows) { da.reset(new DevBuf(sl.device, 8 * nw * rows)); db.reset(new DevBuf(sl.device, 8 * nw * rows)); ds.reset(new DevBuf(sl.device, nw * rows)); }
-    if (sl.comm) fmh_check(fmh_wc_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, da ? (double*)da->p : nullptr, db ? (double*)db->p : nullptr, ds ? (uint8_t*)ds->p : nullptr, nullptr, &per[k], nullptr), "sharded wc sweep");
-    else fmh_check(fmh_wc_sweep(sl.dm->h, grp.h, 0, rows, da ? (double*)da->p : nullptr, db ? (double*)db->p : nullptr, ds ? (uint8_t*)ds->p : nullptr, nullptr, &per[k], nullptr), "wc sweep");
-    if (da) {
-      vector<double> ha = da->fetch<double>(nw * rows), hb = db->fetch<double>(nw * rows);
-      vector<uint8_t> hs = ds->fetch<uint8_t>(nw * rows);
+    // the three track families in ONE device block, fetched with ONE copy: a small region is latency, and every blocking copy is ~20 us
+    // (a [nw][rows] f64 | b [nw][rows] f64 | state [nw][rows] u8)
+    std::unique_ptr<DevBuf> blk;
+    double *da = nullptr, *db = nullptr;
+    uint8_t* ds = nullptr;
+    if (a && rows) {
+      blk.reset(new DevBuf(sl.device, 17 * nw * rows));
+      da = (double*)blk->p; db = da + nw * rows; ds = (uint8_t*)(db + nw * rows);
+    }
+    if (sl.comm) fmh_check(fmh_wc_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, da, db, ds, nullptr, &per[k], nullptr), "sharded wc sweep");
+    else fmh_check(fmh_wc_sweep(sl.dm->h, grp.h, 0, rows, da, db, ds, nullptr, &per[k], nullptr), "wc sweep");
+    if (blk) {
+      const vector<uint8_t> host = blk->fetch<uint8_t>(17 * nw * rows);
+      const double* ha = reinterpret_cast<const double*>(host.data());
+      const double* hb = ha + nw * rows;
+      const uint8_t* hs = host.data() + 16 * nw * rows;
       for (size_t w = 0; w < nw; ++w) {
-        std::copy(ha.begin() + (ptrdiff_t)(w * rows), ha.begin() + (ptrdiff_t)((w + 1) * rows), a->begin() + (ptrdiff_t)(w * S + sl.row0));
-        std::copy(hb.begin() + (ptrdiff_t)(w * rows), hb.begin() + (ptrdiff_t)((w + 1) * rows), b->begin() + (ptrdiff_t)(w * S + sl.row0));
-        std::copy(hs.begin() + (ptrdiff_t)(w * rows), hs.begin() + (ptrdiff_t)((w + 1) * rows), st->begin() + (ptrdiff_t)(w * S + sl.row0));
+        std::copy(ha + w * rows, ha + (w + 1) * rows, a->begin() + (ptrdiff_t)(w * S + sl.row0));
+        std::copy(hb + w * rows, hb + (w + 1) * rows, b->begin() + (ptrdiff_t)(w * S + sl.row0));
+        std::copy(hs + w * rows, hs + (w + 1) * rows, st->begin() + (ptrdiff_t)(w * S + sl.row0));
       }
     }
   });
@@ -1467,16 +1496,16 @@ fmh_hudson_totals sharded_hudson(const RegionMatrix& rm, const vector<uint8_t>& 
       else fmh_check(fmh_hudson_sweep(sl.dm->h, grp.h, 0, rows, formula, nullptr, &per[k], nullptr), "hudson sweep");
       return;
     }
-    DevBuf dfst(sl.device, 8 * std::max<size_t>(rows, 1)), dnum(sl.device, 8 * std::max<size_t>(rows, 1)), dden(sl.device, 8 * std::max<size_t>(rows, 1));
+    DevBuf blk(sl.device, 8 * 3 * std::max<size_t>(rows, 1));  // fst | num | den: one block, one copy back
     fmh_hudson_sites sites{};
-    sites.d_fst = (double*)dfst.p; sites.d_num = (double*)dnum.p; sites.d_den = (double*)dden.p;
+    sites.d_fst = (double*)blk.p; sites.d_num = sites.d_fst + rows; sites.d_den = sites.d_num + rows;
     if (sl.comm) fmh_check(fmh_hudson_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, formula, &sites, &per[k], nullptr), "sharded hudson sweep");
     else fmh_check(fmh_hudson_sweep(sl.dm->h, grp.h, 0, rows, formula, &sites, &per[k], nullptr), "hudson sweep");
     if (!rows) return;
-    vector<double> a = dfst.fetch<double>(rows), b = dnum.fetch<double>(rows), c = dden.fetch<double>(rows);
-    std::copy(a.begin(), a.end(), fst.begin() + (ptrdiff_t)sl.row0);
-    std::copy(b.begin(), b.end(), num.begin() + (ptrdiff_t)sl.row0);
-    std::copy(c.begin(), c.end(), den.begin() + (ptrdiff_t)sl.row0);
+    const vector<double> h = blk.fetch<double>(3 * rows);
+    std::copy(h.begin(), h.begin() + (ptrdiff_t)rows, fst.begin() + (ptrdiff_t)sl.row0);
+    std::copy(h.begin() + (ptrdiff_t)rows, h.begin() + (ptrdiff_t)(2 * rows), num.begin() + (ptrdiff_t)sl.row0);
+    std::copy(h.begin() + (ptrdiff_t)(2 * rows), h.end(), den.begin() + (ptrdiff_t)sl.row0);
   });
   return per[0];
 }
@@ -1500,29 +1529,22 @@ PairSweep sharded_pair_region(const RegionMatrix& rm, const vector<uint8_t>& m0,
   on_slabs(rm, [&](const Slab& sl, size_t k) {
     const size_t rows = sl.dm->variants, cap = std::max<size_t>(rows, 1);
     Groups grp(*sl.dm, {m0, m1});
-    DevBuf dpi(sl.device, 8 * 2 * cap), dth(sl.device, 8 * 2 * cap);
-    std::unique_ptr<DevBuf> dfst, dnum, dden;
-    fmh_pair_diversity_sites div{(double*)dpi.p, (double*)dth.p};
+    // every track of the sweep in ONE device block (pi [2][rows] | theta [2][rows] | fst | num | den), fetched with ONE copy: a region of a few
+    // thousand sites is latency, and each blocking copy costs ~20 us (five of them per sweep before)
+    const size_t ntracks = hudson ? 7 : 4;
+    DevBuf blk(sl.device, 8 * ntracks * cap);
+    double* base = (double*)blk.p;
+    fmh_pair_diversity_sites div{base, base + 2 * rows};
     fmh_hudson_sites sites{};
-    if (hudson) {
-      dfst.reset(new DevBuf(sl.device, 8 * cap)); dnum.reset(new DevBuf(sl.device, 8 * cap)); dden.reset(new DevBuf(sl.device, 8 * cap));
-      sites.d_fst = (double*)dfst->p; sites.d_num = (double*)dnum->p; sites.d_den = (double*)dden->p;
-    }
+    if (hudson) { sites.d_fst = base + 4 * rows; sites.d_num = base + 5 * rows; sites.d_den = base + 6 * rows; }
     const int hf = hudson ? FMH_FORMULA_SPARSE : -1;
     if (sl.comm) fmh_check(fmh_pair_region_sweep_sharded(sl.comm, sl.dm->h, grp.h, 0, rows, summary_formula, hf, &div, hudson ? &sites : nullptr, &per[k], nullptr), "sharded region sweep");
     else fmh_check(fmh_pair_region_sweep(sl.dm->h, grp.h, 0, rows, summary_formula, hf, &div, hudson ? &sites : nullptr, &per[k], nullptr), "region sweep");
     if (!rows) return;
-    const vector<double> a = dpi.fetch<double>(2 * rows), b = dth.fetch<double>(2 * rows);
-    for (int g = 0; g < 2; ++g) {
-      std::copy(a.begin() + (ptrdiff_t)(g * rows), a.begin() + (ptrdiff_t)((g + 1) * rows), out.pi[g].begin() + (ptrdiff_t)sl.row0);
-      std::copy(b.begin() + (ptrdiff_t)(g * rows), b.begin() + (ptrdiff_t)((g + 1) * rows), out.theta[g].begin() + (ptrdiff_t)sl.row0);
-    }
-    if (hudson) {
-      const vector<double> f = dfst->fetch<double>(rows), n = dnum->fetch<double>(rows), d = dden->fetch<double>(rows);
-      std::copy(f.begin(), f.end(), out.fst.begin() + (ptrdiff_t)sl.row0);
-      std::copy(n.begin(), n.end(), out.num.begin() + (ptrdiff_t)sl.row0);
-      std::copy(d.begin(), d.end(), out.den.begin() + (ptrdiff_t)sl.row0);
-    }
+    const vector<double> h = blk.fetch<double>(ntracks * rows);
+    auto slice = [&](size_t track, vector<double>& dst) { std::copy(h.begin() + (ptrdiff_t)(track * rows), h.begin() + (ptrdiff_t)((track + 1) * rows), dst.begin() + (ptrdiff_t)sl.row0); };
+    for (int g = 0; g < 2; ++g) { slice((size_t)g, out.pi[g]); slice((size_t)(2 + g), out.theta[g]); }
+    if (hudson) { slice(4, out.fst); slice(5, out.num); slice(6, out.den); }
   });
   out.tot = per[0];
   return out;

@@ -131,12 +131,16 @@ int fmhi::upload_planes_from_planes(fmh_matrix* m, const uint8_t* const h_planes
   FMH_TRY(use_device(m->device));
   uint8_t* d_planes[4] = {m->p0, m->p1, m->p2, m->pc};
   const size_t row_bytes = ((size_t)m->columns + 7) / 8;
+  // On the calling thread's own stream, not the legacy default stream: that one is ordered against every blocking stream of the device, so
+  // each region worker of run_vcf waited here for the sweeps of all the others (and held them up meanwhile).  The planes are a fresh
+  // allocation: nothing can be pending on them.
+  hipStream_t st = hipStreamPerThread;
   for (int p = 0; p < 4; ++p) {
     if (!d_planes[p]) continue;
-    if (h_pitch != m->plane_pitch || row_bytes != m->plane_pitch) HIP_TRY(hipMemsetAsync(d_planes[p], 0, m->variants * m->plane_pitch, nullptr));  // padding bytes stay zero
-    HIP_TRY(hipMemcpy2DAsync(d_planes[p], m->plane_pitch, h_planes[p], h_pitch, row_bytes, m->variants, hipMemcpyHostToDevice, nullptr));
+    if (h_pitch != m->plane_pitch || row_bytes != m->plane_pitch) HIP_TRY(hipMemsetAsync(d_planes[p], 0, m->variants * m->plane_pitch, st));  // padding bytes stay zero
+    HIP_TRY(hipMemcpy2DAsync(d_planes[p], m->plane_pitch, h_planes[p], h_pitch, row_bytes, m->variants, hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipStreamSynchronize(st));
   return FMH_OK;
 }
 

@@ -84,6 +84,12 @@ int fmh_device_alloc(int device, size_t bytes, void** d_out);
 /* Blocks are recycled through a pool without stream ordering: the caller's outstanding stream work on the block must be
  * complete (every fmh_* call that fills host totals has synchronised its stream; fmh_device_zero has not). */
 int fmh_device_free(int device, void* d_ptr);
+/* `stream` arguments throughout this header are hipStream_t handles passed as void*.  NULL is HIP's legacy default stream: ordered against
+ * every blocking stream of the device - which is what a host that also enqueues work of its own on the default stream wants, and a
+ * device-wide serialisation point when several host threads use one GPU.  FMH_STREAM_PER_THREAD is the calling thread's own stream
+ * (hipStreamPerThread): not ordered against the default stream or other threads.  run_vcf's region workers pass it to the copies of
+ * results that a synchronous fmh_* call has already completed. */
+#define FMH_STREAM_PER_THREAD ((void*)2)
 int fmh_copy_to_host(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
 int fmh_copy_to_device(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
 /* zero-fills device memory, stream-ordered (no synchronisation): accumulators such as fmh_pairwise_differences' outputs */

@@ -37,6 +37,8 @@ def main():
         cmd += ["--workers_per_device", os.environ["RUN_VCF_WORKERS"]]
     if os.environ.get("RUN_VCF_DEVICES"):
         cmd += ["--devices", os.environ["RUN_VCF_DEVICES"]]
+    if os.environ.get("RUN_VCF_PREFIX"):  # e.g. "rocprofv3 --hip-trace --stats --output-format csv -d DIR -o t --" (the binary itself follows the --)
+        cmd = os.environ["RUN_VCF_PREFIX"].split() + cmd
     t0 = time.perf_counter()
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_TIMING="1", FERROMIC_PROGRESS="0"))
     wall = time.perf_counter() - t0
