@@ -233,20 +233,61 @@ bool position_in_regions(int64_t pos, const vector<Interval>& r) {  // process.r
 int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }  // release-build i64 wrap
 
 // ---- number formatting: Rust `{:.6}` ---------------------------------------------------------------
-string fmt6(double x) {
+string fmt6_printf(double x) {
   if (std::isnan(x)) return "NaN";
   if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
   char buf[64];
   snprintf(buf, sizeof buf, "%.6f", x);
   return buf;
 }
+// The same text without printf: a region's tracks are tens of thousands of these (a dense 15-kb region: 65 000, 13 ms of snprintf).
+// |x| = m * 2^e exactly (m < 2^53), so |x| * 10^6 = (m * 10^6) / 2^-e is a 73-bit integer over a power of two: quotient and remainder are
+// exact, the quotient is rounded half to even on the remainder - the decimal expansion of the binary value, correctly rounded, which is
+// what both printf's %.6f and Rust's {:.6} print.  Values of 10^15 and beyond, NaN and infinities take the printf path.
+void fmt6_append(string& out, double x) {
+  if (!(std::fabs(x) < 1e15)) { out += fmt6_printf(x); return; }  // also NaN
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  const bool neg = (bits >> 63) != 0;
+  const int be = (int)((bits >> 52) & 0x7FF);
+  uint64_t m = bits & ((1ull << 52) - 1);
+  int e;  // |x| = m * 2^e
+  if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }
+  unsigned __int128 q;
+  if (e >= 0) {
+    q = ((unsigned __int128)m << e) * 1000000u;  // |x| < 10^15 < 2^50: m << e < 2^50, the product < 2^70
+  } else {
+    const unsigned __int128 prod = (unsigned __int128)m * 1000000u;  // < 2^73
+    const int s = -e;
+    if (s > 80) q = 0;  // |x| * 10^6 < 2^73 / 2^81: far below one half
+    else {
+      q = prod >> s;
+      const unsigned __int128 rem = prod & ((((unsigned __int128)1) << s) - 1), half = ((unsigned __int128)1) << (s - 1);
+      if (rem > half || (rem == half && (q & 1))) ++q;
+    }
+  }
+  const uint64_t ip = (uint64_t)(q / 1000000u), fp = (uint64_t)(q % 1000000u);
+  char buf[32];
+  int n = 31;
+  buf[n] = 0;
+  uint64_t f = fp;
+  for (int k = 0; k < 6; ++k) { buf[--n] = (char)('0' + f % 10); f /= 10; }
+  buf[--n] = '.';
+  uint64_t i = ip;
+  do { buf[--n] = (char)('0' + i % 10); i /= 10; } while (i);
+  if (neg) buf[--n] = '-';
+  out.append(buf + n, (size_t)(31 - n));
+}
+string fmt6(double x) { string o; fmt6_append(o, x); return o; }
 string fmt_opt(const std::optional<double>& v) { return (!v || std::isnan(*v)) ? "NA" : fmt6(*v); }  // process.rs:3702-3713
-string falsta_div_value(double v) { return std::isnan(v) ? "NA" : (v == 0.0 ? "0" : fmt6(v)); }       // process.rs:3786-3792
-string falsta_fst_value(double v) {                                                                     // process.rs:3842-3856
-  if (std::isnan(v)) return "NA";
-  if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
-  if (v == 0.0) return "0";
-  return fmt6(v);
+void falsta_div_value(string& out, double v) {  // process.rs:3786-3792
+  if (std::isnan(v)) out += "NA"; else if (v == 0.0) out += '0'; else fmt6_append(out, v);
+}
+void falsta_fst_value(string& out, double v) {  // process.rs:3842-3856
+  if (std::isnan(v)) out += "NA";
+  else if (std::isinf(v)) out += v > 0 ? "Infinity" : "-Infinity";
+  else if (v == 0.0) out += '0';
+  else fmt6_append(out, v);
 }
 
 // ---- data model (process.rs:397-536) --------------------------------------------------------------
@@ -2017,8 +2058,11 @@ vector<vector<string>> compress_tracks(const vector<vector<TrackFn>>& files, siz
       if (!text.empty()) members[i] = gzip_member(text);
     }
   };
-  // inline when the tracks are tiny, or when the region workers alone already occupy the CPUs (each deflating its own region's tracks)
-  if (approx_tokens * jobs.size() < ((size_t)1 << 16) || 2 * g_region_workers.load() >= worker_threads()) work(0u);
+  // inline when the tracks are tiny; else the shared pool, however many region workers there are (500 regions of 2-25 kb, 16 CPUs:
+  // 2 / 4 / 8 / 16 workers 3.9 / 2.0 / 1.1 / 0.73 ms per region inline, 1.1-1.2 / 0.65-0.69 / 0.63-0.68 / 0.74 through the pool,
+  // profiles/r03/run_vcf_tracks_pool_or_inline.jsonl).  FERROMIC_TRACKS_POOL=0 | 1 forces one of them (measurement).
+  static const int force = getenv("FERROMIC_TRACKS_POOL") ? atoi(getenv("FERROMIC_TRACKS_POOL")) : -1;
+  if (force == 0 || (force < 0 && approx_tokens * jobs.size() < ((size_t)1 << 16))) work(0u);
   else parallel_for((unsigned)std::min<size_t>(worker_threads(), jobs.size()), work);
   vector<vector<string>> out(files.size());
   for (size_t i = 0; i < jobs.size(); ++i) if (!members[i].empty()) out[jobs[i].first].push_back(std::move(members[i]));
@@ -2082,7 +2126,7 @@ bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, P
       if (i + 1 < count && pos_at(i + 1) - 1 == p) continue;
       const int64_t k = p - region.first;
       append_default_run(out, dflt, dl0, (size_t)(k - next_k));
-      out += token_at(i);
+      token_at(out, i);
       out.push_back(',');
       next_k = k + 1;
     }
@@ -2104,7 +2148,7 @@ bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, P
   for (int64_t k = 0; k < n; ++k) {
     if (k) out.push_back(',');
     if (slot[(size_t)k] < 0) out.append(dflt, dl);
-    else out += token_at((size_t)slot[(size_t)k]);
+    else token_at(out, (size_t)slot[(size_t)k]);
   }
   out.push_back('\n');
   return any;
@@ -2129,7 +2173,7 @@ vector<TrackFn> diversity_tracks(const RegionOutput& r) {  // append_diversity_f
         string line;
         vector<int32_t> slot;
         const bool any = falsta_line(line, region, n, sel.size(), [&](size_t i) { return std::get<0>(r.diversity[sel[i]]); },
-                                     [&](size_t i) { const auto& d = r.diversity[sel[i]]; return falsta_div_value(sp.is_pi ? std::get<1>(d) : std::get<2>(d)); },
+                                     [&](string& o, size_t i) { const auto& d = r.diversity[sel[i]]; falsta_div_value(o, sp.is_pi ? std::get<1>(d) : std::get<2>(d)); },
                                      "0", slot);
         if (!any) return "";
         return ">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" +
@@ -2146,11 +2190,11 @@ vector<TrackFn> fst_tracks(const RegionOutput& r) {  // append_fst_falsta, proce
   if (n > (int64_t)1 << 31 || r.wc_sites.size() >= (size_t)1 << 31 || r.hudson_sites.size() >= (size_t)1 << 31)
     throw Error("region too long for a dense FALSTA track");
   const string suffix = "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1);
-  auto add = [&](const string& header, size_t count, std::function<std::pair<int64_t, double>(size_t)> getter) {
+  auto add = [&](const string& header, size_t count, auto getter) {  // getter(i) -> (position, value); no std::function on the per-record path
     tracks.push_back([=]() -> string {
       string out = ">" + header + "_" + suffix + "\n";
       vector<int32_t> slot;
-      falsta_line(out, region, n, count, [&](size_t i) { return getter(i).first; }, [&](size_t i) { return falsta_fst_value(getter(i).second); }, "NA", slot);
+      falsta_line(out, region, n, count, [&](size_t i) { return getter(i).first; }, [&](string& o, size_t i) { falsta_fst_value(o, getter(i).second); }, "NA", slot);
       return out;
     });
   };
@@ -2203,19 +2247,55 @@ int print_formats() {
   return 0;
 }
 
-// --bench_tracks (no GPU): formats and deflates the tracks of a made-up 15-kb region with 120 variants, 500 times on one thread;
+// --check_fmt6 N (no GPU): fmt6 against printf's %.6f on N pseudo-random doubles of every magnitude a statistic can take, exact ties
+// (k / 128 and their neighbours one ulp away), values next to a carry (0.9999995, 9.9999995, ...), zeros and subnormals.
+int check_fmt6(size_t n) {
+  uint64_t state = 0x9E3779B97F4A7C15ull;
+  auto next = [&] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
+  size_t bad = 0, checked = 0;
+  auto check = [&](double v) {
+    ++checked;
+    const string a = fmt6(v), b = fmt6_printf(v);
+    if (a != b && bad++ < 10) fprintf(stderr, "fmt6 mismatch: %.17g -> '%s' vs printf '%s'\n", v, a.c_str(), b.c_str());
+  };
+  const double specials[] = {0.0, -0.0, 5e-7, 4.9999999999999998e-7, 5.0000000000000004e-7, 1.5e-6, 2.5e-6, 0.9999995, 0.99999949999999994, 9.9999995,
+                             99.9999995, 1e-300, -1e-300, 4.9e-324, 1e15, 999999999999999.9, 123456789012345.67, 0.1, 0.2, 0.3, 1.0 / 3.0, 2.0 / 3.0,
+                             1e-6, 1e-7, 0.000001499999999, 0.0078125, -0.0078125, 0.0234375, NAN, INFINITY, -INFINITY, 1e16, -1e22};
+  for (double v : specials) { check(v); check(-v); check(std::nextafter(v, 1e300)); check(std::nextafter(v, -1e300)); }
+  for (int k = 0; k < 200000; ++k) {  // exact ties of the sixth decimal and their neighbours
+    const double t = (double)k / 128.0;
+    check(t); check(std::nextafter(t, 1e300)); check(std::nextafter(t, -1e300)); check(-t);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t r = next();
+    double v;
+    switch (r % 5) {
+      case 0: v = (double)(next() >> 11) / 9007199254740992.0; break;                                  // [0, 1)
+      case 1: v = ((double)(next() >> 11) / 9007199254740992.0) * std::pow(10.0, (double)((int)(r >> 8 & 31) - 12)); break;  // 1e-12 .. 1e19
+      case 2: { uint64_t b = next(); b = (b & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(1023 - 40 + (r >> 8) % 80) << 52); memcpy(&v, &b, 8); break; }  // 2^-40 .. 2^40
+      case 3: v = (double)((int64_t)(next() % 2000000000) - 1000000000) / 1000000.0 + ((r >> 8 & 1) ? 5e-7 : 0.0); break;            // near six-decimal grid points / half-way points
+      default: { uint64_t b = next(); memcpy(&v, &b, 8); break; }                                                                        // any bit pattern
+    }
+    check(v);
+  }
+  printf("fmt6: %zu values checked against printf, %zu differ\n", checked, bad);
+  return bad ? 1 : 0;
+}
+
+// --bench_tracks [variants] (no GPU): formats and deflates the tracks of a made-up 15-kb region with 120 variants (or `variants`), 500 times on one thread;
 // what the writers cost per small region.
-int bench_tracks() {
+int bench_tracks(int variants) {  // 120 = a variant every 125 bp; 3 750 = every 4 bp (tools/run_vcf_many_regions.py's cohort)
   RegionOutput r;
   r.seqname = "1";
   r.region_start1 = 1000;
   r.region_end1 = 15999;
+  const int step = std::max(1, 15000 / std::max(variants, 1));
   for (int g = 0; g < 2; ++g)
     for (int f = 0; f < 2; ++f)
-      for (int i = 0; i < 120; ++i) r.diversity.push_back({1000 + 125 * i, 0.289855 + i * 1e-3, 0.267788, g, f != 0});
-  for (int i = 0; i < 120; ++i) {
-    r.wc_sites.push_back({1000 + 125 * i, 0.5, 0.25, 0.5, 0.5, 0.25, 0.5});
-    r.hudson_sites.push_back({1000 + 125 * i, 0.25, 0.125, 0.5});
+      for (int i = 0; i < variants; ++i) r.diversity.push_back({1000 + step * i, 0.289855 + i * 1e-5, 0.267788 + i * 1e-6, g, f != 0});
+  for (int i = 0; i < variants; ++i) {
+    r.wc_sites.push_back({1000 + step * i, 0.5 + i * 1e-6, 0.25, 0.5, 0.5, 0.25 + i * 1e-6, 0.5});
+    r.hudson_sites.push_back({1000 + step * i, 0.25 + i * 1e-6, 0.125, 0.5});
   }
   const auto t0 = std::chrono::steady_clock::now();
   size_t bytes = 0, members = 0;
@@ -2615,10 +2695,11 @@ int run(const Args& args) {
         }
       };
       vector<int> worker_devices;
-      // Per region the host side (packing, track formatting and deflate: ~10 ms for a few thousand sites) outweighs the GPU side (~1 ms), so the
-      // default is as many workers as the process has CPUs, shared between the GPUs, at least 4 and at most 16 per GPU.
+      // Per region the host side (packing, track formatting and deflate: several ms of CPU for a few thousand sites) outweighs the GPU side
+      // (~1 ms of latencies).  The tracks go through the shared pool, so a region worker mostly overlaps one region's GPU latencies with
+      // another's host work: half the process's CPUs, shared between the GPUs, at least 4 and at most 8 per GPU (16 measured 10 % behind 8).
       const int n_gpus = (int)std::max<size_t>(args.devices.size(), 1);
-      const int workers_per_device = args.workers_per_device > 0 ? args.workers_per_device : std::max(4, std::min(16, (int)fmh_host::usable_cpus() / n_gpus));
+      const int workers_per_device = args.workers_per_device > 0 ? args.workers_per_device : std::max(4, std::min(8, (int)fmh_host::usable_cpus() / 2 / n_gpus));
       for (int d : args.devices.empty() ? vector<int>{args.device} : args.devices)
         for (int k = 0; k < workers_per_device; ++k) worker_devices.push_back(d);
       if (worker_devices.size() > todo.size()) worker_devices.resize(std::max<size_t>(todo.size(), 1));
@@ -2685,7 +2766,8 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--fst_populations") a.fst_populations = value();
     else if (k == "--ingest_only") a.ingest_only = true;
     else if (k == "--print_formats") { a.print_formats = true; return a; }
-    else if (k == "--bench_tracks") { exit(bench_tracks()); }
+    else if (k == "--bench_tracks") { exit(bench_tracks(i + 1 < argc && argv[i + 1][0] != '-' ? atoi(argv[i + 1]) : 120)); }
+    else if (k == "--check_fmt6") { exit(check_fmt6(i + 1 < argc ? (size_t)atoll(argv[i + 1]) : 1000000)); }
     else if (k == "--workers_per_device") a.workers_per_device = std::max(1, atoi(value().c_str()));
     else if (k == "--device") a.device = atoi(value().c_str());
     else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)

@@ -118,3 +118,16 @@ def test_bench_tracks_diagnostic_runs_without_a_gpu():
     assert res.returncode == 0, res.stderr[-1000:]
     m = re.search(r"tracks of one region: ([0-9.]+) ms, (\d+) members, (\d+) bytes", res.stdout)
     assert m and int(m.group(2)) == 17 and 1000 < int(m.group(3)) < 200000 and float(m.group(1)) < 50.0, res.stdout
+
+
+def test_fixed_six_decimals_without_printf_equals_printf():
+    """`run_vcf --check_fmt6 N`: the writers' `{:.6}` formatter (exact integer arithmetic on the binary value, no printf) against printf's
+    %.6f on pseudo-random doubles of every magnitude, the exact ties of the sixth decimal (k / 128) and their one-ulp neighbours, values next
+    to a carry, zeros, subnormals, NaN and infinities (20 M values were run once: none differ)."""
+    from tests.test_gpu_run_vcf import BIN
+
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf not built")
+    res = subprocess.run([BIN, "--check_fmt6", "300000"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert " 0 differ" in res.stdout

@@ -39,9 +39,12 @@ def main():
         cmd += ["--devices", os.environ["RUN_VCF_DEVICES"]]
     if os.environ.get("RUN_VCF_PREFIX"):  # e.g. "rocprofv3 --hip-trace --stats --output-format csv -d DIR -o t --" (the binary itself follows the --)
         cmd = os.environ["RUN_VCF_PREFIX"].split() + cmd
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
     res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_TIMING="1", FERROMIC_PROGRESS="0"))
     wall = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     assert res.returncode == 0, res.stderr[-2000:]
     stages = {}
     for l in res.stderr.splitlines():
@@ -50,6 +53,8 @@ def main():
             stages[name.strip()] = stages.get(name.strip(), 0.0) + float(sec)
     rows = len(open(out_csv).read().splitlines()) - 1
     print(json.dumps({"regions": regions, "csv_rows": rows, "sites": sites, "samples": samples, "wall_s": wall,
+                      "child_user_s": round(ru1.ru_utime - ru0.ru_utime, 3), "child_sys_s": round(ru1.ru_stime - ru0.ru_stime, 3),
+                      "child_minor_faults": ru1.ru_minflt - ru0.ru_minflt, "child_vol_ctx_switches": ru1.ru_nvcsw - ru0.ru_nvcsw,
                       "ms_per_region": 1e3 * stages.get("regions_statistics_and_writers", 0.0) / max(regions, 1), "stages_s": stages}))
 
 
