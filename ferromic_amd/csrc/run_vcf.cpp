@@ -27,6 +27,7 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <array>
 #include <memory>
 #include <optional>
 #include <set>
@@ -1991,6 +1992,37 @@ void gz_append(const string& path, const string& text) {  // open_append_compres
   gzclose(f);
 }
 
+// CRC-32 of the gzip trailer, eight bytes per step (slicing by 8).  zlib 1.2.11's crc32 - what deflate() runs over every input byte when it
+// writes the gzip wrapper itself - does about 1 GB/s, and a region's tracks are a megabyte of text that deflates at several GB/s because
+// it is mostly runs of one token: the checksum was half of a sparse region's track time.  gzip_member therefore deflates RAW and frames the
+// member itself.  `run_vcf --check_fmt6` also checks this against zlib's crc32 on random buffers.
+uint32_t crc32_slice8(const uint8_t* p, size_t n, uint32_t crc = 0) {
+  static const auto table = [] {
+    auto t = std::make_unique<std::array<std::array<uint32_t, 256>, 8>>();
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      (*t)[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) (*t)[(size_t)s][i] = ((*t)[(size_t)s - 1][i] >> 8) ^ (*t)[0][(*t)[(size_t)s - 1][i] & 0xFF];
+    return t;
+  }();
+  const auto& T = *table;
+  crc = ~crc;
+  while (n && ((uintptr_t)p & 7)) { crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8); --n; }
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);  // little-endian host (x86-64)
+    w ^= crc;
+    crc = T[7][w & 0xFF] ^ T[6][(w >> 8) & 0xFF] ^ T[5][(w >> 16) & 0xFF] ^ T[4][(w >> 24) & 0xFF] ^ T[3][(w >> 32) & 0xFF] ^ T[2][(w >> 40) & 0xFF] ^
+          T[1][(w >> 48) & 0xFF] ^ T[0][w >> 56];
+    p += 8; n -= 8;
+  }
+  while (n--) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  return ~crc;
+}
+
 // A complete gzip member holding `text` (what one open_append_compressed + write + finish produces).
 string gzip_member(const string& text) {
   // Level 1: the tracks are long runs of "0," / "NA," around sparse values; the default level spends ~1 ms per 40 kB of such
@@ -2007,14 +2039,16 @@ string gzip_member(const string& text) {
   z_stream& z = st.z;
   if (!st.ready) {
     memset(&z, 0, sizeof z);
-    if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
+    if (deflateInit2(&z, level, Z_DEFLATED, -15 /* raw: header, CRC-32 and length are written here */, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error("deflateInit2 failed");
     st.ready = true;
   } else if (deflateReset(&z) != Z_OK) {
     throw Error("deflateReset failed");
   }
   string out;
   out.resize(deflateBound(&z, (uLong)std::min<size_t>(text.size(), (size_t)1 << 30)) + 64);
-  size_t in_off = 0, out_off = 0;
+  static const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};  // no name, no time stamp, written on Unix: zlib's own default header
+  memcpy(&out[0], header, 10);
+  size_t in_off = 0, out_off = 10;
   for (;;) {
     const size_t n = std::min<size_t>(text.size() - in_off, (size_t)1 << 30);
     z.next_in = (Bytef*)text.data() + in_off;
@@ -2033,7 +2067,9 @@ string gzip_member(const string& text) {
     } while (z.avail_out == 0 || (flush == Z_FINISH && rc != Z_STREAM_END));
     if (flush == Z_FINISH) break;
   }
-  out.resize(out_off);
+  out.resize(out_off + 8);
+  const uint32_t crc = crc32_slice8(reinterpret_cast<const uint8_t*>(text.data()), text.size()), isize = (uint32_t)text.size();
+  for (int k = 0; k < 4; ++k) { out[out_off + (size_t)k] = (char)(crc >> (8 * k)); out[out_off + 4 + (size_t)k] = (char)(isize >> (8 * k)); }
   return out;
 }
 
@@ -2279,7 +2315,17 @@ int check_fmt6(size_t n) {
     check(v);
   }
   printf("fmt6: %zu values checked against printf, %zu differ\n", checked, bad);
-  return bad ? 1 : 0;
+  size_t crc_bad = 0, crc_checked = 0;
+  vector<uint8_t> buf(70000);
+  for (int rep = 0; rep < 400; ++rep) {
+    for (auto& b : buf) b = (uint8_t)(next() >> 56);
+    const size_t off = (size_t)(next() % 9), len = (size_t)(next() % (buf.size() - 8));
+    ++crc_checked;
+    if (crc32_slice8(buf.data() + off, len) != (uint32_t)crc32(0L, buf.data() + off, (uInt)len)) ++crc_bad;
+  }
+  const string member = gzip_member(string(100000, 'x') + "tail");
+  printf("crc32: %zu buffers checked against zlib, %zu differ; a 100 004-byte member is %zu bytes\n", crc_checked, crc_bad, member.size());
+  return bad || crc_bad ? 1 : 0;
 }
 
 // --bench_tracks [variants] (no GPU): formats and deflates the tracks of a made-up 15-kb region with 120 variants (or `variants`), 500 times on one thread;
