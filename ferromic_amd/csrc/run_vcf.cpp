@@ -1995,7 +1995,7 @@ void gz_append(const string& path, const string& text) {  // open_append_compres
 // CRC-32 of the gzip trailer, eight bytes per step (slicing by 8).  zlib 1.2.11's crc32 - what deflate() runs over every input byte when it
 // writes the gzip wrapper itself - does about 1 GB/s, and a region's tracks are a megabyte of text that deflates at several GB/s because
 // it is mostly runs of one token: the checksum was half of a sparse region's track time.  gzip_member therefore deflates RAW and frames the
-// member itself.  `run_vcf --check_fmt6` also checks this against zlib's crc32 on random buffers.
+// member itself.  `run_vcf --check_writers` also checks this against zlib's crc32 on random buffers.
 uint32_t crc32_slice8(const uint8_t* p, size_t n, uint32_t crc = 0) {
   static const auto table = [] {
     auto t = std::make_unique<std::array<std::array<uint32_t, 256>, 8>>();
@@ -2073,10 +2073,236 @@ string gzip_member(const string& text) {
   return out;
 }
 
+// ---- where a track's text goes ------------------------------------------------------------------------------------------------------
+// A FALSTA track is runs of one default token around sparse values: a 1-Mb region is 17 tracks of a million tokens, 45 MB of text of which a
+// few hundred kB are values.  Writers therefore hand their output to a sink as literal text and as RUNS ("pattern" repeated `count` times):
+// TextSink materialises the text (tests, --print_formats, dense tracks that go through zlib), RunDeflateSink writes the gzip member directly
+// - a run is a handful of length-258 back references and a table-driven CRC step, whatever its length.
+struct TrackSink {
+  virtual ~TrackSink() {}
+  virtual void text(const char* p, size_t n) = 0;
+  virtual void run(const char* pattern, size_t period, size_t count) = 0;  // pattern[0 .. period) written `count` times
+  void text(const string& t) { text(t.data(), t.size()); }
+};
+struct TextSink : TrackSink {
+  string out;
+  void text(const char* p, size_t n) override { out.append(p, n); }
+  void run(const char* pattern, size_t period, size_t count) override {
+    thread_local string pat, pat_of;
+    if (pat.empty() || pat_of.size() != period || memcmp(pat_of.data(), pattern, period) != 0) {
+      pat.clear();
+      while (pat.size() < 65536) pat.append(pattern, period);
+      pat_of.assign(pattern, period);
+    }
+    const size_t per_block = pat.size() / period;
+    while (count) {
+      const size_t t = std::min(count, per_block);
+      out.append(pat.data(), t * period);
+      count -= t;
+    }
+  }
+};
+
+// CRC-32 register update without the pre / post inversion (crc32_slice8's inner loop): affine in the register, which is what lets a run of a
+// repeated block be folded in a few table look-ups per block instead of a pass over its bytes.
+uint32_t crc32_raw(const uint8_t* p, size_t n, uint32_t state) { return ~crc32_slice8(p, n, ~state); }
+// The register after `len` bytes of a fixed block, for any register before: state' = M * state ^ c.  M (32 x 32 over GF(2)) is held as four
+// 256-entry tables, c = the block's own contribution.  Levels: the pattern repeated 16, 256, 4 096 and 65 536 times; twice a block is
+// (M^2, M c ^ c), so each level comes from the previous one by four doublings and only the smallest touches bytes.
+struct RunCrc {
+  struct Level { size_t bytes; uint32_t t[4][256]; uint32_t c; };
+  Level level[4];
+  string pattern;
+  uint8_t tail[64 * 16];  // the pattern repeated: the < 16 repetitions below the smallest level
+  static void tables_of(const uint32_t (&col)[32], uint32_t (&t)[4][256]) {
+    for (int b = 0; b < 4; ++b)
+      for (int v = 0; v < 256; ++v) { uint32_t x = 0; for (int k = 0; k < 8; ++k) if (v >> k & 1) x ^= col[8 * b + k]; t[b][v] = x; }
+  }
+  static uint32_t apply(const uint32_t (&col)[32], uint32_t v) { uint32_t x = 0; for (int k = 0; k < 32; ++k) if (v >> k & 1) x ^= col[k]; return x; }
+  explicit RunCrc(const string& pat) : pattern(pat) {
+    const size_t d = pat.size();
+    if (d == 0 || d > 64) throw Error("run pattern of 1..64 bytes expected");
+    for (size_t k = 0; k < 16; ++k) memcpy(tail + k * d, pat.data(), d);
+    uint32_t col[32], c;
+    const vector<uint8_t> zeros(16 * d, 0);
+    for (int k = 0; k < 32; ++k) col[k] = crc32_raw(zeros.data(), zeros.size(), 1u << k);
+    c = crc32_raw(tail, 16 * d, 0);
+    size_t bytes = 16 * d;
+    for (int lv = 0; lv < 4; ++lv) {
+      if (lv) for (int dbl = 0; dbl < 4; ++dbl) {  // sixteen times the block
+        c = apply(col, c) ^ c;
+        uint32_t sq[32];
+        for (int k = 0; k < 32; ++k) sq[k] = apply(col, col[k]);
+        memcpy(col, sq, sizeof col);
+        bytes *= 2;
+      }
+      level[lv].bytes = bytes;
+      level[lv].c = c;
+      tables_of(col, level[lv].t);
+    }
+  }
+  uint32_t advance(uint32_t state, size_t count) const {  // the register after `count` more repetitions of the pattern
+    size_t bytes = count * pattern.size();
+    for (int lv = 3; lv >= 0; --lv) {
+      const Level& L = level[lv];
+      while (bytes >= L.bytes) {
+        state = L.t[0][state & 0xFF] ^ L.t[1][(state >> 8) & 0xFF] ^ L.t[2][(state >> 16) & 0xFF] ^ L.t[3][state >> 24] ^ L.c;
+        bytes -= L.bytes;
+      }
+    }
+    return bytes ? crc32_raw(tail, bytes, state) : state;
+  }
+};
+
+// A gzip member written directly: one deflate block with the FIXED Huffman codes (RFC 1951 3.2.6).  Literal text costs 8-9 bits a byte (no
+// entropy coding: this writer is for tracks that are mostly runs - dense ones go through zlib, compress_tracks decides); a run is its
+// pattern once as literals, then back references of up to 258 bytes at distance = the period, 13 bits each.
+struct RunDeflateSink : TrackSink {
+  string out;
+  uint64_t acc = 0;
+  int nbits = 0;
+  uint32_t crc_state = 0xFFFFFFFFu;  // raw register (crc32's ~crc)
+  uint64_t total = 0;
+  struct Codes { uint16_t lit[288]; uint8_t lit_len[288]; uint16_t dist[30]; uint8_t dist_len[30]; };
+  static uint32_t rev(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i); return r; }
+  // canonical Huffman codes of a set of lengths (RFC 1951 3.2.2), bit-reversed for the LSB-first stream
+  static void canonical(const uint8_t* len, int n, uint16_t* code) {
+    int count[16] = {0}, next[16] = {0};
+    for (int i = 0; i < n; ++i) ++count[len[i]];
+    count[0] = 0;
+    for (int b = 1, c = 0; b < 16; ++b) { c = (c + count[b - 1]) << 1; next[b] = c; }
+    for (int i = 0; i < n; ++i) code[i] = len[i] ? (uint16_t)rev((uint32_t)next[len[i]]++, len[i]) : 0;
+  }
+  static const Codes& fixed_codes() {  // RFC 1951 3.2.6
+    static const Codes k = [] {
+      Codes c{};
+      for (int sym = 0; sym < 288; ++sym) c.lit_len[sym] = sym < 144 ? 8 : sym < 256 ? 9 : sym < 280 ? 7 : 8;
+      canonical(c.lit_len, 288, c.lit);
+      for (int d = 0; d < 30; ++d) { c.dist_len[d] = 5; c.dist[d] = (uint16_t)rev((uint32_t)d, 5); }
+      return c;
+    }();
+    return k;
+  }
+  // A code made for this text instead of the fixed one: digits, ',' and '.' in 4 bits, 'N' 'A' '-' newline, end-of-block and the three longest
+  // length symbols in 6, every other byte and length in 11 or 12 (complete: 12/16 + 8/64 + 246/2048 + 20/4096 = 1); the two run distances
+  // (2 and 3: ",0" and ",NA") in 2 bits, the rest in 5 or 6 (2/4 + 4/32 + 24/64 = 1).  Sent once per member as a dynamic block's header.
+  static const Codes& tuned_codes() {
+    static const Codes k = [] {
+      Codes c{};
+      for (int sym = 0; sym < 286; ++sym) c.lit_len[sym] = sym <= 20 ? 12 : 11;  // twenty control bytes in 12 bits (0..20 without the newline, set below)
+      for (int ch = '0'; ch <= '9'; ++ch) c.lit_len[ch] = 4;
+      c.lit_len[(int)','] = 4; c.lit_len[(int)'.'] = 4;
+      for (int sym : {(int)'N', (int)'A', (int)'-', (int)'\n', 256, 283, 284, 285}) c.lit_len[sym] = 6;
+      canonical(c.lit_len, 286, c.lit);
+      for (int d = 0; d < 30; ++d) c.dist_len[d] = d == 1 || d == 2 ? 2 : d >= 26 ? 5 : 6;
+      canonical(c.dist_len, 30, c.dist);
+      return c;
+    }();
+    return k;
+  }
+  const Codes* code_set;
+  const Codes& codes() const { return *code_set; }
+  // tuned = true: a dynamic block carrying tuned_codes() (about 60 bytes of header: worth it from a few dozen values on)
+  explicit RunDeflateSink(bool tuned = false) : code_set(tuned ? &tuned_codes() : &fixed_codes()) {
+    static const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+    out.assign(reinterpret_cast<const char*>(header), 10);
+    put(1, 1);  // BFINAL
+    if (!tuned) { put(1, 2); return; }  // BTYPE = 01: fixed Huffman codes
+    put(2, 2);                          // BTYPE = 10: the code lengths follow
+    put(286 - 257, 5);                  // HLIT
+    put(30 - 1, 5);                     // HDIST
+    // the code that spells the lengths: only 2, 4, 5, 6, 11 and 12 occur (no repeat symbols): 11 in one bit, 4 / 6 / 12 in three, 2 / 5 in four
+    uint8_t cl_len[19] = {0};
+    cl_len[11] = 1; cl_len[4] = 3; cl_len[6] = 3; cl_len[12] = 3; cl_len[2] = 4; cl_len[5] = 4;
+    uint16_t cl_code[19];
+    canonical(cl_len, 19, cl_code);
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    put(16 - 4, 4);                     // HCLEN: the first sixteen of `order` (up to symbol 2)
+    for (int i = 0; i < 16; ++i) put(cl_len[order[i]], 3);
+    const Codes& c = codes();
+    for (int sym = 0; sym < 286; ++sym) put(cl_code[c.lit_len[sym]], cl_len[c.lit_len[sym]]);
+    for (int d = 0; d < 30; ++d) put(cl_code[c.dist_len[d]], cl_len[c.dist_len[d]]);
+  }
+  void put(uint32_t v, int n) {
+    acc |= (uint64_t)v << nbits;
+    nbits += n;
+    while (nbits >= 8) { out.push_back((char)(acc & 0xFF)); acc >>= 8; nbits -= 8; }
+  }
+  void literal(uint8_t b) { const Codes& c = codes(); put(c.lit[b], c.lit_len[b]); }
+  void match(size_t len, size_t dist) {  // 3 <= len <= 258, 1 <= dist <= 32 768
+    static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dextra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    int k = 28;
+    while (base[k] > len) --k;
+    const Codes& c = codes();
+    put(c.lit[257 + k], c.lit_len[257 + k]);
+    if (extra[k]) put((uint32_t)(len - base[k]), extra[k]);
+    int dk = 29;
+    while (dbase[dk] > dist) --dk;
+    put(c.dist[dk], c.dist_len[dk]);
+    if (dextra[dk]) put((uint32_t)(dist - dbase[dk]), dextra[dk]);
+  }
+  // The values of a track are few distinct texts (theta is one number at every segregating site, pi and the F_ST components functions of a
+  // handful of allele counts): a value seen in the last 32 KiB of the text goes as ONE back reference to its previous occurrence instead of
+  // eight-bit literals - what zlib's hash chains find, at one table probe per token.
+  struct Seen { uint64_t at; uint8_t len; char text[23]; };
+  static constexpr size_t kSeenSlots = 1024;
+  std::unique_ptr<Seen[]> seen{new Seen[kSeenSlots]()};
+  void text(const char* p, size_t n) override {
+    bool as_match = false;
+    if (n >= 4 && n <= sizeof Seen::text) {
+      uint64_t h = 1469598103934665603ull;
+      for (size_t i = 0; i < n; ++i) h = (h ^ (uint8_t)p[i]) * 1099511628211ull;
+      Seen& e = seen[(h >> 20) % kSeenSlots];
+      if (e.len == n && memcmp(e.text, p, n) == 0 && total - e.at <= 32768 && total > e.at) { match(n, (size_t)(total - e.at)); as_match = true; }
+      e.at = total; e.len = (uint8_t)n; memcpy(e.text, p, n);
+    }
+    if (!as_match) for (size_t i = 0; i < n; ++i) literal((uint8_t)p[i]);
+    crc_state = crc32_raw(reinterpret_cast<const uint8_t*>(p), n, crc_state);
+    total += n;
+  }
+  void run(const char* pattern, size_t period, size_t count) override {
+    if (!count) return;
+    if (period > 64 || period == 0) {  // (RunCrc's tail buffer holds patterns of up to 64 bytes)
+      for (size_t k = 0; k < count; ++k) text(pattern, period);
+      return;
+    }
+    thread_local std::map<string, std::unique_ptr<RunCrc>> tables;  // per pattern, built on first use
+    const string key(pattern, period);
+    auto it = tables.find(key);
+    if (it == tables.end()) it = tables.emplace(key, std::make_unique<RunCrc>(key)).first;
+    for (size_t i = 0; i < period; ++i) literal((uint8_t)pattern[i]);
+    size_t rest = (count - 1) * period;
+    while (rest >= 258 + 3 || rest == 258) { match(258, period); rest -= 258; }  // never leave a tail of 1 or 2 bytes behind a full match
+    if (rest > 258) { const size_t half = rest / 2; match(half, period); rest -= half; }
+    if (rest >= 3) { match(rest, period); rest = 0; }
+    for (size_t i = 0; i < rest; ++i) literal((uint8_t)pattern[i % period]);  // rest < 3 only when the whole run is shorter than one match
+    crc_state = it->second->advance(crc_state, count);
+    total += count * period;
+  }
+  string finish() {  // end-of-block, trailer; the object is spent
+    const Codes& c = codes();
+    put(c.lit[256], c.lit_len[256]);
+    if (nbits) put(0, 8 - nbits);
+    const uint32_t crc = ~crc_state, isize = (uint32_t)total;
+    for (int k = 0; k < 4; ++k) out.push_back((char)(crc >> (8 * k)));
+    for (int k = 0; k < 4; ++k) out.push_back((char)(isize >> (8 * k)));
+    return std::move(out);
+  }
+};
+
 // FALSTA tracks of one region: every track is formatted and deflated on its own thread and lands in the file as
 // its own gzip member, in track order (the files are multi-member already: one member per region in the
 // reference; readers see the same decompressed text).
-typedef std::function<string()> TrackFn;
+// One track: write(sink) puts header + line into the sink and returns false (having written nothing) when the track is not to appear;
+// `records` / `tokens` say how dense it is (values against positions), which picks the writer.
+struct TrackFn {
+  std::function<bool(TrackSink&)> write;
+  size_t records = 0, tokens = 0;
+  string text() const { TextSink t; return write(t) ? std::move(t.out) : string(); }  // tests, --print_formats
+};
 // `files` = one list of tracks per output file; returns, per file, the gzip members of its tracks in order (empty tracks dropped).
 // All tracks form one batch: formatted and deflated on the pool when they are large, inline when the whole region is small (hundreds of
 // small regions are compressed by their region workers side by side; waking the pool for 40-kB tracks cost more than deflating them).
@@ -2090,8 +2316,18 @@ vector<vector<string>> compress_tracks(const vector<vector<TrackFn>>& files, siz
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= jobs.size()) break;
-      const string text = files[jobs[i].first][jobs[i].second]();
-      if (!text.empty()) members[i] = gzip_member(text);
+      const TrackFn& track = files[jobs[i].first][jobs[i].second];
+      // mostly runs (fewer than one value per eight positions): the run-aware writer; dense: the text through zlib (entropy-coded values).
+      // FERROMIC_TRACK_WRITER=zlib | runs forces one of them (tests run both).
+      static const char* forced = getenv("FERROMIC_TRACK_WRITER");
+      const bool runs = forced ? strcmp(forced, "runs") == 0 : track.records * 8 < track.tokens;
+      if (runs) {
+        RunDeflateSink sink(track.records >= 48);  // a member with a few dozen values repays the tuned code's 60-byte header
+        if (track.write(sink)) members[i] = sink.finish();
+      } else {
+        const string text = track.text();
+        if (!text.empty()) members[i] = gzip_member(text);
+      }
     }
   };
   // inline when the tracks are tiny; else the shared pool, however many region workers there are (500 regions of 2-25 kb, 16 CPUs:
@@ -2127,32 +2363,25 @@ struct RegionOutput {
 
 // One dense FALSTA line: `n` comma-joined tokens, `dflt` everywhere except at the positions present, where the
 // LAST record of a position wins (the reference assigns into a Vec in record order).
-// `tokens` default tokens, each followed by a comma, copied from a per-thread block of the repeated pattern
-inline void append_default_run(string& out, const char* dflt, size_t dl, size_t tokens) {
-  thread_local string pat, pat_of;
-  if (pat.empty() || pat_of != dflt) {
-    pat.clear();
-    while (pat.size() < 65536) { pat.append(dflt, dl); pat.push_back(','); }
-    pat_of = dflt;
-  }
-  const size_t unit = dl + 1, per_block = pat.size() / unit;
-  while (tokens) {
-    const size_t t = std::min(tokens, per_block);
-    out.append(pat.data(), t * unit);
-    tokens -= t;
-  }
-}
-
+// Written into a TrackSink: the gaps between records are runs of (comma + default token).
 template <class PosAt, class TokenAt>
-bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, PosAt pos_at, TokenAt token_at, const char* dflt,
+bool falsta_line(TrackSink& out, const Interval& region, int64_t n, size_t count, PosAt pos_at, TokenAt token_at, const char* dflt,
                  vector<int32_t>& slot) {
-  const size_t dl0 = strlen(dflt);
-  // Records in ascending position order (the usual case: variants are sorted): the gaps between them are runs of the default token and are
-  // block-copied; equal positions are neighbours, so "the last record wins" is "skip a record whose successor has its position".
+  const size_t dl = strlen(dflt);
+  string unit(1, ',');
+  unit.append(dflt, dl);  // ",0" / ",NA": what a default position adds to a line that has begun
+  // `tokens` default positions starting at position `at` of the line
+  auto default_run = [&](int64_t at, size_t tokens) {
+    if (!tokens) return;
+    if (at == 0) { out.text(dflt, dl); --tokens; }
+    out.run(unit.data(), unit.size(), tokens);
+  };
+  string tok;
+  // Records in ascending position order (the usual case: variants are sorted): the gaps between them are runs of the default token;
+  // equal positions are neighbours, so "the last record wins" is "skip a record whose successor has its position".
   bool ascending = true;
   for (size_t i = 1; i < count && ascending; ++i) ascending = pos_at(i - 1) <= pos_at(i);
   if (ascending) {
-    out.reserve(out.size() + (size_t)n * (dl0 + 1) + 16 * count + 16);
     bool any_rec = false;
     int64_t next_k = 0;  // first position of the line not written yet
     for (size_t i = 0; i < count; ++i) {
@@ -2161,14 +2390,15 @@ bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, P
       any_rec = true;
       if (i + 1 < count && pos_at(i + 1) - 1 == p) continue;
       const int64_t k = p - region.first;
-      append_default_run(out, dflt, dl0, (size_t)(k - next_k));
-      token_at(out, i);
-      out.push_back(',');
+      default_run(next_k, (size_t)(k - next_k));
+      tok.clear();
+      if (k) tok.push_back(',');
+      token_at(tok, i);
+      out.text(tok);
       next_k = k + 1;
     }
-    if (n > next_k) append_default_run(out, dflt, dl0, (size_t)(n - next_k));
-    if (n > 0) out.back() = '\n';
-    else out.push_back('\n');
+    if (n > next_k) default_run(next_k, (size_t)(n - next_k));
+    out.text("\n", 1);
     return any_rec;
   }
   slot.assign((size_t)n, -1);
@@ -2179,15 +2409,21 @@ bool falsta_line(string& out, const Interval& region, int64_t n, size_t count, P
     slot[(size_t)(p - region.first)] = (int32_t)i;
     any = true;
   }
-  const size_t dl = strlen(dflt);
-  out.reserve(out.size() + (size_t)n * (dl + 1) + 16);
   for (int64_t k = 0; k < n; ++k) {
-    if (k) out.push_back(',');
-    if (slot[(size_t)k] < 0) out.append(dflt, dl);
-    else token_at(out, (size_t)slot[(size_t)k]);
+    tok.clear();
+    if (k) tok.push_back(',');
+    if (slot[(size_t)k] < 0) tok.append(dflt, dl);
+    else token_at(tok, (size_t)slot[(size_t)k]);
+    out.text(tok);
   }
-  out.push_back('\n');
+  out.text("\n", 1);
   return any;
+}
+// is any record of the track inside the region? (a diversity track without one is not written at all)
+template <class PosAt>
+bool falsta_any(const Interval& region, size_t count, PosAt pos_at) {
+  for (size_t i = 0; i < count; ++i) if (hal_contains(region, pos_at(i) - 1)) return true;
+  return false;
 }
 
 vector<TrackFn> diversity_tracks(const RegionOutput& r) {  // append_diversity_falsta, process.rs:3740-3806
@@ -2202,19 +2438,25 @@ vector<TrackFn> diversity_tracks(const RegionOutput& r) {  // append_diversity_f
   static const Spec specs[4] = {{false, true, "unfiltered_pi_"}, {false, false, "unfiltered_theta_"}, {true, true, "filtered_pi_"}, {true, false, "filtered_theta_"}};
   for (int g : gids)
     for (const Spec& sp : specs)
-      tracks.push_back([&r, region, n, g, sp]() -> string {
+    {
+      TrackFn track;
+      track.tokens = (size_t)n;
+      for (auto& d : r.diversity) track.records += std::get<3>(d) == g && std::get<4>(d) == sp.filtered;
+      track.write = [&r, region, n, g, sp](TrackSink& out) -> bool {
         vector<size_t> sel;  // records of this (group, filter) in record order
         for (size_t i = 0; i < r.diversity.size(); ++i)
           if (std::get<3>(r.diversity[i]) == g && std::get<4>(r.diversity[i]) == sp.filtered) sel.push_back(i);
-        string line;
+        auto pos_at = [&](size_t i) { return std::get<0>(r.diversity[sel[i]]); };
+        if (!falsta_any(region, sel.size(), pos_at)) return false;
+        out.text(">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" +
+                 std::to_string(r.region_end1) + "_group_" + std::to_string(g) + "\n");
         vector<int32_t> slot;
-        const bool any = falsta_line(line, region, n, sel.size(), [&](size_t i) { return std::get<0>(r.diversity[sel[i]]); },
-                                     [&](string& o, size_t i) { const auto& d = r.diversity[sel[i]]; falsta_div_value(o, sp.is_pi ? std::get<1>(d) : std::get<2>(d)); },
-                                     "0", slot);
-        if (!any) return "";
-        return ">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" +
-               std::to_string(r.region_end1) + "_group_" + std::to_string(g) + "\n" + line;
-      });
+        falsta_line(out, region, n, sel.size(), pos_at,
+                    [&](string& o, size_t i) { const auto& d = r.diversity[sel[i]]; falsta_div_value(o, sp.is_pi ? std::get<1>(d) : std::get<2>(d)); }, "0", slot);
+        return true;
+      };
+      tracks.push_back(std::move(track));
+    }
   return tracks;
 }
 
@@ -2227,12 +2469,16 @@ vector<TrackFn> fst_tracks(const RegionOutput& r) {  // append_fst_falsta, proce
     throw Error("region too long for a dense FALSTA track");
   const string suffix = "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1);
   auto add = [&](const string& header, size_t count, auto getter) {  // getter(i) -> (position, value); no std::function on the per-record path
-    tracks.push_back([=]() -> string {
-      string out = ">" + header + "_" + suffix + "\n";
+    TrackFn track;
+    track.tokens = (size_t)n;
+    track.records = count;
+    track.write = [=](TrackSink& out) -> bool {
+      out.text(">" + header + "_" + suffix + "\n");
       vector<int32_t> slot;
       falsta_line(out, region, n, count, [&](size_t i) { return getter(i).first; }, [&](string& o, size_t i) { falsta_fst_value(o, getter(i).second); }, "NA", slot);
-      return out;
-    });
+      return true;
+    };
+    tracks.push_back(std::move(track));
   };
   if (!r.wc_sites.empty()) {
     const vector<WcSite>* w = &r.wc_sites;
@@ -2278,12 +2524,13 @@ int print_formats() {
   r.hudson_sites.push_back({6, 1.0, 1.0, 1.0});
   r.hudson_sites.push_back({7, -0.5, -0.5, 1.0});
   r.hudson_sites.push_back({11, NAN, 0.0, 0.0});
-  for (auto& t : diversity_tracks(r)) printf("per_site_diversity_output.falsta\t%s", t().c_str());
-  for (auto& t : fst_tracks(r)) printf("per_site_fst_output.falsta\t%s", t().c_str());
+  for (auto& t : diversity_tracks(r)) printf("per_site_diversity_output.falsta\t%s", t.text().c_str());
+  for (auto& t : fst_tracks(r)) printf("per_site_fst_output.falsta\t%s", t.text().c_str());
   return 0;
 }
 
-// --check_fmt6 N (no GPU): fmt6 against printf's %.6f on N pseudo-random doubles of every magnitude a statistic can take, exact ties
+// --check_writers N (no GPU; self-checks of the output writers): the CRC-32 against zlib's, the run-aware gzip writer against the text writer
+// through zlib's inflate, and fmt6 against printf's %.6f on N pseudo-random doubles of every magnitude a statistic can take, exact ties
 // (k / 128 and their neighbours one ulp away), values next to a carry (0.9999995, 9.9999995, ...), zeros and subnormals.
 int check_fmt6(size_t n) {
   uint64_t state = 0x9E3779B97F4A7C15ull;
@@ -2325,17 +2572,72 @@ int check_fmt6(size_t n) {
   }
   const string member = gzip_member(string(100000, 'x') + "tail");
   printf("crc32: %zu buffers checked against zlib, %zu differ; a 100 004-byte member is %zu bytes\n", crc_checked, crc_bad, member.size());
-  return bad || crc_bad ? 1 : 0;
+  // the run-aware gzip writer against the text writer: random tracks (both default tokens, runs of every length around 258 and its multiples,
+  // dense and sparse, records at the first and the last position, empty lines), each member inflated by zlib - which also verifies the
+  // CRC-32 and the length of the trailer - and compared with the text
+  auto inflate_member = [](const string& m, string& out) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return false;
+    out.clear();
+    out.resize(1 << 16);
+    z.next_in = (Bytef*)m.data();
+    z.avail_in = (uInt)m.size();
+    size_t off = 0;
+    int rc;
+    do {
+      if (out.size() - off < (1 << 15)) out.resize(out.size() * 2);
+      z.next_out = (Bytef*)&out[off];
+      z.avail_out = (uInt)(out.size() - off);
+      rc = inflate(&z, Z_NO_FLUSH);
+      off = out.size() - z.avail_out;
+    } while (rc == Z_OK);
+    inflateEnd(&z);
+    out.resize(off);
+    return rc == Z_STREAM_END && z.avail_in == 0;
+  };
+  size_t tracks_checked = 0, tracks_bad = 0;
+  for (int rep = 0; rep < 600; ++rep) {
+    const char* dflt = (rep & 1) ? "NA" : "0";
+    const int64_t n = rep < 8 ? rep : (int64_t)(next() % (rep % 7 == 0 ? 700000 : 3000));
+    const Interval region{1000, 1000 + n};
+    vector<std::pair<int64_t, double>> recs;
+    const uint64_t gap = 1 + next() % (rep % 5 == 0 ? 3 : 600);
+    for (int64_t p = (int64_t)(next() % 3); p < n; p += 1 + (int64_t)(next() % gap)) recs.push_back({1001 + p, (double)(next() >> 11) / 9007199254740992.0});
+    if (rep % 11 == 0 && n > 0) { recs.insert(recs.begin(), {1001, 0.5}); recs.push_back({1000 + n, -0.25}); }
+    for (size_t special : {(size_t)258, (size_t)259, (size_t)260, (size_t)261, (size_t)516, (size_t)517, (size_t)130})  // gaps that hit the match-length edges
+      if (rep % 13 == 0 && (int64_t)(special * 3) < n) recs.push_back({recs.empty() ? 1001 + (int64_t)special : recs.back().first + (int64_t)special, 1.0});
+    if (rep % 17 != 0) std::sort(recs.begin(), recs.end()); else if (recs.size() > 2) std::swap(recs[0], recs[recs.size() / 2]);  // (the unsorted path too)
+    auto write = [&](TrackSink& out) {
+      out.text(string(">header_") + dflt + "\n");
+      vector<int32_t> slot;
+      falsta_line(out, region, n, recs.size(), [&](size_t i) { return recs[i].first; }, [&](string& o, size_t i) { falsta_fst_value(o, recs[i].second); }, dflt, slot);
+    };
+    TextSink text;
+    RunDeflateSink runs(rep % 2 == 0);  // both code sets
+    write(text);
+    write(runs);
+    const string member2 = runs.finish();
+    string back;
+    ++tracks_checked;
+    if (!inflate_member(member2, back) || back != text.out) {
+      if (tracks_bad++ < 5) fprintf(stderr, "run-aware member differs: rep %d, %lld positions, %zu records, text %zu bytes, inflated %zu\n", rep, (long long)n, recs.size(), text.out.size(), back.size());
+    }
+    string back2;
+    if (!inflate_member(gzip_member(text.out), back2) || back2 != text.out) ++tracks_bad;
+  }
+  printf("run-aware gzip writer: %zu tracks inflated by zlib and compared with the text, %zu differ\n", tracks_checked, tracks_bad);
+  return bad || crc_bad || tracks_bad ? 1 : 0;
 }
 
-// --bench_tracks [variants] (no GPU): formats and deflates the tracks of a made-up 15-kb region with 120 variants (or `variants`), 500 times on one thread;
+// --bench_tracks [variants [length]] (no GPU): formats and deflates the tracks of a made-up 15-kb region (or `length` bp) with 120 variants (or `variants`), 500 times on one thread;
 // what the writers cost per small region.
-int bench_tracks(int variants) {  // 120 = a variant every 125 bp; 3 750 = every 4 bp (tools/run_vcf_many_regions.py's cohort)
+int bench_tracks(int variants, int length) {  // 120 = a variant every 125 bp; 3 750 = every 4 bp (tools/run_vcf_many_regions.py's cohort)
   RegionOutput r;
   r.seqname = "1";
   r.region_start1 = 1000;
-  r.region_end1 = 15999;
-  const int step = std::max(1, 15000 / std::max(variants, 1));
+  r.region_end1 = 1000 + length - 1;
+  const int step = std::max(1, length / std::max(variants, 1));
   for (int g = 0; g < 2; ++g)
     for (int f = 0; f < 2; ++f)
       for (int i = 0; i < variants; ++i) r.diversity.push_back({1000 + step * i, 0.289855 + i * 1e-5, 0.267788 + i * 1e-6, g, f != 0});
@@ -2345,10 +2647,11 @@ int bench_tracks(int variants) {  // 120 = a variant every 125 bp; 3 750 = every
   }
   const auto t0 = std::chrono::steady_clock::now();
   size_t bytes = 0, members = 0;
-  for (int rep = 0; rep < 500; ++rep)
-    for (auto& file : compress_tracks({diversity_tracks(r), fst_tracks(r)}, 15000)) for (auto& m : file) { bytes += m.size(); ++members; }
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 500;
-  printf("tracks of one region: %.3f ms, %zu members, %zu bytes\n", ms, members / 500, bytes / 500);
+  const int reps = length > 100000 ? 20 : 500;
+  for (int rep = 0; rep < reps; ++rep)
+    for (auto& file : compress_tracks({diversity_tracks(r), fst_tracks(r)}, (size_t)length)) for (auto& m : file) { bytes += m.size(); ++members; }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+  printf("tracks of one region: %.3f ms, %zu members, %zu bytes\n", ms, members / (size_t)reps, bytes / (size_t)reps);
   return 0;
 }
 
@@ -2812,8 +3115,11 @@ Args parse_args(int argc, char** argv) {  // clap Args, process.rs:67-144
     else if (k == "--fst_populations") a.fst_populations = value();
     else if (k == "--ingest_only") a.ingest_only = true;
     else if (k == "--print_formats") { a.print_formats = true; return a; }
-    else if (k == "--bench_tracks") { exit(bench_tracks(i + 1 < argc && argv[i + 1][0] != '-' ? atoi(argv[i + 1]) : 120)); }
-    else if (k == "--check_fmt6") { exit(check_fmt6(i + 1 < argc ? (size_t)atoll(argv[i + 1]) : 1000000)); }
+    else if (k == "--bench_tracks") {  // [variants [region length]]
+      const int v = i + 1 < argc && argv[i + 1][0] != '-' ? atoi(argv[i + 1]) : 120;
+      exit(bench_tracks(v, i + 2 < argc && argv[i + 1][0] != '-' && argv[i + 2][0] != '-' ? atoi(argv[i + 2]) : 15000));
+    }
+    else if (k == "--check_writers" || k == "--check_fmt6") { exit(check_fmt6(i + 1 < argc ? (size_t)atoll(argv[i + 1]) : 1000000)); }
     else if (k == "--workers_per_device") a.workers_per_device = std::max(1, atoi(value().c_str()));
     else if (k == "--device") a.device = atoi(value().c_str());
     else if (k == "--devices") {  // "4" = devices 0..3, "0,2,5" = those devices (one worker thread each)

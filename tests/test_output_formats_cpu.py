@@ -120,14 +120,18 @@ def test_bench_tracks_diagnostic_runs_without_a_gpu():
     assert m and int(m.group(2)) == 17 and 1000 < int(m.group(3)) < 200000 and float(m.group(1)) < 50.0, res.stdout
 
 
-def test_fixed_six_decimals_without_printf_equals_printf():
-    """`run_vcf --check_fmt6 N`: the writers' `{:.6}` formatter (exact integer arithmetic on the binary value, no printf) against printf's
-    %.6f on pseudo-random doubles of every magnitude, the exact ties of the sixth decimal (k / 128) and their one-ulp neighbours, values next
-    to a carry, zeros, subnormals, NaN and infinities (20 M values were run once: none differ)."""
+def test_writer_self_checks():
+    """`run_vcf --check_writers N` (no GPU): (1) the writers' `{:.6}` formatter (exact integer arithmetic on the binary value, no printf) against
+    printf's %.6f on pseudo-random doubles of every magnitude, the exact ties of the sixth decimal (k / 128) and their one-ulp neighbours, values
+    next to a carry, zeros, subnormals, NaN and infinities (20 M values were run once: none differ); (2) the slicing-by-8 CRC-32 against zlib's on
+    random buffers; (3) the run-aware gzip writer (runs of the default token as back references, table-driven CRC steps, both Huffman code sets,
+    value tokens as back references to their last occurrence) against the text writer on 600 random tracks - sorted and unsorted records, both
+    default tokens, gaps at the match-length edges, empty lines, 700 000-position lines - each member inflated by zlib, which also verifies the
+    trailer's CRC-32 and length."""
     from tests.test_gpu_run_vcf import BIN
 
     if not os.path.exists(BIN):
         pytest.skip("run_vcf not built")
-    res = subprocess.run([BIN, "--check_fmt6", "300000"], capture_output=True, text=True, timeout=120)
+    res = subprocess.run([BIN, "--check_writers", "300000"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert " 0 differ" in res.stdout
+    assert res.stdout.count(" 0 differ") == 3, res.stdout

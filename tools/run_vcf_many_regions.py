@@ -25,8 +25,8 @@ def main():
     rng = random.Random(5)
     cfg = "seqnames\tstart\tend\tPOS\torig_ID\tverdict\tcateg\t" + "\t".join(names) + "\n"
     for _ in range(regions):
-        a = rng.randint(1, length - 30_000)
-        b = a + rng.randint(2_000, 25_000)
+        a = rng.randint(1, length - int(os.environ.get("RUN_VCF_REGION_MAX", "25000")) - 5_000)
+        b = a + rng.randint(2_000, int(os.environ.get("RUN_VCF_REGION_MAX", "25000")))
         cells = [rng.choice(["0|0", "0|1", "1|0", "1|1"]) for _ in range(samples)]
         cfg += f"chr1\t{a}\t{b}\t{a}\tid\tpass\tinv\t" + "\t".join(cells) + "\n"
     open(os.path.join(tmp, "config.tsv"), "w").write(cfg)
@@ -52,8 +52,10 @@ def main():
             name, sec = l[len("[TIMING]"):].rsplit(" ", 1)
             stages[name.strip()] = stages.get(name.strip(), 0.0) + float(sec)
     rows = len(open(out_csv).read().splitlines()) - 1
+    out_dir = os.path.dirname(out_csv)
+    sizes = {f: os.path.getsize(os.path.join(out_dir, f)) for f in sorted(os.listdir(out_dir)) if f.endswith(".gz")}
     print(json.dumps({"regions": regions, "csv_rows": rows, "sites": sites, "samples": samples, "wall_s": wall,
-                      "child_user_s": round(ru1.ru_utime - ru0.ru_utime, 3), "child_sys_s": round(ru1.ru_stime - ru0.ru_stime, 3),
+                      "gz_bytes": sizes, "child_user_s": round(ru1.ru_utime - ru0.ru_utime, 3), "child_sys_s": round(ru1.ru_stime - ru0.ru_stime, 3),
                       "child_minor_faults": ru1.ru_minflt - ru0.ru_minflt, "child_vol_ctx_switches": ru1.ru_nvcsw - ru0.ru_nvcsw,
                       "ms_per_region": 1e3 * stages.get("regions_statistics_and_writers", 0.0) / max(regions, 1), "stages_s": stages}))
 

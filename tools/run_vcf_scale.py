@@ -62,7 +62,7 @@ class BgzfWriter:
 
 def write_inputs(tmp: str, sites: int, samples: int, seed: int, compress: str = "none"):
     rng = np.random.default_rng(seed)
-    gaps = rng.integers(1, 7, size=sites)
+    gaps = rng.integers(1, int(os.environ.get("RUN_VCF_GAP_MAX", "7")), size=sites)  # RUN_VCF_GAP_MAX=200: a variant every 100 bp on average
     pos = np.cumsum(gaps)  # 1-based VCF positions
     length = int(pos[-1]) + 10
     names = [f"SYN{i:05d}" for i in range(samples)]
