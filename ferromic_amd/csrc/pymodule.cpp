@@ -126,6 +126,20 @@ vector<uint64_t> missing_words_from_flags(const uint8_t* missing_flag, size_t to
   return words;
 }
 
+shared_ptr<DevMatrix> upload_planes(const uint8_t* plane0, const uint8_t* called_or_null, size_t pitch, size_t variants, size_t samples, size_t ploidy,
+                                    uint8_t max_allele) {
+  auto m = std::make_shared<DevMatrix>();
+  m->variants = variants; m->samples = samples; m->ploidy = ploidy;
+  m->device = current_device();
+  int rc;
+  {
+    py::gil_scoped_release nogil;
+    rc = fmh_matrix_create_packed(plane0, nullptr, nullptr, called_or_null, pitch, variants, samples, ploidy, max_allele, m->device, &m->h);
+  }
+  fmh_check(rc);
+  return m;
+}
+
 struct Groups {
   fmh_groups* h = nullptr;
   int n = 0;
@@ -471,16 +485,44 @@ struct Dense {
   int64_t variants = 0, samples = 0, ploidy = 0;
   ByteBuf g;             // [S][N][P], negatives stored as 0
   ByteBuf neg;           // empty = nothing missing, else one flag per entry
+  // A biallelic int8 / uint8 array is packed to bit planes WHILE it is read (convert_planes below): plane0 = the allele bit, called = the
+  // entries that are not negative, rows of `plane_pitch` bytes, column c = bit (c & 7) of byte (c >> 3) - what fmh_matrix_create_packed takes.
+  // Then g / neg stay empty until someone asks for bytes (materialize): a 1 GB array is read once and 125 MB are written, instead of a 1 GB
+  // narrowed copy that the first statistic packs again.
+  ByteBuf plane0, called;
+  size_t plane_pitch = 0;
+  bool planes_only = false, any_missing = false;
+  bool has_missing() const { return planes_only ? any_missing : !neg.empty(); }
   int max_allele = 0;
   shared_ptr<DevMatrix> device;
   shared_ptr<DevMatrix> device_matrix() {
     if (!device) {
-      bool any = false;
-      vector<uint64_t> words;
-      if (!neg.empty()) words = missing_words_from_flags(neg.data(), neg.size(), &any);
-      device = upload_matrix(g.data(), any ? words.data() : nullptr, (size_t)variants, (size_t)samples, (size_t)ploidy, (uint8_t)max_allele);
+      if (planes_only) {
+        device = upload_planes(plane0.data(), any_missing ? called.data() : nullptr, plane_pitch, (size_t)variants, (size_t)samples, (size_t)ploidy, (uint8_t)max_allele);
+      } else {
+        bool any = false;
+        vector<uint64_t> words;
+        if (!neg.empty()) words = missing_words_from_flags(neg.data(), neg.size(), &any);
+        device = upload_matrix(g.data(), any ? words.data() : nullptr, (size_t)variants, (size_t)samples, (size_t)ploidy, (uint8_t)max_allele);
+      }
     }
     return device;
+  }
+  // the byte form (g, neg) of a planes-only matrix, for the rare caller that needs entries on the host (the sparse copy of a population with
+  // missing calls)
+  void materialize() {
+    if (!planes_only || !g.empty() || variants == 0) return;
+    const size_t cols = (size_t)(samples * ploidy), total = (size_t)variants * cols;
+    g.resize(total);
+    if (any_missing) neg.resize(total);
+    for (size_t r = 0; r < (size_t)variants; ++r) {
+      const uint8_t* p = plane0.data() + r * plane_pitch;
+      const uint8_t* c = any_missing ? called.data() + r * plane_pitch : nullptr;
+      for (size_t k = 0; k < cols; ++k) {
+        g[r * cols + k] = (uint8_t)((p[k >> 3] >> (k & 7)) & 1);
+        if (c) neg[r * cols + k] = (uint8_t)(((c[k >> 3] >> (k & 7)) & 1) ^ 1);
+      }
+    }
   }
   // DenseMembership::build, stats.rs:1252-1284
   vector<uint8_t> mask_for(const vector<Hap>& haps) const {
@@ -715,6 +757,73 @@ void convert_block(const py::array& arr, ByteBuf& g, ByteBuf& neg, bool* any_neg
   *max_allele = mx;
 }
 
+// int8 / uint8 input whose values are all 0 / 1 (or negative = missing, int8): bit planes straight from the array, sixteen entries per
+// step - the narrowing pass and the library's host packer (host_pack.hpp: the same movemask bit order) in one read.  Returns false, having
+// touched nothing that matters, as soon as any called entry is above 1: the caller then takes the byte route (convert_block).
+template <class T>
+bool convert_planes(const py::array& arr, Dense& d, size_t rows, size_t cols) {
+  static_assert(sizeof(T) == 1, "one-byte entries");
+  auto a = py::array_t<T, py::array::c_style | py::array::forcecast>(arr);
+  const T* src = a.data();
+  const size_t written = ((cols + 15) / 16) * 2;             // two bytes per sixteen columns
+  const size_t pitch = ((cols + 7) / 8 + 15) / 16 * 16;      // the device's plane pitch: each plane then goes up in one copy (fmh_matrix_create_packed)
+  if (rows == 0 || cols == 0) return false;
+  // a look at 64 rows spread over the array first: a multi-allelic cohort shows an allele above 1 there and is spared the wasted pass
+  for (size_t k = 0; k < 64; ++k) {
+    const T* row = src + ((rows - 1) * k / 63) * cols;
+    for (size_t c = 0; c < cols; ++c) if (row[c] > 1) return false;
+  }
+  d.plane0.resize(rows * pitch);
+  d.called.resize(rows * pitch);
+  uint8_t* p0 = d.plane0.data();
+  uint8_t* pc = d.called.data();
+  std::atomic<bool> big{false}, negs{false}, ones{false};
+  parallel_ranges(rows * cols, [&](size_t b, size_t e, size_t) {
+    // whole rows per worker: [b, e) is an entry range, rounded to rows here (workers get disjoint row ranges)
+    const size_t r0 = (b + cols - 1) / cols, r1 = e == rows * cols ? rows : (e + cols - 1) / cols;
+    const __m128i zero = _mm_setzero_si128(), hi = _mm_set1_epi8((char)0xFE);
+    __m128i vbig = zero, vneg = zero;
+    uint32_t any_one = 0;
+    for (size_t r = r0; r < r1 && !big.load(std::memory_order_relaxed); ++r) {
+      const T* row = src + r * cols;
+      uint8_t* o0 = p0 + r * pitch;
+      uint8_t* oc = pc + r * pitch;
+      for (size_t c = 0; c < cols; c += 16) {
+        __m128i v;
+        uint32_t valid = 0xFFFFu;
+        if (c + 16 <= cols) v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(row + c));
+        else {
+          alignas(16) uint8_t tmp[16] = {0};
+          memcpy(tmp, row + c, cols - c);
+          v = _mm_load_si128(reinterpret_cast<const __m128i*>(tmp));
+          valid = (1u << (cols - c)) - 1u;
+        }
+        __m128i isneg = zero;
+        if constexpr (std::is_signed<T>::value) isneg = _mm_cmplt_epi8(v, zero);
+        const __m128i kept = _mm_andnot_si128(isneg, v);
+        vbig = _mm_or_si128(vbig, _mm_and_si128(kept, hi));
+        vneg = _mm_or_si128(vneg, isneg);
+        const uint16_t b0 = (uint16_t)_mm_movemask_epi8(_mm_slli_epi16(kept, 7));
+        const uint16_t bc = (uint16_t)(~(uint32_t)_mm_movemask_epi8(isneg) & valid);
+        any_one |= b0;
+        memcpy(o0 + (c >> 3), &b0, 2);
+        memcpy(oc + (c >> 3), &bc, 2);
+      }
+      if (written < pitch) { memset(o0 + written, 0, pitch - written); memset(oc + written, 0, pitch - written); }  // the row's padding
+    }
+    if (_mm_movemask_epi8(_mm_cmpeq_epi8(vbig, zero)) != 0xFFFF) big = true;
+    if (_mm_movemask_epi8(vneg) != 0) negs = true;
+    if (any_one) ones = true;
+  });
+  if (big) { d.plane0.release(); d.called.release(); return false; }
+  d.plane_pitch = pitch;
+  d.planes_only = true;
+  d.any_missing = negs;
+  if (!negs) d.called.release();
+  d.max_allele = ones ? 1 : 0;
+  return true;
+}
+
 std::pair<shared_ptr<Store>, shared_ptr<Dense>> convert_numeric_array(const py::handle& genotypes, const py::handle& positions) {
   static const char* kMsg = "genotypes must be a numpy.ndarray with dtype uint8/int8/uint16/int16 and shape (variants, samples, ploidy)";
   if (!py::isinstance<py::array>(genotypes)) value_error(kMsg);
@@ -728,7 +837,18 @@ std::pair<shared_ptr<Store>, shared_ptr<Dense>> convert_numeric_array(const py::
   auto dense = std::make_shared<Dense>();
   bool any_neg = false;
   int mx = 0;
-  if (u8) convert_block<uint8_t>(arr, dense->g, dense->neg, &any_neg, &mx);
+  // diploid biallelic one-byte input: straight to bit planes (FERROMIC_NUMPY_BYTES=1, or the library's u8-row kernels forced with
+  // FMH_LAYOUT=bytes - the u8 soak -, keep the byte route)
+  static const bool bytes_route = [] {
+    long long forced = 0;
+    (void)fmh_get_option("FMH_LAYOUT", &forced);
+    return forced != 0 || getenv("FERROMIC_NUMPY_BYTES") != nullptr;
+  }();
+  bool planes = false;
+  if (!bytes_route && P == 2 && N > 0 && S > 0 && (u8 || i8))
+    planes = u8 ? convert_planes<uint8_t>(arr, *dense, (size_t)S, (size_t)(N * P)) : convert_planes<int8_t>(arr, *dense, (size_t)S, (size_t)(N * P));
+  if (planes) { any_neg = dense->any_missing; mx = dense->max_allele; }
+  else if (u8) convert_block<uint8_t>(arr, dense->g, dense->neg, &any_neg, &mx);
   else if (i8) convert_block<int8_t>(arr, dense->g, dense->neg, &any_neg, &mx);
   else if (u16) convert_block<uint16_t>(arr, dense->g, dense->neg, &any_neg, &mx);
   else convert_block<int16_t>(arr, dense->g, dense->neg, &any_neg, &mx);
@@ -749,6 +869,7 @@ std::pair<shared_ptr<Store>, shared_ptr<Dense>> convert_numeric_array(const py::
     // the sparse half of convert_numeric_array (lib.rs:1165-1206): a sample with ANY missing allele is None as a whole;
     // 0xFF keeps its sentinel meaning (allele 255 is indistinguishable from missing)
     st->lazy = [src, S, N, P](vector<uint8_t>& d, vector<uint8_t>& c) {
+      src->materialize();  // (a planes-only matrix: its bytes are rebuilt here, once)
       const size_t total = (size_t)(S * N * P);
       d.assign(total, 0);
       c.assign(total, 0);

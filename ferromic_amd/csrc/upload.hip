@@ -137,7 +137,13 @@ int fmhi::upload_planes_from_planes(fmh_matrix* m, const uint8_t* const h_planes
   hipStream_t st = hipStreamPerThread;
   for (int p = 0; p < 4; ++p) {
     if (!d_planes[p]) continue;
-    if (h_pitch != m->plane_pitch || row_bytes != m->plane_pitch) HIP_TRY(hipMemsetAsync(d_planes[p], 0, m->variants * m->plane_pitch, st));  // padding bytes stay zero
+    if (h_pitch == m->plane_pitch) {
+      // the caller's rows have the device's pitch (their bytes past the last column are zero, include/ferromic_hip.h): ONE copy of the whole
+      // plane.  A pitched copy is a descriptor per row: a million 125-byte rows took seconds.
+      HIP_TRY(hipMemcpyAsync(d_planes[p], h_planes[p], m->variants * m->plane_pitch, hipMemcpyHostToDevice, st));
+      continue;
+    }
+    HIP_TRY(hipMemsetAsync(d_planes[p], 0, m->variants * m->plane_pitch, st));  // padding bytes stay zero
     HIP_TRY(hipMemcpy2DAsync(d_planes[p], m->plane_pitch, h_planes[p], h_pitch, row_bytes, m->variants, hipMemcpyHostToDevice, st));
   }
   HIP_TRY(hipStreamSynchronize(st));

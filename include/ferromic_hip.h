@@ -119,8 +119,10 @@ int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missing_or_null, 
 /*
  * The same for a host that already holds BIT PLANES (run_vcf after ingest, a cohort stored packed): plane k = bit k of the allele
  * value (h_plane1 iff max_allele >= 2, h_plane2 iff max_allele >= 4), h_called_or_null = 1 bits for called entries; a row is
- * h_pitch bytes, column c is bit (c & 7) of byte (c >> 3), bits past the last column zero.  Pitched copies, no conversion:
- * ceil(H / 8) bytes per site and plane cross PCIe.  The planes are taken at their word (no max_allele check is possible).
+ * h_pitch bytes, column c is bit (c & 7) of byte (c >> 3), bits past the last column zero.  No conversion: ceil(H / 8) bytes per site
+ * and plane cross PCIe.  With h_pitch = the device's own plane pitch - ceil(H / 8) rounded up to 16 - each plane goes up in ONE copy
+ * (then the padding bytes of a row must be zero as well); any other pitch takes a pitched copy, a descriptor per row, which is slow for
+ * millions of short rows.  The planes are taken at their word (no max_allele check is possible).
  */
 int fmh_matrix_create_packed(const uint8_t* h_plane0, const uint8_t* h_plane1_or_null, const uint8_t* h_plane2_or_null,
                              const uint8_t* h_called_or_null, size_t h_pitch, size_t variants, size_t samples, size_t ploidy,
