@@ -87,6 +87,16 @@ int current_device() {
     d = (int)v;
   }
   g_device.store(d);
+  // Once per process, with the start-up: the first pageable copy of more than a few KB (and the first device block of its size class) costs
+  // 7-8 ms on the GPU box - otherwise paid by the first statistic of whichever cohort is the first large enough.
+  for (size_t bytes : {(size_t)64 << 10, (size_t)1 << 20}) {
+    void* p = nullptr;
+    if (fmh_device_alloc(d, bytes, &p) != FMH_OK) break;
+    vector<uint8_t> h(bytes, 0);
+    (void)fmh_copy_to_device(d, p, h.data(), bytes, nullptr);
+    (void)fmh_copy_to_host(d, h.data(), p, bytes, nullptr);
+    (void)fmh_device_free(d, p);
+  }
   return d;
 }
 
