@@ -1277,10 +1277,11 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
 // invariants of the epilogue loop alive across the counting loop (233 VGPRs, two waves), and occupancy is worth more than that (2 -> 3 waves: 16 %)
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM, int LPR>
 constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL && !MISSING && P <= 2 && LPR == 16 && (MODE & kModeWc) == 0) ? 3 : 1; }
-// __launch_bounds__' second argument (workgroups of four waves per CU = waves per SIMD): the eight-group W&C kernels of a biallelic packed
-// matrix end one register above 256 when left alone - one wave per SIMD instead of two
-template <int P, int MODE, bool GENERAL, int MM>
-constexpr int sweep_min_blocks() { return (MM == 3 /* kMaskPacked */ && !GENERAL && P == 8 && (MODE & kModeWc) != 0) ? 2 : 1; }
+// __launch_bounds__' second argument (workgroups of four waves per CU = waves per SIMD): the eight-group W&C kernels of a packed matrix
+// (biallelic, and multi-allelic on two planes) end one register above 256 when left alone - one wave per SIMD instead of two; the
+// three-plane ones would spill to scratch under that bound and are left alone
+template <int P, int MODE, bool GENERAL, int MM, int NPL>
+constexpr int sweep_min_blocks() { return (MM == 3 /* kMaskPacked */ && P == 8 && (MODE & kModeWc) != 0 && NPL == 2) ? 2 : 1; }
 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
@@ -1308,7 +1309,7 @@ inline size_t defer_lds_bytes(int P, int mode, bool missing, int depth) {
 }
 
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
-__global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM>())) void sweep_kernel(const SweepArgs A) {
+__global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL>())) void sweep_kernel(const SweepArgs A) {
   static_assert(NPL == 2 || (NPL == 3 && GENERAL && MM == kMaskPacked), "a third plane exists on packed multi-allelic matrices only");
   static_assert(LPR == 16 || ((LPR == 4 || LPR == 8) && MM == kMaskPacked), "four / eight lanes per row exist for the packed cores only");
   extern __shared__ __align__(16) unsigned char smem[];
