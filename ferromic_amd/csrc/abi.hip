@@ -75,6 +75,8 @@ const OptionRow kOptionRows[] = {
     {"FMH_PD_OCC", &Options::pd_occ, 0, nullptr},
     {"FMH_PIPE", &Options::pipe, -1, nullptr},
     {"FMH_GRAPH", &Options::graph, 0, nullptr},
+    {"FMH_FLAT", &Options::flat, -1, nullptr},
+    {"FMH_FLAT_SLOTS", &Options::flat_slots, 0, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -105,8 +107,15 @@ Options& fmhi::options() {
     for (size_t i = 0; i < kOptionCount; ++i) {
       const OptionRow& row = kOptionRows[i];
       long long x = row.dflt;
-      // a variable that is set but empty or unparsable counts as "1" (round 2's presence switches: FMH_PACKED_NO_PREFETCH=, FMH_PD_INT8=yes)
-      if (const char* v = getenv(row.key)) { if (!parse_option(row, v, &x)) x = 1; }
+      // a variable that is set but empty or unparsable counts as "1" for the integer switches (round 2's presence switches:
+      // FMH_PACKED_NO_PREFETCH=, FMH_PD_INT8=yes); a word-valued one (FMH_LAYOUT, FMH_COMM_TRANSPORT) keeps its default and says so, as
+      // fmh_set_option refuses the same text
+      if (const char* v = getenv(row.key)) {
+        if (!parse_option(row, v, &x)) {
+          if (row.words) { x = row.dflt; fprintf(stderr, "libferromic_hip: %s='%s' is not one of %s: ignored\n", row.key, v, row.words); }
+          else x = 1;
+        }
+      }
       g_option_initial[i] = x;
       (o.*row.field).store(x);
     }
@@ -709,7 +718,12 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
   // byte masks and, behind them, the same masks as one bit per column: ONE device block and ONE copy (every statistic of the Python module
   // makes its groups per call; two blocking copies were 24 us of a 50-us call, tools/measure_call_overheads.py)
   const size_t bytes_len = (size_t)g->padded * g->mask_pitch, bits_len = (size_t)g->padded * (g->mask_pitch / 16) * 2;
-  std::vector<uint8_t> staged(bytes_len + bits_len, 0);
+  // third form, for the flat-tile route of short packed rows (sweep_flat_kernels.hpp): the bit masks interleaved [vector][group][4 dwords], the
+  // vector count padded to a multiple of 4 with zeros - scalar loads fetch every group's mask of one vector at once
+  const size_t pvec = ((size_t)m->columns + 127) / 128;
+  const size_t flat_vecs = pvec <= (size_t)kFlatMaskMaxVec ? round_up(pvec, 4) : 0;
+  const size_t flat_len = flat_vecs * g->padded * 16;
+  std::vector<uint8_t> staged(bytes_len + bits_len + flat_len, 0);
   uint16_t* bits = reinterpret_cast<uint16_t*>(staged.data() + bytes_len);  // bytes_len is a multiple of 2048
   for (int p = 0; p < n_groups; ++p) {
     uint64_t cnt = 0;
@@ -720,6 +734,12 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
       cnt += v;
     }
     g->sizes[p] = cnt;
+  }
+  if (flat_len) {  // bits_len is a multiple of 256: the image is 16-byte aligned
+    uint8_t* flat = staged.data() + bytes_len + bits_len;
+    for (int p = 0; p < n_groups; ++p)
+      for (size_t v = 0; v < pvec; ++v)
+        memcpy(flat + (v * g->padded + p) * 16, reinterpret_cast<const uint8_t*>(bits) + (size_t)p * (g->mask_pitch / 8) + v * 16, 16);
   }
   hipError_t e = pool_malloc(g->device, (void**)&g->masks, staged.size());
   // (on the calling thread's own stream: a plain hipMemcpy runs on the legacy default stream, which waits for - and holds up - every blocking
@@ -732,6 +752,7 @@ extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int
     return fail(FMH_ERR_HIP, "group mask upload failed: %s", hipGetErrorString(e));
   }
   g->mask_bits = reinterpret_cast<uint16_t*>(g->masks + bytes_len);
+  g->mask_flat = flat_len ? reinterpret_cast<uint32_t*>(g->masks + bytes_len + bits_len) : nullptr;
   *out = g;
   return FMH_OK;
 }
@@ -894,6 +915,8 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   a.masks = g->masks;
   a.mask_pitch = g->mask_pitch;
   a.mask_bits = g->mask_bits;
+  a.mask_flat = g->mask_flat;
+  a.flat_slots = 0;
   for (int p = 0; p < 8; ++p) a.group_size[p] = p < g->n_groups ? (uint32_t)g->sizes[p] : 0;
   a.n_groups = g->n_groups;
   a.max_allele = m->max_allele;
@@ -1025,8 +1048,14 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     return fail(FMH_ERR_UNSUPPORTED, "unsupported sweep mode %d", mode);
   if (mask_mode == kMaskGlobalBytes && (P > 2 || mode == kModeWc))
     return fail(FMH_ERR_UNSUPPORTED, "%d group masks of %u columns exceed the LDS budget: sweep at most two groups at a time on rows this wide", P, m->columns);
+  // Short packed rows, biallelic, nothing missing: the LDS-staged flat-tile route (sweep_flat_kernels.hpp: one row per lane, scalar masks).
+  // FMH_FLAT: 1 = wherever it is built, 0 = never, -1 = where it measured ahead of the four-lane route.
+  const long long want_flat = opt.flat.load();
+  const bool flat = mask_mode == kMaskPacked && !mfma && !missing && !general && m->pvec <= (uint32_t)kFlatMaskMaxVec && g->mask_flat &&
+                    flat_route_builds(P, mode) && want_flat != 0 && (want_flat > 0 || flat_route_default(P, mode, m->pvec));
   int rc;
-  if (mfma) rc = launch_sweep_mfma(P, mode, a, smem, st, ctx, &grid);
+  if (flat) rc = launch_sweep_flat(P, mode, a, st, ctx, &grid);
+  else if (mfma) rc = launch_sweep_mfma(P, mode, a, smem, st, ctx, &grid);
   else if (mask_mode == kMaskPacked && general && m->p2)  // alleles 4..7: three planes
     rc = lpr == 4 ? launch_sweep_packed4_3p(P, mode, missing, general, a, smem, st, ctx, &grid) : launch_sweep_packed16_3p(P, mode, missing, general, a, smem, st, ctx, &grid);
   else if (mask_mode == kMaskPacked) rc = lpr == 4 ? launch_sweep_packed4(P, mode, missing, general, a, smem, st, ctx, &grid) : launch_sweep_packed16(P, mode, missing, general, a, smem, st, ctx, &grid);

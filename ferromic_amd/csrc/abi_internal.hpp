@@ -68,6 +68,8 @@ struct Options {
   std::atomic<long long> upload_threads{0};      // FMH_UPLOAD_THREADS: host packer threads; 0 = the CPU share
   std::atomic<long long> pd_two_planes{0}, pd_int8{0}, pd_planes_bytes{(long long)8 << 30}, pd_kchunk{0}, pd_sb{0}, pd_occ{0};  // FMH_PD_*: pairwise path
   std::atomic<long long> pipe{-1};               // FMH_PIPE: the pipelined tile loop on four-lane rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead (one and two groups)
+  std::atomic<long long> flat{-1};               // FMH_FLAT: the LDS-staged flat-tile route on short packed rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead
+  std::atomic<long long> flat_slots{0};          // FMH_FLAT_SLOTS: tile images per wave on that route (1 | 2); 0 = by the LDS a tile takes
   std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
   std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };
@@ -183,6 +185,11 @@ int launch_sweep_packed16_3p(int P, int mode, bool missing, bool general, const 
 int launch_sweep_bytes(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 int launch_sweep_bits(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 int launch_sweep_global(int P, int mode, bool missing, bool general, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
+// the LDS-staged flat-tile route (sweep_flat.hip): packed rows of at most kFlatMaskMaxVec vectors, biallelic, nothing missing
+constexpr int kFlatMaskMaxVec = 32;
+bool flat_route_builds(int P, int mode);
+inline bool flat_route_default(int P, int mode, uint32_t pvec) { (void)P; (void)mode; (void)pvec; return false; }  // until measured
+int launch_sweep_flat(int P, int mode, const fmh::SweepArgs& a, hipStream_t st, const LaunchCtx& ctx, int* grid);
 // counts on the int8 matrix cores (sweep_mfma.hip): u8 rows, biallelic, nothing missing, at most 4 (padded) groups
 int launch_sweep_mfma(int P, int mode, const fmh::SweepArgs& a, size_t smem, hipStream_t st, const LaunchCtx& ctx, int* grid);
 
@@ -215,6 +222,7 @@ struct fmh_groups {
   size_t pitch = 0;
   size_t mask_pitch = 0;     // pitch rounded up to 2048: covers the kernels' zero-padded mask stride
   uint16_t* mask_bits = nullptr;  // [padded][mask_pitch / 16]: the same masks as one 16-bit word per 16-byte vector
+  uint32_t* mask_flat = nullptr;  // [round_up(ceil(columns / 128), 4)][padded][4]: the bit masks interleaved by vector (rows of at most 4 096 columns; same block)
   uint32_t columns = 0;
   uint64_t sizes[FMH_MAX_GROUPS] = {0};
   std::vector<uint8_t> host_mask;  // [n_groups][columns] as handed in (the wide-matrix W&C route re-batches the groups)

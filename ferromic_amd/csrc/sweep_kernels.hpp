@@ -71,6 +71,8 @@ struct SweepArgs {
   const uint8_t* masks;   // device [P][mask_pitch] 0/1 bytes, zero beyond the row
   size_t mask_pitch;      // bytes per mask: pitch rounded up to 2048 (>= nvec_pad * 16)
   const uint16_t* mask_bits;  // device [P][mask_pitch / 16]: bit b of word v = column 16 v + b is a member
+  const uint32_t* mask_flat;  // flat-tile route (sweep_flat_kernels.hpp): the bit masks interleaved [vector, padded to a multiple of 4][P][4 dwords], zero beyond the row
+  int flat_slots;             // flat-tile route: tile images per wave in LDS (1 or 2)
   uint32_t group_size[8]; // mask popcounts
   uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
   int unroll;             // vectors per lane issued back to back (4 or 8)
@@ -313,11 +315,13 @@ __device__ __forceinline__ double* wc_rcp_table() {
   __shared__ double table[8 + 1 + 3 * kMaxWcSlots + kMaxWcSlots];
   return table;
 }
-template <int P>
+template <int P, int WAVES = 4>
 __device__ __forceinline__ void wc_rcp_init(const SweepArgs& A) {  // every thread of the block, before a __syncthreads()
   constexpr int NW = 1 + (P * (P - 1)) / 2;
+  constexpr int WM = WAVES - 1;  // WAVES is a power of two
+  static_assert((WAVES & (WAVES - 1)) == 0, "waves per block");
   double* table = wc_rcp_table();
-  // Wave w fills the entries I = w (mod 4): all its lanes write the same value to the same word.  The wave index is made provably
+  // Wave w fills the entries I = w (mod WAVES): all its lanes write the same value to the same word.  The wave index is made provably
   // uniform and every index into the kernel arguments is a compile-time constant of a fully unrolled loop, so each entry is a scalar
   // branch around scalar loads (a lane-dependent or runtime index made hipcc copy the 1.7 KB argument struct to scratch memory).
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -325,12 +329,12 @@ __device__ __forceinline__ void wc_rcp_init(const SweepArgs& A) {  // every thre
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     total += A.group_size[i];
-    if (wave == (i & 3)) table[i] = refined_rcp((double)A.group_size[i]);
+    if (wave == (i & WM)) table[i] = refined_rcp((double)A.group_size[i]);
   }
-  if (wave == (P & 3)) table[P] = refined_rcp((double)total);
+  if (wave == (P & WM)) table[P] = refined_rcp((double)total);
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
-    if (wave == (k & 3)) {
+    if (wave == (k & WM)) {
       table[P + 1 + 3 * k + 0] = refined_rcp(A.wc_shape[k].s2_den);
       table[P + 1 + 3 * k + 1] = refined_rcp(A.wc_shape[k].nbar_m1);
       table[P + 1 + 3 * k + 2] = refined_rcp(A.wc_shape[k].a_den);
@@ -341,7 +345,7 @@ __device__ __forceinline__ void wc_rcp_init(const SweepArgs& A) {  // every thre
   for (int x = 0; x < P; ++x) {
 #pragma unroll
     for (int y = x + 1; y < P; ++y) {
-      if (wave == (q & 3)) table[P + 1 + 3 * NW + q] = refined_rcp((double)((unsigned long long)A.group_size[x] + A.group_size[y]));
+      if (wave == (q & WM)) table[P + 1 + 3 * NW + q] = refined_rcp((double)((unsigned long long)A.group_size[x] + A.group_size[y]));
       ++q;
     }
   }
@@ -354,14 +358,14 @@ __device__ __forceinline__ double* wc_shape_table() {
   __shared__ double table[5 * kMaxWcSlots];
   return table;
 }
-template <int P>
+template <int P, int WAVES = 4>
 __device__ __forceinline__ void wc_shape_init(const SweepArgs& A) {  // every thread of the block, before a __syncthreads()
   constexpr int NW = 1 + (P * (P - 1)) / 2;
   double* table = wc_shape_table();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
-    if (wave == (k & 3)) {
+    if (wave == (k & (WAVES - 1))) {
       table[5 * k + 0] = A.wc_shape[k].s2_den;
       table[5 * k + 1] = A.wc_shape[k].rm1_over_r;
       table[5 * k + 2] = A.wc_shape[k].nbar_m1;
@@ -1215,12 +1219,13 @@ __device__ __forceinline__ void finish_biallelic_site(SiteTally<P>& mine, double
 
 // Block reduction of the per-lane regional accumulators (fixed order: lane tree, then waves 0..3) into this block's row of
 // the partial vectors.  Called once, by every thread of the block, after the tile loop.
-template <int P, int MODE>
+template <int P, int MODE, int WAVES = kWavesPerBlock>
 __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTotals<P, MODE>& T) {
+  static_assert(WAVES * 64 >= kMaxF64 + kMaxU64, "one thread per partial slot");
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  __shared__ double s_f64[kWavesPerBlock][kMaxF64];
-  __shared__ unsigned long long s_u64[kWavesPerBlock][kMaxU64];
+  __shared__ double s_f64[WAVES][kMaxF64];
+  __shared__ unsigned long long s_u64[WAVES][kMaxU64];
   auto put_f64 = [&](int slot, double v) { v = wave_sum(v); if (lane == 0) s_f64[wave][slot] = v; };
   auto put_u64 = [&](int slot, unsigned long long v) { v = wave_sum(v); if (lane == 0) s_u64[wave][slot] = v; };
   if (lane < kMaxF64) s_f64[wave][lane] = 0.0;
@@ -1258,12 +1263,12 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
   __syncthreads();
   if (threadIdx.x < kMaxF64) {
     double v = 0.0;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += s_f64[w][threadIdx.x];
+    for (int w = 0; w < WAVES; ++w) v += s_f64[w][threadIdx.x];
     A.part_f64[(size_t)blockIdx.x * kMaxF64 + threadIdx.x] = v;
   } else if (threadIdx.x < kMaxF64 + kMaxU64) {
     const int i = threadIdx.x - kMaxF64;
     unsigned long long v = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) v += s_u64[w][i];
+    for (int w = 0; w < WAVES; ++w) v += s_u64[w][i];
     A.part_u64[(size_t)blockIdx.x * kMaxU64 + i] = v;
   }
 }
