@@ -271,7 +271,10 @@ def parse_args():
                     help="N = 1: one blocking fmh_hudson_sweep per step instead of the pipelined begin / end pair on a local communicator")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
                     help="all ranks share cuda:0 (needs --transport torch --backend gloo): exercises the sharded code path on a one-GPU box")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if not 1 <= args.pipeline_depth <= 3:  # FMH_SHARDED_IN_FLIGHT - 1: one more and _begin refuses mid-run
+        ap.error("--pipeline-depth must be 1, 2 or 3 (the library keeps at most FMH_SHARDED_IN_FLIGHT = 4 sharded sweeps in flight per communicator)")
+    return args
 
 
 def main() -> int:

@@ -181,7 +181,8 @@ constexpr int kOffWcAttempted = 62;  // u64 slot of the W&C vector that carries 
 struct fmh_comm {
   int world = 1, rank = 0, device = 0;
   int transport = 0;
-  ncclComm_t nccl = nullptr;
+  ncclComm_t nccl = nullptr;  // read and cleared under nccl_mu only: fmh_comm_abort may come from any thread, while a peer thread is enqueueing on it
+  std::mutex nccl_mu;
   std::shared_ptr<HostGroup> host;
   hipStream_t stream = nullptr;  // the reduce runs here, beside the sweeps on the caller's stream
   int cus = 0, max_grid = 0;
@@ -235,7 +236,9 @@ int comm_alloc(fmh_comm* c) {
 void comm_free(fmh_comm* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+  ncclComm_t last = nullptr;
+  { std::lock_guard<std::mutex> hold(c->nccl_mu); last = c->nccl; c->nccl = nullptr; }
+  if (last && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(last);
   (void)hipFree(c->d_f64); (void)hipFree(c->d_u64);
   (void)hipHostFree(c->h_f64); (void)hipHostFree(c->h_u64);
   if (c->done) (void)hipEventDestroy(c->done);
@@ -256,6 +259,10 @@ void comm_free(fmh_comm* c) {
 int rccl_reduce_on_stream(fmh_comm* c, double* d_f64, size_t nf, unsigned long long* d_u64, size_t nu) {
   RcclApi* api = nullptr;
   FMH_TRY(rccl_api(&api));
+  // the handle stays valid while this thread enqueues on it: fmh_comm_abort takes it out of the struct under the same mutex before it calls
+  // ncclCommAbort, so an abort either comes first (error below) or waits until the enqueue has returned
+  std::lock_guard<std::mutex> hold(c->nccl_mu);
+  if (c->aborted || !c->nccl) return fail(FMH_ERR_INVALID, "the communicator was aborted");
   RCCL_TRY(api, api->GroupStart());
   if (nf) RCCL_TRY(api, api->AllReduce(d_f64, d_f64, nf, kNcclFloat64, kNcclSum, c->nccl, c->stream));
   if (nu) RCCL_TRY(api, api->AllReduce(d_u64, d_u64, nu, kNcclUint64, kNcclSum, c->nccl, c->stream));
@@ -387,10 +394,16 @@ extern "C" int fmh_comm_abort(fmh_comm* c) {
   if (!c) return fail(FMH_ERR_INVALID, "communicator is NULL");
   c->aborted = true;
   if (c->host) c->host->abort(c->rank);
-  if (c->transport == 0 && c->nccl && g_rccl.CommAbort) {
-    (void)g_rccl.CommAbort(c->nccl);  // also releases a peer thread of this process that is blocked on this communicator's stream
+  // Exactly one caller gets the handle (several slab threads of run_vcf may abort every communicator of a failed group at once): it is taken
+  // out of the struct under the mutex that rccl_reduce_on_stream holds while it enqueues, and only then aborted - never twice, never under a
+  // peer's ncclAllReduce call.
+  ncclComm_t mine = nullptr;
+  if (c->transport == 0) {
+    std::lock_guard<std::mutex> hold(c->nccl_mu);
+    mine = c->nccl;
     c->nccl = nullptr;
   }
+  if (mine && g_rccl.CommAbort) (void)g_rccl.CommAbort(mine);  // also releases a peer thread of this process that is blocked on this communicator's stream
   return FMH_OK;
 }
 
@@ -425,6 +438,8 @@ extern "C" int fmh_allreduce_totals_end(fmh_comm* c, double* h_f64, uint64_t* h_
   if (c->transport == 0) {
     FMH_TRY(use_device(c->device));
     HIP_TRY(hipEventSynchronize(c->done));
+    // ncclCommAbort ends the reduce kernels in flight, so the event completes - over unreduced values
+    if (c->aborted) return fail(FMH_ERR_INVALID, "the communicator was aborted while this reduce was in flight");
   } else if (c->transport == 1) {
     FMH_TRY(c->host->allreduce(c->rank, c->h_f64, c->pend_nf, reinterpret_cast<uint64_t*>(c->h_u64), c->pend_nu));
   }
@@ -564,6 +579,9 @@ int sharded_collect(fmh_comm* c, int kind, ShardSlot** out) {
     (void)hipGetLastError();
   }
   if (rc == FMH_OK && c->transport == 1) rc = c->host->allreduce(c->rank, s.h_f64, kMaxF64, reinterpret_cast<uint64_t*>(s.h_u64), kMaxU64);
+  // RCCL transport: ncclCommAbort ends the reduce kernels in flight and the event above completes - over unreduced totals.  The header promises
+  // that every collective on an aborted communicator fails, so it does (the slot is still released below).
+  if (rc == FMH_OK && c->transport == 0 && c->world > 1 && c->aborted) rc = fail(FMH_ERR_INVALID, "the communicator was aborted while this sweep's reduce was in flight");
   // (transport 2, a local one-rank communicator: nothing to add)
   ++c->tail;
   s.busy = false;

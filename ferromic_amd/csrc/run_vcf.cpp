@@ -1205,7 +1205,8 @@ struct ShardState {
 // so the region ends with an error on every slab and is logged as dropped.  The communicators are unusable afterwards: restore_shard_group()
 // re-creates them before the next sharded region (or leaves later regions whole when that fails).
 void abort_shard_group() {
-  g_shard.broken = true;
+  // once per failure: the peers that fail BECAUSE the group was aborted come through here too
+  if (g_shard.broken.exchange(true)) return;
   for (fmh_comm* c : g_shard.comms) if (c) fmh_comm_abort(c);
 }
 void restore_shard_group() {  // called with region_mutex held

@@ -926,6 +926,91 @@ __device__ __forceinline__ void count_row_allele(const MatrixView& mv, const voi
   for (int p = 0; p < P; ++p) c[p] = row16_sum(c[p]);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// the dense multi-allelic D_xy adds its products in FIRST-OCCURRENCE order (stats.rs:3106-3139, 2557-2590)
+// ------------------------------------------------------------------------------------------------
+// dense_hudson_sites_general / calculate_dxy_dense walk the `used` list of the population with fewer distinct alleles (ties: population 1)
+// - the alleles in the order dense_collect_counts (stats.rs:2823-2880) first met them along the population's ascending column offsets - and
+// add (c1 * inv1) * (c2 * inv2) for every allele both populations carry.  f64 addition commutes, so the order only shows in the bits when
+// THREE or more alleles are shared; the sweep's general path adds in ascending allele order and repairs exactly those sites afterwards:
+// the whole wave scans the site's row once per shared allele for its first member column (below), and the products are added again in that
+// order.  Rare on real data (a site with three alleles shared by both populations), so the cost is a uniform branch per tile elsewhere.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)x, off, 64); x = y < x ? y : x; }
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off, 64);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+}
+__device__ __forceinline__ uint32_t first_bit128(const uint4& v) {  // index of the lowest set bit of a 128-bit vector (x = bits 0..31), 0xFFFFFFFF if none
+  if (v.x) return (uint32_t)__builtin_ctz(v.x);
+  if (v.y) return 32u + (uint32_t)__builtin_ctz(v.y);
+  if (v.z) return 64u + (uint32_t)__builtin_ctz(v.z);
+  if (v.w) return 96u + (uint32_t)__builtin_ctz(v.w);
+  return 0xFFFFFFFFu;
+}
+// Column of the first CALLED member of group p that carries allele a in matrix row `row` (p, a, row wave-uniform; every lane of the wave
+// takes part, 64 vectors per trip); 0xFFFFFFFF if there is none.  Packed matrices: NPL planes; byte rows: any allele value.
+template <int MM, bool MISSING, int NPL>
+__device__ __forceinline__ uint32_t first_member_column(const MatrixView& mv, const void* __restrict__ lds_mask, uint32_t nvec_pad, size_t row, int p, uint32_t a) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t v0 = 0; v0 < mv.nvec; v0 += 64) {  // uniform trip count
+    const uint32_t v = v0 + lane;
+    uint32_t pos = 0xFFFFFFFFu;
+    if (v < mv.nvec) {
+      if constexpr (MM == kMaskPacked) {
+        uint4 ind = reinterpret_cast<const uint4*>(lds_mask)[(uint32_t)p * nvec_pad + v];
+        if (MISSING) ind = and128(ind, load_vec(mv.bits + row * mv.bits_pitch + (size_t)v * 16));
+        const uint4 x0 = load_vec(mv.data + row * mv.pitch + (size_t)v * 16);
+        ind = (a & 1u) ? and128(ind, x0) : make_uint4(ind.x & ~x0.x, ind.y & ~x0.y, ind.z & ~x0.z, ind.w & ~x0.w);
+        if constexpr (NPL >= 2) {
+          const uint4 x1 = load_vec(mv.data1 + row * mv.pitch + (size_t)v * 16);
+          ind = (a & 2u) ? and128(ind, x1) : make_uint4(ind.x & ~x1.x, ind.y & ~x1.y, ind.z & ~x1.z, ind.w & ~x1.w);
+        }
+        if constexpr (NPL >= 3) {
+          const uint4 x2 = load_vec(mv.data2 + row * mv.pitch + (size_t)v * 16);
+          ind = (a & 4u) ? and128(ind, x2) : make_uint4(ind.x & ~x2.x, ind.y & ~x2.y, ind.z & ~x2.z, ind.w & ~x2.w);
+        }
+        const uint32_t b = first_bit128(ind);
+        if (b != 0xFFFFFFFFu) pos = v * 128u + b;
+      } else {
+        const uint4 g = load_vec(mv.data + row * mv.pitch + (size_t)v * 16);
+        uint4 m = mask_vec<MM>(lds_mask, (uint32_t)p * nvec_pad + v);  // 0/1 bytes, zero beyond the row
+        if (MISSING) {
+          const uint4 cb = called_bytes(*reinterpret_cast<const uint16_t*>(mv.bits + row * mv.bits_pitch + (size_t)v * 2));
+          m = and128(m, cb);
+        }
+        const uint32_t a4 = a * 0x01010101u;
+        const uint4 e = make_uint4(eq_bytes(g.x, a4) & m.x, eq_bytes(g.y, a4) & m.y, eq_bytes(g.z, a4) & m.z, eq_bytes(g.w, a4) & m.w);
+        const uint32_t b = first_bit128(e);  // bit 8 k of the vector = byte k
+        if (b != 0xFFFFFFFFu) pos = v * 16u + (b >> 3);
+      }
+    }
+    const uint32_t best = wave_min_u32(pos);
+    if (best != 0xFFFFFFFFu) return best;  // later trips hold larger columns
+  }
+  return 0xFFFFFFFFu;
+}
+// byte rows: called members of group p carrying allele a in one row, counted by the whole wave (the rescue path of rows with alleles beyond the planes)
+template <int MM, bool MISSING>
+__device__ __forceinline__ uint32_t wave_member_count(const MatrixView& mv, const void* __restrict__ lds_mask, uint32_t nvec_pad, size_t row, int p, uint32_t a) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t c = 0;
+  const uint32_t a4 = a * 0x01010101u;
+  for (uint32_t v = lane; v < mv.nvec; v += 64) {
+    const uint4 g = load_vec(mv.data + row * mv.pitch + (size_t)v * 16);
+    uint4 m = mask_vec<MM>(lds_mask, (uint32_t)p * nvec_pad + v);
+    if (MISSING) m = and128(m, called_bytes(*reinterpret_cast<const uint16_t*>(mv.bits + row * mv.bits_pitch + (size_t)v * 2)));
+    c = dot4(eq_bytes(g.x, a4), m.x, c); c = dot4(eq_bytes(g.y, a4), m.y, c); c = dot4(eq_bytes(g.z, a4), m.z, c); c = dot4(eq_bytes(g.w, a4), m.w, c);
+  }
+  asm volatile("s_nop 3" : "+v"(c));  // dot4 result -> cross-lane read (see row16_sum)
+  return wave_sum_u32(c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // regional accumulators kept per lane
 // ------------------------------------------------------------------------------------------------
@@ -1599,6 +1684,9 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
       const size_t my_row = tile_row0 + lane;
       const bool my_ok = my_row < A.row_count;
       double inv1 = 0.0, inv2 = 0.0;
+      uint32_t shared_k = 0;  // byte rows with alleles beyond the planes: alleles both populations carry at this lane's site
+      const int hud_formula = A.hudson_formula_p1 ? A.hudson_formula_p1 - 1 : A.formula;  // as site_epilogue
+      (void)shared_k; (void)hud_formula;
       auto consume = [&](uint32_t a, const uint32_t (&c)[P], bool mine_ok, size_t out_row) {
         if (A.acounts && mine_ok) {
 #pragma unroll
@@ -1641,6 +1729,43 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
 #pragma unroll
             for (int p = 0; p < P; ++p) c4[a][p] = a <= bound ? allele_count_from_planes<NPLK>(a, mine.n[p], my_s[p]) : 0u;
         }
+        if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+          // dense formula set: the reference adds the products in first-occurrence order (see first_member_column); sites where three or more
+          // alleles are shared get their dot product again in that order
+          if (hud_formula == kFormulaDense && bound >= 2) {
+            constexpr uint32_t NA = 1u << NPLK;
+            uint32_t shared = 0;
+#pragma unroll
+            for (uint32_t a = 0; a < NA; ++a) {
+              if (a <= bound && allele_count_from_planes<NPLK>(a, mine.n[0], my_s[0]) != 0 && allele_count_from_planes<NPLK>(a, mine.n[1], my_s[1]) != 0) shared |= 1u << a;
+            }
+            const uint32_t driver = mine.distinct[0] <= mine.distinct[1] ? 0u : 1u;  // used1.len() <= used2.len()
+            unsigned long long todo = __ballot(my_ok && __builtin_popcount(shared) >= 3);
+            while (todo) {  // wave-uniform
+              const int L = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              const uint32_t sh = (uint32_t)__builtin_amdgcn_readlane((int)shared, L);
+              const int d = __builtin_amdgcn_readlane((int)driver, L);
+              const size_t frow = A.row_begin + tile_row0 + (size_t)L;
+              uint32_t fp[NA];
+#pragma unroll
+              for (uint32_t a = 0; a < NA; ++a)
+                fp[a] = ((sh >> a) & 1u) ? first_member_column<MM, MISSING, NPLK>(mv, lds_mask, nvec_pad, frow, d, a) : 0xFFFFFFFFu;
+              double dot = 0.0;  // every lane adds its own site's products in site L's order; only lane L keeps the sum
+              uint32_t left = sh;
+              while (left) {
+                uint32_t bestv = 0xFFFFFFFFu, besta = 0;
+#pragma unroll
+                for (uint32_t a = 0; a < NA; ++a)
+                  if (((left >> a) & 1u) && fp[a] <= bestv) { bestv = fp[a]; besta = a; }
+                left &= ~(1u << besta);
+                const uint32_t c0 = allele_count_from_planes<NPLK>(besta, mine.n[0], my_s[0]), c1 = allele_count_from_planes<NPLK>(besta, mine.n[1], my_s[1]);
+                dot += ((double)c0 * inv1) * ((double)c1 * inv2);
+              }
+              if (lane == L) hud_dot = dot;
+            }
+          }
+        }
       } else if constexpr (MM != kMaskPacked) {
         // byte rows carrying an allele beyond the planes (>= 4): one pass per allele value over each row, re-read from L2
         for (int s = 0; s < LPR; ++s) {
@@ -1659,7 +1784,45 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
           for (uint32_t a = 0; a <= bound; ++a) {
             uint32_t c[P];
             count_row_allele<P, MISSING, MM>(mv, lds_mask, nvec_pad, row_ptr, bits_ptr, row_ok, gl, a, c);
-            if (own) consume(a, c, row_ok, rel);
+            if (own) {
+              consume(a, c, row_ok, rel);
+              if constexpr ((MODE & kModeHudson) != 0 && P >= 2) shared_k += (c[0] != 0 && c[1] != 0) ? 1u : 0u;
+            }
+          }
+        }
+        if constexpr ((MODE & kModeHudson) != 0 && P >= 2) {
+          // the same repair for byte rows with alleles beyond the planes: no per-allele table fits in registers, so the wave looks for the
+          // next first-seen shared allele round by round (each round: one scan of the row per allele value) and recounts it
+          if (hud_formula == kFormulaDense) {
+            const uint32_t driver = mine.distinct[0] <= mine.distinct[1] ? 0u : 1u;
+            unsigned long long todo = __ballot(my_ok && shared_k >= 3);
+            while (todo) {
+              const int L = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              const int d = __builtin_amdgcn_readlane((int)driver, L);
+              const uint32_t rounds = (uint32_t)__builtin_amdgcn_readlane((int)shared_k, L);
+              const double i1 = 1.0 / (double)(uint32_t)__builtin_amdgcn_readlane((int)mine.n[0], L);
+              const double i2 = 1.0 / (double)(uint32_t)__builtin_amdgcn_readlane((int)mine.n[1], L);
+              const size_t frow = A.row_begin + tile_row0 + (size_t)L;
+              double dot = 0.0;
+              uint32_t prev = 0;
+              for (uint32_t r = 0; r < rounds; ++r) {
+                uint32_t bestv = 0xFFFFFFFFu, besta = 0;
+                for (uint32_t a = 0; a <= bound; ++a) {
+                  const uint32_t f = first_member_column<MM, MISSING, 2>(mv, lds_mask, nvec_pad, frow, d, a);
+                  if (f == 0xFFFFFFFFu || (r != 0 && f <= prev) || f >= bestv) continue;
+                  if (wave_member_count<MM, MISSING>(mv, lds_mask, nvec_pad, frow, 1 - d, a) == 0) continue;  // not shared
+                  bestv = f;
+                  besta = a;
+                }
+                if (bestv == 0xFFFFFFFFu) break;
+                const uint32_t c0 = wave_member_count<MM, MISSING>(mv, lds_mask, nvec_pad, frow, 0, besta);
+                const uint32_t c1 = wave_member_count<MM, MISSING>(mv, lds_mask, nvec_pad, frow, 1, besta);
+                dot += ((double)c0 * i1) * ((double)c1 * i2);
+                prev = bestv;
+              }
+              if (lane == L) hud_dot = dot;
+            }
           }
         }
       }

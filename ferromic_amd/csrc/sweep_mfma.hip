@@ -20,14 +20,15 @@ int launch_mfma(const SweepArgs& args, size_t smem, hipStream_t st, const Launch
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, smem));
     if (occ < 1) occ = 1;
     if (occ > 8) occ = 8;
-    const int env_occ = (int)options().max_occ.load();
-    if (env_occ > 0 && occ > env_occ) occ = env_occ;
     cached_occ[dev] = occ;
     cached_smem[dev] = smem;
   }
+  // FMH_MAX_OCC is applied per launch, outside the cache: fmh_set_option may change it at any time (tools/ab_env.py alternates it)
+  int occ_now = cached_occ[dev];
+  if (const int env_occ = (int)options().max_occ.load(); env_occ > 0 && occ_now > env_occ) occ_now = env_occ;
   const size_t ntiles = (args.row_count + kTileRows - 1) / kTileRows;
   size_t blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-  size_t cap = (size_t)ctx.cus * cached_occ[dev];
+  size_t cap = (size_t)ctx.cus * occ_now;
   if (const long long v = options().grid_per_cu.load(); v > 0) cap = (size_t)ctx.cus * (size_t)v;  // the same grid options as the other routes
   if (const long long v = options().grid_blocks.load(); v > 0) cap = (size_t)v;
   if (blocks > cap) blocks = cap;  // persistent grid (equalising the tile rounds per workgroup was measured: fewer resident waves, slower)

@@ -404,8 +404,9 @@ int fmh_hudson_sweep_sharded(fmh_comm* c, const fmh_matrix* m, const fmh_groups*
  * The same pipeline for the other two regional reductions north_star names ("RCCL reduce ... for the sum-a / sum-b and global pi
  * accumulators"): sweep -> finalise on the device -> grouped ncclAllReduce of the 64 + 64 accumulators on the communicator's stream ->
  * one D2H; no host hop, FMH_SHARDED_IN_FLIGHT sweeps of ANY kind may be in flight per communicator and each _end collects the oldest
- * (it must be of its kind).  W&C: calculate_overall_fst_wc's sums (stats.rs:2145-2374) - two to four groups run as one fused kernel; five
- * to eight groups, or rows too wide for all masks, run the blocking fmh_wc_sweep inside _begin and only the reduce is pipelined.
+ * (it must be of its kind).  W&C: calculate_overall_fst_wc's sums (stats.rs:2145-2374) - two to eight groups run as one fused kernel (five
+ * to eight: with alleles up to 3); more than 3 alleles with five to eight groups, or rows too wide for all masks, run the blocking fmh_wc_sweep
+ * inside _begin and only the reduce is pipelined.
  * Population summaries: build_dense_population_summary's scalars (stats.rs:1367-1470) for up to FMH_MAX_GROUPS populations.
  * Per-site tracks stay on the rank that owns the rows; haplotype_capacity is the local mask popcount (identical on every rank).
  */

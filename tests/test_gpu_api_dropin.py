@@ -16,20 +16,21 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def build_variant(position, genotypes):
-    return {"position": position, "genotypes": genotypes}
+def variant_record(pos, calls):
+    """One variant as the module's input coercion takes it (lib.rs:825-1367): a mapping with `position` and per-sample `genotypes`."""
+    return dict(position=pos, genotypes=calls)
+
+
+build_variant = variant_record
 
 
 # ---- src/pytests/test_ferromic.py ----------------------------------------------------------------
 
 
-def test_segregating_sites_counts_polymorphic_sites():
-    variants = [
-        build_variant(100, [[0, 0], [0, 1]]),
-        build_variant(150, [[0, 0], [0, 0]]),
-        build_variant(200, [[0, 1], [1, 1]]),
-    ]
-    assert fm.segregating_sites(variants) == 2
+def test_segregating_sites_on_the_reference_vectors(kats):
+    for case in kats["count_segregating_sites"]["cases"]:
+        records = [variant_record(v["pos"], v["g"]) for v in case["variants"]]
+        assert fm.segregating_sites(records) == case["expected"], case
 
 
 def test_population_from_numpy_accepts_python_positions(kats):

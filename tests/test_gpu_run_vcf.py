@@ -87,6 +87,49 @@ def write_case(tmp, k):
                 config_file=str(tmp / "config.tsv"), enable_fst=k["enable_fst"])
 
 
+def write_cli_integration_case(tmp, k):
+    """The files test_variant_filtering_cli_integration writes (filter_tests.rs:82-246), from the fixture's texts and recipes, plus the
+    .fai that `samtools faidx` would put next to the FASTA (the reference opens it through an indexed reader, process.rs:1917)."""
+    os.makedirs(tmp / "vcfs_test", exist_ok=True)
+    (tmp / "test_allow.tsv").write_text(k["allow"])
+    (tmp / "test_config.tsv").write_text(k["config"])
+    for name, body in k["vcfs"].items():
+        (tmp / "vcfs_test" / name).write_text(k["vcf_header"] + body)
+    rec = k["fasta_recipe"]
+    seq = rec["unit"] * rec["repeat"]
+    fasta, fai, gtf, off = "", "", "", 0
+    for c in rec["chromosomes"]:
+        hdr = f">{c}\n"
+        fai += f"{c}\t{len(seq)}\t{off + len(hdr)}\t{len(seq)}\t{len(seq) + 1}\n"
+        fasta += hdr + seq + "\n"
+        off += len(hdr) + len(seq) + 1
+        gtf += f'{c}\t.\tgene\t1\t1000\t.\t+\t.\tgene_id "gene_{c}"; gene_name "gene_{c}";\n'
+    (tmp / "reference.fasta").write_text(fasta)
+    (tmp / "reference.fasta.fai").write_text(fai)
+    (tmp / "annotations.gtf").write_text(gtf)
+    return dict(vcf_folder=str(tmp / "vcfs_test"), reference=str(tmp / "reference.fasta"), gtf=str(tmp / "annotations.gtf"),
+                config_file=str(tmp / "test_config.tsv"), allow_file=str(tmp / "test_allow.tsv"), min_gq=k["args"]["min_gq"])
+
+
+def test_reference_cli_integration_case(tmp_path, kats):
+    """The reference's own CLI integration input (12-row config with _lowconf suffixes and non-pass verdicts, an allow file with a chromosome
+    that has no line for one entry, three tiny VCFs with GQ < 30 rows, entries on a chromosome without a VCF): run_vcf against the oracle's
+    restatement cell for cell, the FALSTA tracks byte for byte, and the reference test's own (weak) asserts."""
+    k = kats["cli_integration_filtering"]
+    kw = write_cli_integration_case(tmp_path, k)
+    exp = V.run(output_file=str(tmp_path / "oracle" / "output_stats.csv"), **kw)
+    got = run_binary(str(tmp_path / "gpu" / "output_stats.csv"), **kw)
+    compare(got, exp)
+    csv_text = got["output_stats.csv"]
+    assert csv_text and any(word in csv_text for word in k["expect"]["output_contains_any"])
+    # without the index the reference stops at the indexed reader (process.rs:1917); so does run_vcf, with a message that names the file
+    os.remove(kw["reference"] + ".fai")
+    cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--config_file", kw["config_file"],
+           "--output_file", str(tmp_path / "gpu2" / "o.csv"), "--min_gq", "30", "--allow_file", kw["allow_file"]]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_PROGRESS="0"), timeout=300)
+    assert "reference.fasta.fai" in res.stderr + res.stdout
+
+
 @pytest.mark.parametrize("case", ["falsta_zero_fill", "falsta_hudson_tracks"])
 def test_reference_end_to_end_cases(tmp_path, kats, case):
     kw = write_case(tmp_path, kats[case])

@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 from oracle import run_vcf_ref as V
-from tests.test_gpu_run_vcf import BIN, make_cohort
+from tests.test_gpu_run_vcf import BIN, make_cohort, write_cli_integration_case
 
 
 def oracle_digests(kw, min_gq=30, mask_file=None, allow_file=None, exclude=()):
@@ -28,8 +28,11 @@ def oracle_digests(kw, min_gq=30, mask_file=None, allow_file=None, exclude=()):
         final_mask = {k: list(v) for k, v in (mask or {}).items()}
         final_mask.setdefault(chrom, []).extend(V.find_n_regions(seq))
         hulls = [(max(e.interval[0] - 3_000_000, 0), min(e.interval[1] + 3_000_000, len(seq))) for e in by_chr[chrom]]
-        variants, flags, names = V.process_vcf(V.find_vcf_file(kw["vcf_folder"], chrom), chrom, V.merge_intervals(hulls), min_gq, final_mask,
-                                               allow, set(exclude))
+        try:
+            vcf_path = V.find_vcf_file(kw["vcf_folder"], chrom)
+        except Exception:
+            continue  # no VCF for this chromosome: its entries are skipped (process.rs:2001-2010)
+        variants, flags, names = V.process_vcf(vcf_path, chrom, V.merge_intervals(hulls), min_gq, final_mask, allow, set(exclude))
         h = 1469598103934665603
         for v, fl in zip(variants, flags):
             for b in list(int(v.position).to_bytes(8, "little", signed=True)) + [fl, v.genotypes.stride] + list(v.genotypes.data):
@@ -73,6 +76,22 @@ def test_ingest_matches_oracle_parse(tmp_path, storage):
            for m in re.finditer(r"\[INGEST\] chr (\S+): (\d+) variants x (\d+) samples digest ([0-9a-f]{16})", res.stdout)}
     exp = oracle_digests(kw, min_gq=31, mask_file=str(tmp_path / "mask.bed"), allow_file=str(tmp_path / "allow.tsv"))
     assert got == exp and len(got) == 3
+
+
+def test_ingest_of_the_reference_cli_integration_input(tmp_path, kats):
+    """The input of the reference's CLI integration test (filter_tests.rs:82-246) through the ingest stage: chromosomes without a VCF (chr1)
+    are skipped, the others give the oracle's variants, flags (GQ < 30, outside the allow list) and sample lists."""
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    kw = write_cli_integration_case(tmp_path, kats["cli_integration_filtering"])
+    cmd = [BIN, "--vcf_folder", kw["vcf_folder"], "--reference", kw["reference"], "--gtf", kw["gtf"], "--config_file", kw["config_file"],
+           "--output_file", str(tmp_path / "out" / "o.csv"), "--allow_file", kw["allow_file"], "--min_gq", "30", "--ingest_only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, FERROMIC_PROGRESS="0", FERROMIC_THREADS="2"), timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = {m.group(1): (int(m.group(2)), int(m.group(3)), m.group(4))
+           for m in re.finditer(r"\[INGEST\] chr (\S+): (\d+) variants x (\d+) samples digest ([0-9a-f]{16})", res.stdout)}
+    exp = oracle_digests(kw, min_gq=30, allow_file=kw["allow_file"])
+    assert got == exp and set(got) == {"17", "22", "3"}, (got, exp)
 
 
 def test_cli_region_argument_matches_reference_rules(tmp_path, kats):

@@ -13,7 +13,9 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int NV, bool READ, bool WRITE>
+// DEFER > 1: a wave reads DEFER of its tiles back to back and only then writes their tracks (what deferring the epilogues of a real kernel does to
+// its traffic: the same bytes, bursts of DEFER x tracks stores per wave instead of `tracks` stores after every tile)
+template <int NV, bool READ, bool WRITE, int DEFER = 1>
 __global__ __launch_bounds__(256) void ceiling_kernel(const uint8_t* __restrict__ data, size_t rows, int n_f64, int n_u32, int n_u8,
                                                       double* __restrict__ o64, uint32_t* __restrict__ o32, uint8_t* __restrict__ o8,
                                                       unsigned long long* __restrict__ sink) {
@@ -21,20 +23,30 @@ __global__ __launch_bounds__(256) void ceiling_kernel(const uint8_t* __restrict_
   const size_t ntiles = rows / 64;
   const size_t wave_id = (size_t)blockIdx.x * 4 + wave, nwaves = (size_t)gridDim.x * 4;
   unsigned acc = 0;
-  for (size_t tile = wave_id; tile < ntiles; tile += nwaves) {
+  for (size_t tile0 = wave_id; tile0 < ntiles; tile0 += nwaves * DEFER) {
     if (READ) {
-      const uint8_t* base = data + tile * (size_t)(NV * 1024) + (size_t)lane * 16;
-      uint4 x[NV];
+#pragma unroll 1
+      for (int b = 0; b < DEFER; ++b) {
+        const size_t tile = tile0 + (size_t)b * nwaves;
+        if (tile >= ntiles) break;
+        const uint8_t* base = data + tile * (size_t)(NV * 1024) + (size_t)lane * 16;
+        uint4 x[NV];
 #pragma unroll
-      for (int c = 0; c < NV; ++c) x[c] = *reinterpret_cast<const uint4*>(base + (size_t)c * 1024);
+        for (int c = 0; c < NV; ++c) x[c] = *reinterpret_cast<const uint4*>(base + (size_t)c * 1024);
 #pragma unroll
-      for (int c = 0; c < NV; ++c) acc += x[c].x ^ x[c].y ^ x[c].z ^ x[c].w;
+        for (int c = 0; c < NV; ++c) acc += x[c].x ^ x[c].y ^ x[c].z ^ x[c].w;
+      }
     }
     if (WRITE) {
-      const size_t site = tile * 64 + lane;
-      for (int k = 0; k < n_u32; ++k) __builtin_nontemporal_store(acc, o32 + (size_t)k * rows + site);
-      for (int k = 0; k < n_f64; ++k) __builtin_nontemporal_store((double)acc, o64 + (size_t)k * rows + site);
-      for (int k = 0; k < n_u8; ++k) __builtin_nontemporal_store((uint8_t)acc, o8 + (size_t)k * rows + site);
+#pragma unroll 1
+      for (int b = 0; b < DEFER; ++b) {
+        const size_t tile = tile0 + (size_t)b * nwaves;
+        if (tile >= ntiles) break;
+        const size_t site = tile * 64 + lane;
+        for (int k = 0; k < n_u32; ++k) __builtin_nontemporal_store(acc, o32 + (size_t)k * rows + site);
+        for (int k = 0; k < n_f64; ++k) __builtin_nontemporal_store((double)acc, o64 + (size_t)k * rows + site);
+        for (int k = 0; k < n_u8; ++k) __builtin_nontemporal_store((uint8_t)acc, o8 + (size_t)k * rows + site);
+      }
     }
   }
   if (acc == 0xFFFFFFFFu) sink[0] = acc;
@@ -50,13 +62,17 @@ void run_all(const uint8_t* data, size_t rows, int n_f64, int n_u32, int n_u8, d
   for (int a = 6; a < argc || a == 6; ++a) {
     const int per_cu = a < argc ? atoi(argv[a]) : 4;
     const int grid = cus * per_cu;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
       float best = 1e9f;
       for (int rep = 0; rep < 30; ++rep) {
         CHECK(hipEventRecord(e0));
         if (mode == 0) hipLaunchKernelGGL((ceiling_kernel<NV, true, false>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
         if (mode == 1) hipLaunchKernelGGL((ceiling_kernel<NV, true, true>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
         if (mode == 2) hipLaunchKernelGGL((ceiling_kernel<NV, false, true>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
+        if (mode == 3) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 2>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
+        if (mode == 4) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 4>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
+        if (mode == 5) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 8>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
+        if (mode == 6) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 16>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -66,7 +82,7 @@ void run_all(const uint8_t* data, size_t rows, int n_f64, int n_u32, int n_u8, d
       const double bytes = (mode != 2 ? rd : 0.0) + (mode != 0 ? wr : 0.0);
       printf("{\"mode\": \"%s\", \"rows\": %zu, \"pitch\": %d, \"f64_tracks\": %d, \"u32_tracks\": %d, \"u8_tracks\": %d, \"workgroups_per_cu\": %d, \"best_ms\": %.4f, \"GBs\": %.0f, "
              "\"frac_of_8TBs\": %.3f}\n",
-             mode == 0 ? "read" : mode == 1 ? "read+tracks" : "tracks", rows, NV * 16, n_f64, n_u32, n_u8, per_cu, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
+             mode == 0 ? "read" : mode == 1 ? "read+tracks" : mode == 2 ? "tracks" : mode == 3 ? "read+tracks defer 2" : mode == 4 ? "read+tracks defer 4" : mode == 5 ? "read+tracks defer 8" : "read+tracks defer 16", rows, NV * 16, n_f64, n_u32, n_u8, per_cu, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
       fflush(stdout);
     }
   }
