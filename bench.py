@@ -269,6 +269,13 @@ def parse_args():
                     help="N > 1, strong scaling: skip rank 0's own sweep of the whole cohort after the timed region (parity_vs_n1.computed)")
     ap.add_argument("--sync-steps", action="store_true",
                     help="N = 1: one blocking fmh_hudson_sweep per step instead of the pipelined begin / end pair on a local communicator")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs driven by ONE process: N host threads, fmh_comm_init_all over --devices (default 0..N-1), the same pipelined "
+                         "fmh_hudson_sweep_sharded_begin / _end loop and the same comm / per_rank / parity_vs_n1 evidence as the launcher route - the route "
+                         "run_vcf --devices takes; needs neither torch.distributed.run nor gloo")
+    ap.add_argument("--devices", default=None,
+                    help="--single-process: comma-separated device indices, one rank each (default 0..gpus-1); a device listed twice selects the "
+                         "library's in-process host rendezvous (the rehearsal of N > 1 on a one-GPU box)")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
                     help="all ranks share cuda:0 (needs --transport torch --backend gloo): exercises the sharded code path on a one-GPU box")
     args = ap.parse_args()
@@ -277,8 +284,187 @@ def parse_args():
     return args
 
 
+def main_single_process(args) -> int:
+    """One process, one host thread per GPU, the library's own communicators (fmh_comm_init_all): what run_vcf --devices does, with the
+    bench's step structure.  The threads exist before anything touches a GPU; if the RCCL communicators cannot be created the run goes
+    through the library's in-process host rendezvous instead, says so (config.transport_fallback) and exits 3 after printing the line."""
+    import threading
+
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    world = len(devices)
+    args.gpus = world
+    H = args.haplotypes
+    if H % 2:
+        raise SystemExit("haplotypes must be even (diploid samples)")
+    N = H // 2
+    poc = np.repeat((np.arange(N) >= N // 2).astype(np.uint8), 2)
+    masks = np.stack([(poc == 0), (poc == 1)]).astype(np.uint8)
+    gate = threading.Barrier(world + 1)   # main <-> workers: communicators are ready (or the run is off)
+    sync = threading.Barrier(world)       # the workers among themselves: both sides of the timed region
+    shared = {"comms": None, "abort": False}
+    reports = [None] * world
+    errors = [None] * world
+
+    def worker(r):
+        try:
+            gate.wait()
+            if shared["abort"]:
+                return
+            from ferromic_amd import _abi, device, sharding
+
+            lib = _abi.load()
+            comm, dev = shared["comms"][r], devices[r]
+            if args.scaling == "strong":
+                total = args.sites
+                begin, end = sharding.slab_for_rank(total, r, world)
+            else:
+                total = args.sites * world
+                begin, end = r * args.sites, (r + 1) * args.sites
+            S = end - begin
+            seed = total + N
+            thr = synthetic_thresholds(S, begin, seed)
+            dm = device.DeviceMatrix.alloc(S, N, 2, with_missing=False, max_allele=1, device=dev)
+            dm.generate(seed, begin, thr, poc, 0)
+            if args.layout == "packed":
+                dm.pack(release_bytes=True)
+            groups = device.Groups(dm, masks)
+            bufs = {n: device.DeviceBuffer(dev, 8 * max(S, 1)) for n in ("dxy", "pi1", "pi2", "num", "den")}
+            bufs["alt"] = device.DeviceBuffer(dev, 4 * 2 * max(S, 1))
+            bufs["called"] = device.DeviceBuffer(dev, 4 * 2 * max(S, 1))
+            sites = _abi.HudsonSites(None, bufs["dxy"].ptr, bufs["pi1"].ptr, bufs["pi2"].ptr, bufs["num"].ptr, bufs["den"].ptr, bufs["alt"].ptr, bufs["called"].ptr)
+            totals = _abi.HudsonTotals()
+            in_flight = 0
+
+            def run_steps(k):
+                nonlocal in_flight
+                for _ in range(k):
+                    _abi.check(lib.fmh_hudson_sweep_sharded_begin(comm._h, dm._h, groups._h, 0, S, _abi.FORMULA_DENSE, C.byref(sites), None))
+                    in_flight += 1
+                    if in_flight > args.pipeline_depth:
+                        _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(totals)))
+                        in_flight -= 1
+                while in_flight > 0:
+                    _abi.check(lib.fmh_hudson_sweep_sharded_end(comm._h, C.byref(totals)))
+                    in_flight -= 1
+                _abi.check(lib.fmh_stream_synchronize(dev, None))
+
+            run_steps(args.warmup)
+            sync.wait()
+            if r == 0:
+                lib.fmh_timing_enable(max(1, args.timing_sample))
+                lib.fmh_timing_reset()
+                lib.fmh_timing_reset_reduce()
+            sync.wait()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            mine_elapsed = time.perf_counter() - t0
+            sync.wait()
+            elapsed = time.perf_counter() - t0  # barrier + device synchronisation on both sides: the slowest rank's time
+            reports[r] = {"rank": r, "device": dev, "slab": [begin, end], "sites": S, "elapsed_ms_per_step": mine_elapsed / args.steps * 1e3,
+                          "elapsed": elapsed, "total": total, "seed": seed, "totals": totals, "comm": comm.describe(), "keep": (dm, groups, bufs)}
+        except BaseException as exc:  # noqa: BLE001 - reported by the main thread; the peers are released through the communicators' abort
+            errors[r] = exc
+            shared["abort"] = True
+            try:
+                for c in shared["comms"] or []:
+                    c.abort()
+            except Exception:  # noqa: BLE001
+                pass
+            for b in (gate, sync):
+                b.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    # ---- only now the first GPU call -----------------------------------------------------------------------------------------
+    from ferromic_amd import _abi, sharding
+
+    lib = _abi.load()
+    transport_note = None
+    try:
+        shared["comms"] = sharding.Comm.init_all(devices)
+    except Exception as exc:  # noqa: BLE001 - RCCL could not come up: the in-process rendezvous carries the sums, and the line says so
+        transport_note = f"fmh_comm_init_all over RCCL failed ({type(exc).__name__}: {exc}); accumulators summed through the library's in-process host rendezvous"
+        print("bench.py: " + transport_note, file=sys.stderr)
+        try:
+            with _abi.options(FMH_COMM_TRANSPORT="host"):
+                shared["comms"] = sharding.Comm.init_all(devices)
+        except Exception as exc2:  # noqa: BLE001
+            shared["abort"] = True
+            gate.wait()
+            print(f"bench.py: no communicator could be created: {exc2}", file=sys.stderr)
+            return 2
+    gate.wait()
+    for t in threads:
+        t.join()
+    failed = [(r, e) for r, e in enumerate(errors) if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if failed or any(rep is None for rep in reports):
+        for r, e in failed:
+            print(f"bench.py: rank {r} failed: {type(e).__name__}: {e}", file=sys.stderr)
+        return 2
+    kernel_ms, launches, kmin, kmax = C.c_double(), C.c_uint64(), C.c_double(), C.c_double()
+    lib.fmh_timing_read(C.byref(kernel_ms), C.byref(launches))
+    lib.fmh_timing_read_minmax(C.byref(kmin), C.byref(kmax))
+    red_ms, red_n = C.c_double(), C.c_uint64()
+    lib.fmh_timing_read_reduce(C.byref(red_ms), C.byref(red_n))
+    lib.fmh_timing_enable(0)
+    avg_kernel_s = kernel_ms.value / 1e3 / max(launches.value, 1)
+    first = reports[0]
+    elapsed = max(rep["elapsed"] for rep in reports)
+    totals, total, S = first["totals"], first["total"], first["sites"]
+    packed = args.layout == "packed"
+    b_site = ((H + 7) // 8 if packed else H) + W_OUT_HUDSON
+    achieved = b_site * S / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    comm_report = dict(first["comm"], source="fmh_comm_describe (libferromic_hip.so)")
+    per_rank = []
+    for rep in reports:
+        # one process: the library's sweep / reduce timers are process-wide, so every rank carries the all-rank figures (equal slabs)
+        per_rank.append({"rank": rep["rank"], "device": rep["device"], "slab": rep["slab"], "sites": rep["sites"], "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "kernel_ms_min": kmin.value, "kernel_ms_max": kmax.value, "kernel_launches_timed": int(launches.value),
+                         "reduce_ms_avg": (red_ms.value / red_n.value) if red_n.value else None, "reduces_timed": int(red_n.value),
+                         "elapsed_ms_per_step": rep["elapsed_ms_per_step"],
+                         "comm": {k: rep["comm"].get(k) for k in ("transport", "world", "rank", "device")}})
+    reduce_name = {"rccl": "RCCL (ncclAllReduce issued by libferromic_hip.so on each communicator's stream)",
+                   "host": "the library's in-process host rendezvous", "local": "nothing (one rank)"}.get(str(comm_report.get("transport")), str(comm_report.get("transport")))
+    result = {
+        "metric": "variant-sites/sec (pi + Hudson FST)", "value": total * args.steps / elapsed, "unit": "sites/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "u1" if packed else "u8", "data": "synthetic",
+        "config": {"workload": f"C4 fused per-site pi + Hudson FST sweep: {total} sites x {H} haplotypes, {S} sites on each of {world} ranks, 2 populations, biallelic, "
+                               "no missing data, matrix resident in HBM " + ("bit-packed" if packed else "as u8 rows"),
+                   "total_sites": total, "sites_per_gpu": S, "haplotypes": H, "populations": 2, "seed": first["seed"], "layout": args.layout,
+                   "devices": devices, "launcher": "none: one process, one host thread per rank, fmh_comm_init_all",
+                   "parallelism": f"region-sharded x{world} from ONE process: one contiguous slab per rank, per-site tracks stay on the owning GPU, the 128 regional accumulators "
+                                  f"summed by {reduce_name}, every host thread {args.pipeline_depth} steps ahead of its oldest uncollected reduce",
+                   **({"transport_fallback": transport_note} if transport_note else {})},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "traffic_source": "none: not collected on the single-process route", "kernel_ms_avg": avg_kernel_s * 1e3,
+                     "kernel_launches_timed": int(launches.value), "timing_sample": max(1, args.timing_sample), "kernel_sites_per_launch": S,
+                     "algorithmic_bytes_per_site": b_site},
+        "results": {"hudson_fst": totals.numerator_sum / totals.denominator_sum if totals.denominator_sum > 1e-12 else None,
+                    "segregating_sites": [int(totals.pop[0].segregating_sites), int(totals.pop[1].segregating_sites)],
+                    "sites_with_components": int(totals.sites_with_components), "dxy_uncallable_sites": int(totals.dxy_uncallable_sites),
+                    "pi_sum": [totals.pop[0].pi_sum, totals.pop[1].pi_sum]},
+        "comm": dict(comm_report, per_rank=per_rank, ranks_reporting=len(per_rank), kernel_ms_avg_min_over_ranks=avg_kernel_s * 1e3,
+                     kernel_ms_avg_max_over_ranks=avg_kernel_s * 1e3, reduce_ms_avg_max_over_ranks=(red_ms.value / red_n.value) if red_n.value else None,
+                     reduce_note="HIP events on the communicators' streams around ncclGroupStart .. ncclGroupEnd (process-wide average); null on the host rendezvous"),
+    }
+    for rep in reports[1:]:  # every rank must hold the same all-rank totals
+        t = rep["totals"]
+        assert int(t.pop[0].segregating_sites) == int(totals.pop[0].segregating_sites) and t.numerator_sum == totals.numerator_sum, "ranks disagree on the reduced totals"
+    for rep in reports:
+        rep["keep"] = None  # release the slabs before rank 0 sweeps the whole cohort
+    result["parity_vs_n1"] = parity_vs_n1(args, {"scaling": args.scaling, "total_sites": total, "seed": first["seed"]}, totals, 0, world, devices[0], lib, masks, poc, N, H)
+    print(json.dumps(result), flush=True)
+    for c in shared["comms"]:
+        c.close()
+    return 3 if transport_note else 0
+
+
 def main() -> int:
     args = parse_args()
+    if args.single_process:
+        return main_single_process(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started plainly with --gpus N: become the launcher (nothing has touched the GPU yet) and hand the job to N ranks
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",

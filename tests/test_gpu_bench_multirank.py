@@ -101,6 +101,36 @@ def test_rccl_collective_path_with_one_rank():
     assert u8["roofline"]["algorithmic_bytes_per_site"] == 1056 and u8["dtype"] == "u8"
 
 
+def test_single_process_route():
+    """`bench.py --single-process`: one process, one host thread per rank, fmh_comm_init_all - the route run_vcf --devices takes, without
+    torch.distributed.run or gloo.  [0]: the library's RCCL communicator with one rank; [0, 0]: two ranks on the in-process host rendezvous
+    (RCCL cannot place two ranks on one device).  Both carry the same evidence as the launcher route and agree with one plain rank."""
+    S = 300_000
+    common = ["--steps", "3", "--warmup", "1", "--haplotypes", "1000", "--no-cpu-baseline", "--sites", str(2 * S)]
+    one = run([sys.executable, "bench.py"] + common)
+    rccl = run([sys.executable, "bench.py", "--single-process", "--devices", "0"] + common)
+    c = rccl["comm"]
+    assert rccl["n_gpus"] == 1 and c["transport"] == "rccl" and c["world"] == 1 and "rccl" in str(c["rccl_library"]).lower() and c["source"].startswith("fmh_comm_describe")
+    assert c["ranks_reporting"] == 1 and c["per_rank"][0]["slab"] == [0, 2 * S] and c["per_rank"][0]["reduces_timed"] >= 1 and c["per_rank"][0]["reduce_ms_avg"] > 0
+    assert rccl["results"] == one["results"] and "launcher" in rccl["config"] and "transport_fallback" not in rccl["config"]
+    assert rccl["parity_vs_n1"]["computed"]["ok"] is True
+    host = run([sys.executable, "bench.py", "--single-process", "--gpus", "2", "--devices", "0,0"] + common)
+    c = host["comm"]
+    assert host["n_gpus"] == 2 and c["transport"] == "host" and c["world"] == 2 and c["ranks_reporting"] == 2
+    assert [r["rank"] for r in c["per_rank"]] == [0, 1] and [r["slab"] for r in c["per_rank"]] == [[0, S], [S, 2 * S]]
+    for r in c["per_rank"]:
+        assert r["sites"] == S and r["kernel_launches_timed"] >= 1 and 0 < r["kernel_ms_min"] <= r["kernel_ms_avg"] <= r["kernel_ms_max"] and r["elapsed_ms_per_step"] > 0
+        assert r["comm"]["world"] == 2 and r["comm"]["transport"] == "host"
+    assert host["value"] == pytest.approx(2 * S * 3 / (host["ms_per_step"] * 3 / 1e3), rel=1e-6)
+    assert host["results"]["segregating_sites"] == one["results"]["segregating_sites"]
+    assert host["results"]["hudson_fst"] == pytest.approx(one["results"]["hudson_fst"], rel=1e-9)
+    pv = host["parity_vs_n1"]
+    assert pv["mode"] == "strong" and pv["computed"]["ok"] is True and pv["computed"]["hudson_fst_rel_err"] <= 1e-9 and pv["computed"]["pi_sum_rel_err"] <= 1e-9
+    weak = run([sys.executable, "bench.py", "--single-process", "--devices", "0,0", "--scaling", "weak", "--steps", "2", "--warmup", "1", "--haplotypes", "400",
+                "--sites", "100000", "--no-cpu-baseline"])
+    assert weak["scaling"] == "weak" and weak["config"]["total_sites"] == 200000 and weak["config"]["sites_per_gpu"] == 100000
+
+
 def test_bench_line_contract():
     """The one JSON line the driver parses: every field of the contract, with the roofline and cpu_baseline objects."""
     d = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--sites", "200000", "--haplotypes", "400", "--cpu-sample-sites", "50000"])
