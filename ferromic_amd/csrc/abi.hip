@@ -77,6 +77,7 @@ const OptionRow kOptionRows[] = {
     {"FMH_GRAPH", &Options::graph, 0, nullptr},
     {"FMH_FLAT", &Options::flat, -1, nullptr},
     {"FMH_FLAT_SLOTS", &Options::flat_slots, 0, nullptr},
+    {"FMH_FLAT_DEFER", &Options::flat_defer, 0, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -917,6 +918,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   a.mask_bits = g->mask_bits;
   a.mask_flat = g->mask_flat;
   a.flat_slots = 0;
+  a.flat_defer = 1;
   for (int p = 0; p < 8; ++p) a.group_size[p] = p < g->n_groups ? (uint32_t)g->sizes[p] : 0;
   a.n_groups = g->n_groups;
   a.max_allele = m->max_allele;

@@ -69,7 +69,8 @@ struct Options {
   std::atomic<long long> pd_two_planes{0}, pd_int8{0}, pd_planes_bytes{(long long)8 << 30}, pd_kchunk{0}, pd_sb{0}, pd_occ{0};  // FMH_PD_*: pairwise path
   std::atomic<long long> pipe{-1};               // FMH_PIPE: the pipelined tile loop on four-lane rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead (one and two groups)
   std::atomic<long long> flat{-1};               // FMH_FLAT: the LDS-staged flat-tile route on short packed rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead
-  std::atomic<long long> flat_slots{0};          // FMH_FLAT_SLOTS: tile images per wave on that route (1 | 2); 0 = by the LDS a tile takes
+  std::atomic<long long> flat_slots{0};          // FMH_FLAT_SLOTS: 0 = the register-staged variant (default); 1 | 2 = the LDS-DMA variants with that many tile images per wave
+  std::atomic<long long> flat_defer{0};          // FMH_FLAT_DEFER: tiles a wave counts before it runs their epilogues on the register-staged variant (1..8); 0 = by the launch size
   std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
   std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };

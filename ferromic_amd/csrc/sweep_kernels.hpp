@@ -72,7 +72,8 @@ struct SweepArgs {
   size_t mask_pitch;      // bytes per mask: pitch rounded up to 2048 (>= nvec_pad * 16)
   const uint16_t* mask_bits;  // device [P][mask_pitch / 16]: bit b of word v = column 16 v + b is a member
   const uint32_t* mask_flat;  // flat-tile route (sweep_flat_kernels.hpp): the bit masks interleaved [vector, padded to a multiple of 4][P][4 dwords], zero beyond the row
-  int flat_slots;             // flat-tile route: tile images per wave in LDS (1 or 2)
+  int flat_slots;             // flat-tile route: tile images per wave in LDS (1 or 2); 0 = the register-staged variant (one image, the next tile in VGPRs)
+  int flat_defer;             // register-staged variant: tiles a wave counts before it runs their epilogues (1 .. kFlatDeferMax)
   uint32_t group_size[8]; // mask popcounts
   uint32_t nvec_pad;      // LDS mask stride: nvec rounded up to a multiple of 16*unroll
   int unroll;             // vectors per lane issued back to back (4 or 8)
@@ -1306,7 +1307,7 @@ __device__ __forceinline__ void finish_biallelic_site(SiteTally<P>& mine, double
 // the partial vectors.  Called once, by every thread of the block, after the tile loop.
 template <int P, int MODE, int WAVES = kWavesPerBlock>
 __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTotals<P, MODE>& T) {
-  static_assert(WAVES * 64 >= kMaxF64 + kMaxU64, "one thread per partial slot");
+
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   __shared__ double s_f64[WAVES][kMaxF64];
@@ -1346,15 +1347,16 @@ __device__ __forceinline__ void reduce_block_totals(const SweepArgs& A, LaneTota
     }
   }
   __syncthreads();
-  if (threadIdx.x < kMaxF64) {
-    double v = 0.0;
-    for (int w = 0; w < WAVES; ++w) v += s_f64[w][threadIdx.x];
-    A.part_f64[(size_t)blockIdx.x * kMaxF64 + threadIdx.x] = v;
-  } else if (threadIdx.x < kMaxF64 + kMaxU64) {
-    const int i = threadIdx.x - kMaxF64;
-    unsigned long long v = 0;
-    for (int w = 0; w < WAVES; ++w) v += s_u64[w][i];
-    A.part_u64[(size_t)blockIdx.x * kMaxU64 + i] = v;
+  for (int i = threadIdx.x; i < kMaxF64 + kMaxU64; i += WAVES * 64) {  // (one pass for workgroups of two waves and more)
+    if (i < kMaxF64) {
+      double v = 0.0;
+      for (int w = 0; w < WAVES; ++w) v += s_f64[w][i];
+      A.part_f64[(size_t)blockIdx.x * kMaxF64 + i] = v;
+    } else {
+      unsigned long long v = 0;
+      for (int w = 0; w < WAVES; ++w) v += s_u64[w][i - kMaxF64];
+      A.part_u64[(size_t)blockIdx.x * kMaxU64 + (i - kMaxF64)] = v;
+    }
   }
 }
 

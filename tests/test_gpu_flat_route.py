@@ -94,8 +94,11 @@ def test_flat_tile_route_is_the_same_bits(dev, fmh_opts, S, N):
     exp = R.build_dense_population_summary(m, lists[0])
     assert np.array_equal(base["hud"].sites["alt"][0], np.array(exp.alt_counts, dtype=np.uint32))
     fmh_opts.setenv("FMH_FLAT", "1")
-    for slots in ("1", "2"):
+    # FMH_FLAT_SLOTS: 0 = the register-staged variant (with its deferral depths), 1 / 2 = the LDS-DMA variants
+    for slots, defer in (("0", "1"), ("0", "3"), ("0", "8"), ("1", None), ("2", None)):
         fmh_opts.setenv("FMH_FLAT_SLOTS", slots)
+        if defer is not None:
+            fmh_opts.setenv("FMH_FLAT_DEFER", defer)
         for blocks in (None, "1", "3"):
             if blocks is None:
                 fmh_opts.delenv("FMH_GRID_BLOCKS", raising=False)
@@ -104,8 +107,9 @@ def test_flat_tile_route_is_the_same_bits(dev, fmh_opts, S, N):
                     continue
                 fmh_opts.setenv("FMH_GRID_BLOCKS", blocks)
             got = run_all(dev, dm, g1, g2, g4, S)
-            same(got, base, f"{S}x{N} slots {slots} blocks {blocks}")
+            same(got, base, f"{S}x{N} slots {slots} defer {defer} blocks {blocks}")
         fmh_opts.delenv("FMH_GRID_BLOCKS", raising=False)
+        fmh_opts.delenv("FMH_FLAT_DEFER", raising=False)
 
 
 def test_flat_tile_route_fused_region_sweep(dev, fmh_opts):

@@ -13,6 +13,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.environ.get("FERROMIC_RUN_VCF_BIN") or os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")  # the override: the sanitizer build (make asan)
 
 
 @pytest.fixture(scope="module")
@@ -135,3 +136,35 @@ def test_writer_self_checks():
     res = subprocess.run([BIN, "--check_writers", "300000"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count(" 0 differ") == 3, res.stdout
+
+
+def test_run_aware_gzip_writer_round_trips_through_zlib_and_gzip(tmp_path):
+    """The hand-written DEFLATE writer of the FALSTA tracks (deflate_runs.cpp: fixed and tuned Huffman codes, runs as back references, values seen
+    before as back references, CRC-32 folded per run) on the writers' adversarial tracks - both default tokens, run lengths around 258 and its
+    multiples, records at the first and last position, unsorted records, empty and 700 000-position regions.  Every member must inflate to
+    the track's text with zlib (which also checks the trailer's CRC-32 and length) AND with Python's gzip module, and so must the member the
+    zlib level-1 writer makes of the same text."""
+    import gzip
+    import zlib
+
+    if not os.path.exists(BIN):
+        pytest.skip("run_vcf binary not built")
+    out = tmp_path / "cases"
+    res = subprocess.run([BIN, "--dump_writer_cases", str(out), "60"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    texts = sorted(p for p in os.listdir(out) if p.endswith(".txt"))
+    assert len(texts) == 60
+    sizes, run_bytes, zlib_bytes = [], 0, 0
+    for name in texts:
+        base = str(out / name[:-4])
+        text = open(base + ".txt", "rb").read()
+        for kind in ("runs", "zlib"):
+            member = open(f"{base}.{kind}.gz", "rb").read()
+            d = zlib.decompressobj(31)  # gzip framing: header, CRC-32 and ISIZE are verified
+            assert d.decompress(member) + d.flush() == text and d.eof and d.unused_data == b"", (name, kind, "zlib")
+            assert gzip.decompress(member) == text, (name, kind, "gzip")
+        sizes.append(len(text))
+        run_bytes += os.path.getsize(base + ".runs.gz")
+        zlib_bytes += os.path.getsize(base + ".zlib.gz")
+    assert max(sizes) > 300_000 and min(sizes) < 32  # tracks of several hundred thousand positions and an empty region are among the cases
+    assert run_bytes < 3 * zlib_bytes  # the run-aware members stay in the size class of zlib's (they are chosen for sparse tracks only)
