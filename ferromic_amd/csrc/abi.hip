@@ -78,6 +78,7 @@ const OptionRow kOptionRows[] = {
     {"FMH_FLAT", &Options::flat, -1, nullptr},
     {"FMH_FLAT_SLOTS", &Options::flat_slots, 0, nullptr},
     {"FMH_FLAT_DEFER", &Options::flat_defer, 0, nullptr},
+    {"FMH_WC_EXACT", &Options::wc_exact, 1, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -327,7 +328,7 @@ static size_t device_lds_per_cu(int device) {
 }
 static size_t sweep_lds_limit(int device) { return device_lds_limit(device); }
 // the eight-group W&C kernels keep their regional sums through a static LDS scratch (sweep_kernels.hpp, wc_xpose_scratch): that much less for masks
-static size_t wc_lds_limit(int device, int padded) { return sweep_lds_limit(device) - (padded == 8 ? fmh::kWcXposeLdsBytes + 1024 : 0); }
+static size_t wc_lds_limit(int device, int padded) { return sweep_lds_limit(device) - (padded >= 5 ? fmh::kWcXposeLdsBytes + 1024 : 0); }
 static size_t sweep_lds_bytes(int padded, size_t nvec) { return (size_t)padded * round_up(nvec, 64) * 2; }
 
 static int check_dims(size_t variants, size_t samples, size_t ploidy) {
@@ -701,6 +702,14 @@ extern "C" int fmh_matrix_generate(fmh_matrix* m, uint64_t seed, uint64_t first_
 // groups
 // ------------------------------------------------------------------------------------------------
 static int padded_groups(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
+// The group count the W&C kernel of a sweep is instantiated with: the padded one (1, 2, 4, 8), or EXACTLY five, six or seven on a packed
+// biallelic matrix with nothing missing - the slots of the padding are then not even compiled in (sweep_launch.inc).
+int fmhi::wc_kernel_groups(const fmh_matrix* m, const fmh_groups* g) {
+  if (!m || !g) return 0;
+  const bool packed = m->p0 && !(m->data && layout_bytes_forced());
+  if (g->n_groups >= 5 && g->n_groups <= 7 && packed && !m->has_missing && m->max_allele <= 1 && options().wc_exact.load() != 0) return g->n_groups;
+  return g->padded;
+}
 
 extern "C" int fmh_groups_create(const fmh_matrix* m, const uint8_t* h_mask, int n_groups, fmh_groups** out) {
   if (!out) return fail(FMH_ERR_INVALID, "out is NULL");
@@ -924,7 +933,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   a.max_allele = m->max_allele;
   if (mode & kModeWc) {
     // without missing data every site has n_i = group size: the allele-independent W&C terms are per launch
-    const int P = g->padded;
+    const int P = mode == kModeWc ? wc_kernel_groups(m, g) : g->padded;
     uint32_t n8[8];
     bool use8[8];
     for (int i = 0; i < 8; ++i) { n8[i] = i < P ? a.group_size[i] : 0; use8[i] = n8[i] != 0; }
@@ -951,7 +960,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
   if (a.row_count == 0) return FMH_OK;
   const bool missing = m->has_missing;
   const bool general = m->max_allele > 1;
-  const int P = g->padded;
+  const int P = mode == kModeWc ? wc_kernel_groups(m, g) : g->padded;
   const Options& opt = options();  // one snapshot of the switches per enqueue (atomics; the environment is never read here)
   a.unroll = opt.unroll.load() == 8 ? 8 : 4;
   a.nvec_pad = (uint32_t)round_up(m->nvec, 16 * a.unroll);
@@ -989,8 +998,8 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
       a.nvec_pad = (uint32_t)round_up(m->pvec, (size_t)lpr * a.unroll);
     };
     const bool no_prefetch = opt.packed_no_prefetch.load() != 0;
-    pick(P == 8 && (general || missing || no_prefetch));
-    if (P == 8 && a.nvec_pad != (uint32_t)(lpr * a.unroll)) pick(true);  // not one batch per row: the shallow set
+    pick(P >= 5 && (general || missing || no_prefetch));
+    if (P >= 5 && a.nvec_pad != (uint32_t)(lpr * a.unroll)) pick(true);  // not one batch per row: the shallow set
     // The prefetching row loop (tile_rows_packed_prefetch) is taken when one batch of loads covers a row.  Same-process A/Bs (tools/ab_env.py
     // FMH_PACKED_NO_PREFETCH=1): on four-lane rows (1 000 and 2 500 haplotypes) it is level or 1-6 % ahead at every launch size; on sixteen-lane
     // rows with two groups (5 000 haplotypes) it was 2.4-2.9 % ahead at 625 k sites, level at 1 M and 0.6-2.4 % behind from 1.25 M to 10 M sites -
@@ -1340,10 +1349,10 @@ static int wc_slot_sums(DeviceScratch& scratch, hipStream_t st, size_t nslots, s
 
 // W&C kernel slots follow the padded-P pair order; maps them to the caller's G-group order (a.wc_slot for the kernel's stores,
 // slot_of for the host's unpacking; -1 = a padded group takes part, never reported)
-void fmhi::wc_slot_map(const fmh_groups* g, SweepArgs& a, int (&slot_of)[32]) {
+void fmhi::wc_slot_map(const fmh_matrix* m, const fmh_groups* g, SweepArgs& a, int (&slot_of)[32]) {
   for (int k = 0; k < 32; ++k) { a.wc_slot[k] = -1; slot_of[k] = -1; }
   if (!g) return;
-  const int P = g->padded, G = g->n_groups;
+  const int P = m ? wc_kernel_groups(m, g) : g->padded, G = g->n_groups;
   a.wc_slot[0] = 0;
   slot_of[0] = 0;
   int k = 1;
@@ -1382,7 +1391,7 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   a.wc_state = d_state;
   a.called = d_group_called;
   int slot_of[32];
-  wc_slot_map(g, a, slot_of);
+  wc_slot_map(m, g, a, slot_of);
   // the fused kernel for 5..8 groups keeps the counts of alleles 0..3 per site; cohorts with alleles beyond 3 take the counts route
   const bool many_alleles8 = m && g && g->padded == 8 && m->max_allele > 3;
   if (m && g && (many_alleles8 || sweep_lds_bytes(g->padded, m->nvec) > wc_lds_limit(m->device, g->padded))) {
@@ -1404,7 +1413,7 @@ extern "C" int fmh_wc_sweep(const fmh_matrix* m, const fmh_groups* g, size_t row
   if (h_totals) {
     memset(h_totals, 0, sizeof *h_totals);
     h_totals->sites_attempted = row_count;
-    const int P = g->padded;
+    const int P = wc_kernel_groups(m, g);
     const int nw = 1 + P * (P - 1) / 2;
     for (int k = 0; k < nw; ++k) {
       if (slot_of[k] < 0) continue;

@@ -71,6 +71,7 @@ struct Options {
   std::atomic<long long> flat{-1};               // FMH_FLAT: the LDS-staged flat-tile route on short packed rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead
   std::atomic<long long> flat_slots{0};          // FMH_FLAT_SLOTS: 0 = the register-staged variant (default); 1 | 2 = the LDS-DMA variants with that many tile images per wave
   std::atomic<long long> flat_defer{0};          // FMH_FLAT_DEFER: tiles a wave counts before it runs their epilogues on the register-staged variant (1..8); 0 = by the launch size
+  std::atomic<long long> wc_exact{1};            // FMH_WC_EXACT: 0 = five to seven W&C groups run the padded eight-group kernel again (A/B of the exact kernels)
   std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
   std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };
@@ -172,7 +173,8 @@ int pair_region_args(const fmh_groups* g, size_t row_begin, size_t row_count, in
                      const fmh_hudson_sites* sites, fmh::SweepArgs& a, int* mode);
 int harmonic_table(int device, size_t max_k, hipStream_t st, const double** out);
 // W&C slot order of the padded kernel -> the caller's pair order; which W&C / summaries calls are one fused sweep (abi.hip)
-void wc_slot_map(const fmh_groups* g, fmh::SweepArgs& a, int (&slot_of)[32]);
+void wc_slot_map(const fmh_matrix* m, const fmh_groups* g, fmh::SweepArgs& a, int (&slot_of)[32]);
+int wc_kernel_groups(const fmh_matrix* m, const fmh_groups* g);
 bool wc_fused_lane_totals(const fmh_matrix* m, const fmh_groups* g);
 bool summaries_single_sweep(const fmh_matrix* m, const fmh_groups* g);
 

@@ -707,7 +707,7 @@ extern "C" int fmh_wc_sweep_sharded_begin(fmh_comm* c, const fmh_matrix* m, cons
   a.row_count = row_count;
   a.formula = FMH_FORMULA_SPARSE;
   a.wc_a = d_a; a.wc_b = d_b; a.wc_state = d_state; a.called = d_group_called;
-  wc_slot_map(g, a, s.slot_of);
+  wc_slot_map(m, g, a, s.slot_of);
   if (wc_fused_lane_totals(m, g)) return sharded_enqueue(c, m, g, kModeWc, a, (hipStream_t)stream, s, false);
   // alleles beyond 3 with five to eight groups, or rows too wide for all masks at once: the blocking call (the counts route), then the same
   // device-side reduce of its totals, laid out like the fused kernel's vector in CALLER slot order

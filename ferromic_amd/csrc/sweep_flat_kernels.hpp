@@ -34,9 +34,9 @@
 namespace fmh {
 
 #ifndef FMH_FLAT_WAVES
-#define FMH_FLAT_WAVES 2
+#define FMH_FLAT_WAVES 1
 #endif
-constexpr int kFlatWaves = FMH_FLAT_WAVES;  // waves per workgroup: 2 x nvec KiB per slot keeps 6 waves per CU resident at 20-KiB tiles
+constexpr int kFlatWaves = FMH_FLAT_WAVES;  // waves per workgroup.  One: nothing is shared between the waves of this route but the W&C tables, and single-wave workgroups pack a CU's LDS with one more 20-KiB tile image than pairs do (same-box A/B, profiles/r04/ab_flat_variants.jsonl: four-group summaries 1.06-1.09 -> 1.00-1.03 of the four-lane route)
 constexpr int kFlatBlock = kFlatWaves * kWave;
 constexpr int kFlatMaxVec = 32;            // rows of up to 32 vectors (the four-lane route's range)
 constexpr uint32_t kFlatLdsSlack = 256;    // reads of the padded last vectors of a slot's last row stay inside the allocation

@@ -1027,8 +1027,8 @@ struct LaneTotals {
   // transposition sixteen rows at a time - every lane writes its value of a row, lane (r, q) adds up a quarter of row r, the quad adds the
   // quarters - and one double per row behind the wave's scratch accumulates over the tiles (kWcLdsTotals, wc_xpose_put).  (Until round 3 the
   // host summed the per-site tracks in a second pass, wc_slot_reduce_kernel: half as long again as the sweep, and it needed the tracks.)
-  static constexpr bool kWcLaneTotals = (MODE & kModeWc) != 0 && P < 8;
-  static constexpr bool kWcLdsTotals = (MODE & kModeWc) != 0 && P == 8;
+  static constexpr bool kWcLaneTotals = (MODE & kModeWc) != 0 && P <= 4;
+  static constexpr bool kWcLdsTotals = (MODE & kModeWc) != 0 && P >= 5;
   static constexpr int kWcRegSlots = kWcLaneTotals ? 1 + (P * (P - 1)) / 2 : 1;
   static constexpr int kWcXposeRows = 3 * (1 + (P * (P - 1)) / 2);
   static constexpr int kWcBatches = kWcLdsTotals ? (kWcXposeRows + kWcXRows - 1) / kWcXRows : 1;
@@ -1261,7 +1261,7 @@ __device__ __forceinline__ void site_epilogue(const SweepArgs& A, size_t out_idx
 #pragma unroll
       for (int p = 0; p < P; ++p) { cc[1][p] = t.alt[p]; cc[0][p] = t.n[p] - t.alt[p]; }
       wc_for_each_slot<P, 2, !MISSING>(A, t.n, cc, finish);
-    } else if constexpr (P == 8) {
+    } else if constexpr (P >= 5) {
       // eight groups, multi-allelic: the counts of alleles 0..3 (c4), every slot computed and finished in turn like the biallelic
       // case - the same per-allele terms in the same allele order as the accumulating form below
       wc_for_each_slot<P, 4, !MISSING>(A, t.n, *reinterpret_cast<const uint32_t (*)[4][P]>(c4), finish);
@@ -1373,7 +1373,7 @@ constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL 
 // (biallelic, and multi-allelic on two planes) end one register above 256 when left alone - one wave per SIMD instead of two; the
 // three-plane ones would spill to scratch under that bound and are left alone
 template <int P, int MODE, bool GENERAL, int MM, int NPL>
-constexpr int sweep_min_blocks() { return (MM == 3 /* kMaskPacked */ && P == 8 && (MODE & kModeWc) != 0 && NPL == 2) ? 2 : 1; }
+constexpr int sweep_min_blocks() { return (MM == 3 /* kMaskPacked */ && P >= 5 && (MODE & kModeWc) != 0 && NPL == 2) ? 2 : 1; }
 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
       for (int k = 0; k < NS; ++k) my_s[p][k] = 0;
     // packed cores: the batch depth U is the launch's (A.unroll); with eight groups only the shallow batches are built in this row loop -
     // deeper ones kept P x U mask vectors live and spilled to scratch (the one-batch-per-row loop above takes any depth: its masks stay in LDS)
-    constexpr bool kShallow = P == 8;
+    constexpr bool kShallow = P >= 5;
     for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;
@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
 
     // W&C with eight groups on the general path: no per-slot accumulators across the allele loop (29 slots = 116 registers); the counts of
     // alleles 0..3 are kept instead and site_epilogue finishes slot by slot (the host sends max_allele > 3 to the counts route)
-    constexpr bool kWc8 = GENERAL && P == 8 && (MODE & kModeWc) != 0;
+    constexpr bool kWc8 = GENERAL && P >= 5 && (MODE & kModeWc) != 0;
     uint32_t c4[kWc8 ? 4 : 1][P];
     if constexpr (GENERAL) {
       // The alleles of the tile's 64 sites are consumed here, one site per lane (all 64 lanes busy), from the subset sums each

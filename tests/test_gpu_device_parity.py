@@ -184,6 +184,13 @@ WC_CASES = [
     (80, 30, 3, 3, 0.1, 0.05, 1, 2),
     (60, 50, 5, 2, 0.05, 0.0, 0, 5),
     (4, 60_000, 3, 1, 0.02, 0.0, 0, 7),  # 120 000 columns: fused W&C with bit masks in LDS
+    # biallelic, nothing missing, five to eight groups: the kernels instantiated for EXACTLY five, six and seven groups (round 4) and the eight-group one
+    (150, 40, 5, 1, 0.0, 0.0, 0, 3),
+    (130, 45, 6, 1, 0.0, 0.0, 0, 0),
+    (140, 50, 7, 1, 0.0, 0.0, 0, 2),
+    (90, 64, 8, 1, 0.0, 0.0, 0, 1),
+    (70, 2600, 5, 1, 0.0, 0.0, 0, 10),  # 5 200 columns: sixteen lanes per row
+    (70, 2100, 7, 1, 0.0, 0.0, 0, 0),
 ]
 
 
@@ -428,6 +435,32 @@ def test_mask_routes_agree(dev, fmh_opts):
             assert np.array_equal(got[3].alt, base[3].alt) and np.array_equal(got[3].called, base[3].called)
             assert got[3].totals == base[3].totals
         fmh_opts.delenv("FMH_MASK_MODE", raising=False)
+
+
+def test_exact_group_count_kernels_are_the_padded_kernels_bits(dev, fmh_opts):
+    """Five, six and seven W&C groups on a packed biallelic matrix with nothing missing run kernels instantiated for exactly that many groups;
+    FMH_WC_EXACT=0 sends them through the padded eight-group kernel again.  Every per-site a, b, state and count must be the same bits, the
+    informative-site counts equal, the regional sums equal to 1e-12 (the eight-group kernel sums through another LDS transposition layout)."""
+    rng = np.random.default_rng(5678)
+    for (S, N, G) in ((3000, 400, 5), (2500, 1250, 5), (2000, 640, 6), (2100, 900, 7), (1500, 2700, 6)):
+        m = H.random_dense_matrix(rng, S, N, 2, 1, 0.0)
+        dm = upload(dev, m)
+        lists = [H.haps_for_samples(range(i, N - 3, G)) for i in range(G)]
+        g = dev.Groups.from_haplotype_lists(dm, lists)
+        for blocks in (None, "2"):
+            if blocks:
+                fmh_opts.setenv("FMH_GRID_BLOCKS", blocks)
+            fmh_opts.setenv("FMH_WC_EXACT", "0")
+            base = dev.wc_sweep(dm, g, 5, S - 9)
+            fmh_opts.setenv("FMH_WC_EXACT", "1")
+            got = dev.wc_sweep(dm, g, 5, S - 9)
+            what = f"{S}x{N} {G} groups blocks {blocks}"
+            assert np.array_equal(got.a.view(np.uint64), base.a.view(np.uint64)) and np.array_equal(got.b.view(np.uint64), base.b.view(np.uint64)), what
+            assert np.array_equal(got.state, base.state) and np.array_equal(got.group_called, base.group_called), what
+            assert np.array_equal(got.informative_sites, base.informative_sites) and got.sites_attempted == base.sites_attempted, what
+            assert np.allclose(got.sum_a, base.sum_a, rtol=1e-12, atol=1e-15) and np.allclose(got.sum_b, base.sum_b, rtol=1e-12, atol=1e-15), what
+            fmh_opts.delenv("FMH_GRID_BLOCKS", raising=False)
+        fmh_opts.delenv("FMH_WC_EXACT", raising=False)
 
 
 def test_deferred_epilogues_are_the_same_bits(dev, fmh_opts):
