@@ -298,6 +298,42 @@ void parse_genotypes(const py::handle& obj, ParsedVariant* out) {
     }
     out->len.push_back(n);
   };
+  // Buffer fast path (round 4): a record whose genotypes are ONE numpy integer array - (samples, ploidy), or (samples,) for haploid calls - is read
+  // through its buffer instead of one Python object per allele (per_site_diversity fed 100 000 records of 500 genotypes spent 1.2 s in the
+  // object-by-object walk).  Same result as that walk: every row a genotype of `ploidy` alleles, a value outside 0..255 the same OverflowError.
+  if (py::isinstance<py::array>(obj)) {
+    py::array arr = py::reinterpret_borrow<py::array>(obj);
+    const char kind = arr.dtype().kind();
+    const py::ssize_t item = arr.itemsize();
+    if ((kind == 'i' || kind == 'u') && (arr.ndim() == 1 || arr.ndim() == 2) && (item == 1 || item == 2 || item == 4 || item == 8)) {
+      const py::ssize_t n = arr.shape(0), ploidy = arr.ndim() == 2 ? arr.shape(1) : 1;
+      const py::ssize_t s0 = arr.strides(0), s1 = arr.ndim() == 2 ? arr.strides(1) : 0;
+      const char* base = static_cast<const char*>(arr.data());
+      out->len.reserve((size_t)n);
+      out->off.reserve((size_t)n);
+      out->alleles.reserve(out->alleles.size() + (size_t)(n * ploidy));
+      for (py::ssize_t i = 0; i < n; ++i) {
+        out->off.push_back((uint32_t)out->alleles.size());
+        for (py::ssize_t k = 0; k < ploidy; ++k) {
+          const char* q = base + i * s0 + k * s1;
+          long long v;
+          if (kind == 'i') {
+            if (item == 1) { int8_t x; memcpy(&x, q, 1); v = x; } else if (item == 2) { int16_t x; memcpy(&x, q, 2); v = x; }
+            else if (item == 4) { int32_t x; memcpy(&x, q, 4); v = x; } else { int64_t x; memcpy(&x, q, 8); v = x; }
+          } else {
+            unsigned long long u;
+            if (item == 1) { uint8_t x; memcpy(&x, q, 1); u = x; } else if (item == 2) { uint16_t x; memcpy(&x, q, 2); u = x; }
+            else if (item == 4) { uint32_t x; memcpy(&x, q, 4); u = x; } else { uint64_t x; memcpy(&x, q, 8); u = x; }
+            v = u > 255 ? 256 : (long long)u;
+          }
+          if (v < 0 || v > 255) raise(PyExc_OverflowError, "out of range integral type conversion attempted");
+          out->alleles.push_back((uint8_t)v);
+        }
+        out->len.push_back((int32_t)ploidy);
+      }
+      return;
+    }
+  }
   if (PyList_CheckExact(obj.ptr()) || PyTuple_CheckExact(obj.ptr())) {
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(obj.ptr());
     PyObject** items = PySequence_Fast_ITEMS(obj.ptr());

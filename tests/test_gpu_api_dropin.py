@@ -436,3 +436,29 @@ def test_pairwise_differences_reference_cases_literal(kats):
         got = {f"{p.sample_i},{p.sample_j}": [p.differences, p.comparable_sites] for p in res}
         for key, exp in case["expected"].items():
             assert got[key] == exp, (case["name"], key)
+
+
+def test_records_with_numpy_genotypes_take_the_buffer_path():
+    """A variant record whose `genotypes` is one numpy integer array (samples x ploidy, any of the integer dtypes, strided views too) is read
+    through its buffer; the result must be what the same calls as nested lists give, and a value outside 0..255 the same OverflowError."""
+    rng = np.random.default_rng(31)
+    S, N = 400, 37
+    calls = rng.integers(0, 3, size=(S, N, 2))
+    haps = [(i, side) for i in range(N) for side in (0, 1)]
+    as_lists = [variant_record(10 * i + 3, calls[i].tolist()) for i in range(S)]
+    base = fm.per_site_diversity(as_lists, haps)
+    for dtype in (np.int8, np.uint8, np.int16, np.uint16, np.int32, np.int64):
+        arr = calls.astype(dtype)
+        wide = np.zeros((S, N, 4), dtype=dtype)
+        wide[:, :, ::2] = arr  # a strided view per record
+        for records in ([variant_record(10 * i + 3, arr[i]) for i in range(S)], [variant_record(10 * i + 3, wide[i][:, ::2]) for i in range(S)],
+                        [(10 * i + 3, arr[i]) for i in range(S)]):
+            got = fm.per_site_diversity(records, haps)
+            assert len(got) == len(base)
+            for a, b in zip(got, base):
+                assert a.position == b.position and a.pi == b.pi and a.watterson_theta == b.watterson_theta
+    assert fm.segregating_sites([variant_record(1, np.array([0, 1, 1, 0], dtype=np.int8))]) == fm.segregating_sites([variant_record(1, [0, 1, 1, 0])])  # haploid calls
+    with pytest.raises(OverflowError):
+        fm.per_site_diversity([variant_record(5, np.array([[0, -1], [1, 0]], dtype=np.int8))], [(0, 0), (1, 1)])
+    with pytest.raises(OverflowError):
+        fm.per_site_diversity([variant_record(5, np.array([[0, 300], [1, 0]], dtype=np.int16))], [(0, 0), (1, 1)])
