@@ -73,6 +73,9 @@ const OptionRow kOptionRows[] = {
     {"FMH_PD_KCHUNK", &Options::pd_kchunk, 0, nullptr},
     {"FMH_PD_SB", &Options::pd_sb, 0, nullptr},
     {"FMH_PD_OCC", &Options::pd_occ, 0, nullptr},
+    {"FMH_PD_PHASED", &Options::pd_phased, 1, nullptr},
+    {"FMH_PD_SLABS", &Options::pd_slabs, 1, nullptr},
+    {"FMH_PD_SLAB_BYTES", &Options::pd_slab_bytes, (long long)4 << 30, nullptr},
     {"FMH_PIPE", &Options::pipe, -1, nullptr},
     {"FMH_GRAPH", &Options::graph, 0, nullptr},
     {"FMH_FLAT", &Options::flat, -1, nullptr},
@@ -1565,6 +1568,9 @@ extern "C" int fmh_device_release_scratch(int device) {
   if (w->pd_planes) (void)hipFree(w->pd_planes);
   w->pd_planes = nullptr;
   w->pd_planes_bytes = 0;
+  if (w->pd_slabs) (void)hipFree(w->pd_slabs);
+  w->pd_slabs = nullptr;
+  w->pd_slab_bytes = 0;
   pool_trim(device);
   upload_release(device);
   return FMH_OK;

@@ -66,7 +66,7 @@ struct Options {
   std::atomic<long long> pitch_align{16};        // FMH_PITCH_ALIGN: row pitch alignment of u8 matrices
   std::atomic<long long> comm_host{0};           // FMH_COMM_TRANSPORT = host: in-process rendezvous instead of RCCL (fmh_comm_init_all)
   std::atomic<long long> upload_threads{0};      // FMH_UPLOAD_THREADS: host packer threads; 0 = the CPU share
-  std::atomic<long long> pd_two_planes{0}, pd_int8{0}, pd_planes_bytes{(long long)8 << 30}, pd_kchunk{0}, pd_sb{0}, pd_occ{0};  // FMH_PD_*: pairwise path
+  std::atomic<long long> pd_two_planes{0}, pd_int8{0}, pd_planes_bytes{(long long)8 << 30}, pd_kchunk{0}, pd_sb{0}, pd_occ{0}, pd_phased{1}, pd_slabs{1}, pd_slab_bytes{(long long)4 << 30};  // FMH_PD_*: pairwise path
   std::atomic<long long> pipe{-1};               // FMH_PIPE: the pipelined tile loop on four-lane rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead (one and two groups)
   std::atomic<long long> flat{-1};               // FMH_FLAT: the LDS-staged flat-tile route on short packed rows: 1 = wherever it is built, 0 = never, -1 = where it measured ahead
   std::atomic<long long> flat_slots{0};          // FMH_FLAT_SLOTS: 0 = the register-staged variant (default); 1 | 2 = the LDS-DMA variants with that many tile images per wave
@@ -126,6 +126,8 @@ struct Workspace {
   std::vector<double*> retired_harmonic;
   uint8_t* pd_planes = nullptr;  // pairwise-differences planes, kept between calls (fmh_device_release_scratch frees them)
   size_t pd_planes_bytes = 0;
+  int* pd_slabs = nullptr;       // the phased Gram kernel's per-item partial tiles
+  size_t pd_slab_bytes = 0;
   std::mutex in_use;  // the harmonic table's growth and the pairwise scratch: one holder at a time per device
 };
 int workspace(int device, Workspace** out);

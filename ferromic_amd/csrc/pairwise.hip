@@ -30,6 +30,9 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
   // counts 0..4 are exact in FP4 (e2m1): twice the MFMA rate of int8 at half the plane bytes (pairwise_kernels.hpp)
   const bool env_int8 = options().pd_int8.load() != 0;  // measurements / tests: the int8 route
   const bool fp4 = m->ploidy <= 4 && !env_int8;
+  // round 4: the phase-interleaved Gram kernel (pd_gram256p_kernel) and its planes layout (K halves contiguous); FMH_PD_PHASED=0 keeps round 3's
+  const bool phased = options().pd_phased.load() != 0;
+  const int layout = phased ? 1 : 0;
   const size_t spb = fp4 ? 2 : 1;            // sites per byte of a plane row
   const size_t ksites = kPdStageK * spb;     // sites per K block = per Gram stage
   // sites are processed in slabs so that the sample-major planes stay within a fixed budget of HBM
@@ -88,10 +91,10 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
       if (smem_p > 64 * 1024 && (e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p)) != hipSuccess) break;
       if (fp4)
         hipLaunchKernelGGL(pd_planes_packed_kernel<true>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
-                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
+                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad, layout);
       else
         hipLaunchKernelGGL(pd_planes_packed_kernel<false>, grid_p, dim3(256), smem_p, st, q0, q1, qc, m->plane_pitch, rows, (uint32_t)n_samples,
-                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad);
+                           (uint32_t)m->ploidy, n_alleles, n_planes, single ? 1 : 0, single ? 1 : 0, sbp, planes, n_pad, s_pad, layout);
     } else {
       if (!m->data && !via_unpack) { e = hipErrorInvalidValue; break; }
       MatrixView mv{};
@@ -120,10 +123,10 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
       const dim3 planes_grid((unsigned)(s_pad / ksites), (unsigned)(n_pad / sb));
       if (fp4)
         hipLaunchKernelGGL(pd_planes_kernel<true>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
-                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
+                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad, layout);
       else
         hipLaunchKernelGGL(pd_planes_kernel<false>, planes_grid, dim3(256), planes_smem, st, mv, rows, (uint32_t)n_samples, (uint32_t)m->ploidy, n_alleles,
-                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad);
+                           n_planes, single ? 1 : 0, single ? 1 : 0, sb, planes, n_pad, s_pad, layout);
     }
     if ((e = hipGetLastError()) != hipSuccess) break;
     // persistent grid: as many workgroups per CU as are resident, dealt round-robin to the 8 XCDs; K is cut into 8 * j slices, j per XCD, sized so
@@ -140,7 +143,14 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
       if (env_occ > 0 && occ > env_occ) occ = env_occ;
       gram_occ[m->device][fp4] = occ;
     }
-    const unsigned grid = (unsigned)std::max(8, w->cus * gram_occ[m->device][fp4] / 8 * 8);  // persistent: every workgroup resident
+    static thread_local bool phased_ready[64][2];
+    if (phased && !phased_ready[m->device][fp4]) {
+      e = hipFuncSetAttribute(fp4 ? (const void*)pd_gram256p_kernel<true> : (const void*)pd_gram256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPdPhaseLdsBytes);
+      if (e != hipSuccess) break;
+      phased_ready[m->device][fp4] = true;
+    }
+    // persistent: every workgroup resident (the phased kernel's two K tiles of LDS leave one workgroup per CU)
+    const unsigned grid = phased ? (unsigned)std::max(8, w->cus / 8 * 8) : (unsigned)std::max(8, w->cus * gram_occ[m->device][fp4] / 8 * 8);
     const size_t slots = grid / 8;
     size_t j = env_chunk ? std::max<size_t>(1, (k_bytes + 8 * env_chunk - 1) / (8 * env_chunk)) : std::max<size_t>(1, (slots * 8 + tiles - 1) / tiles);
     // an item's accumulators must stay exact: int32 for the int8 route, integers up to 2^24 in f32 for FP4 (counts <= ploidy)
@@ -151,7 +161,36 @@ extern "C" int fmh_pairwise_differences(const fmh_matrix* m, size_t n_samples, u
     if (k_chunk < k_floor) k_chunk = k_floor;
     if (k_chunk > k_cap) k_chunk = k_cap;
     j = ((k_bytes + k_chunk - 1) / k_chunk + 7) / 8;
+    // the phased kernel writes every item's partial tile as a plain slab and a second kernel sums the slabs (no atomics) when the slabs fit the budget
+    int* slabs = nullptr;
+    if (phased && options().pd_slabs.load() != 0) {
+      const size_t slab_bytes = tiles * 8 * j * (size_t)kPdBig * kPdBig * sizeof(int);
+      if (slab_bytes <= (size_t)options().pd_slab_bytes.load()) {
+        if (w->pd_slab_bytes < slab_bytes) {
+          if (w->pd_slabs) (void)hipFree(w->pd_slabs);
+          w->pd_slabs = nullptr;
+          w->pd_slab_bytes = 0;
+          if ((e = hipMalloc((void**)&w->pd_slabs, slab_bytes)) != hipSuccess) break;
+          w->pd_slab_bytes = slab_bytes;
+        }
+        slabs = w->pd_slabs;
+      }
+    }
     auto gram = [&](int plane_begin, int plane_count, int negate, unsigned long long* dst, unsigned long long* totals = nullptr) {
+      if (phased) {
+        if (fp4)
+          hipLaunchKernelGGL((pd_gram256p_kernel<true>), dim3(grid), dim3(kPdPhaseThreads), kPdPhaseLdsBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
+                             k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals, slabs);
+        else
+          hipLaunchKernelGGL((pd_gram256p_kernel<false>), dim3(grid), dim3(kPdPhaseThreads), kPdPhaseLdsBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
+                             k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals, slabs);
+        if (slabs && hipGetLastError() == hipSuccess) {
+          const size_t threads = tiles * 16384;
+          hipLaunchKernelGGL(pd_slab_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, slabs, (uint32_t)nt, (uint32_t)j, k_chunk, k_bytes,
+                             (uint32_t)n_samples, negate, dst, totals);
+        }
+        return hipGetLastError();
+      }
       if (fp4)
         hipLaunchKernelGGL((pd_gram256_kernel<4, 4, true>), dim3(grid), dim3(1024), 2 * kPdBigStageBytes, st, planes, n_pad, k_bytes, plane_begin, plane_count,
                            k_chunk, (uint32_t)j, (uint32_t)n_samples, negate, dst, totals);

@@ -27,6 +27,17 @@ constexpr int kPdStageK = 128;  // K BYTES per sample per Gram stage: 128 sites 
 // exact as the int8 route (checked on the device: tools/microbench/fp4_gram_probe.hip, the pairwise parity tests).
 __device__ __forceinline__ uint32_t pd_fp4_code(uint32_t count) { return (0x65420u >> (4 * count)) & 0xFu; }
 
+// Where the 16-byte chunk `chunk` (0..7 of a sample's 128 K bytes in K block kb) of plane p goes.
+//   layout 0 (pd_gram256_kernel): planes[p][kb][sample][128], chunk positions XOR-swizzled by (sample >> 1) & 7;
+//   layout 1 (pd_gram256p_kernel, round 4): planes[p][kb][K half][sample][64] - every (operand, K half) tile of 256 samples is ONE contiguous
+//     16 KiB run - with the four chunk positions of a half XOR-swizzled by g((sample >> 2) & 3), g = {2, 0, 1, 3}: the 16 rows of an MFMA fragment
+//     then hit 16 different 16-byte bank groups in every one of the hardware's ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...).
+__device__ __forceinline__ size_t pd_plane_offset(int layout, size_t p, size_t k_blocks, size_t kb, size_t n_pad, size_t smp, uint32_t chunk) {
+  if (layout == 0) return ((p * k_blocks + kb) * n_pad + smp) * (size_t)128 + ((chunk ^ (uint32_t)((smp >> 1) & 7)) << 4);
+  const uint32_t half = chunk >> 2, c4 = chunk & 3, g = (0x3102u >> (4 * (uint32_t)((smp >> 2) & 3))) & 3u;
+  return (((p * k_blocks + kb) * 2 + half) * n_pad + smp) * (size_t)64 + ((c4 ^ g) << 4);
+}
+
 // planes[p][site / 128][sample][site % 128]: p = 0..A-1 allele counts, then (only when calls can be missing)
 // p = A genotype length and p = A+1 valid (length > 0).  K-blocked so that one Gram stage (128 samples x 128 K
 // bytes) is one contiguous 16 KiB run.  Plane p holds allele value p + allele_base (single-plane mode: allele 1 only);
@@ -37,7 +48,7 @@ __device__ __forceinline__ uint32_t pd_fp4_code(uint32_t count) { return (0x6542
 template <bool FP4>
 __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, size_t row_count, uint32_t samples,
                                                         uint32_t ploidy, int n_alleles, int n_planes, int allele_base, int ones_row,
-                                                        uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
+                                                        uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int layout) {
   extern __shared__ __align__(16) unsigned char pd_smem[];
   constexpr uint32_t KS = FP4 ? 2 * kPdStageK : kPdStageK;  // sites per K block
   constexpr uint32_t PER = KS / 8;                          // sites per 16-byte chunk of the output row
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void pd_planes_kernel(const MatrixView mv, siz
         }
       }
       // 16-byte chunk positions are XOR-swizzled by (sample >> 1) & 7 for the Gram kernel's unpadded LDS image
-      *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<uint4*>(planes + pd_plane_offset(layout, (size_t)p, k_blocks, kb, n_pad, smp, chunk)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
   }
 }
@@ -155,7 +166,7 @@ template <bool FP4>
 __global__ __launch_bounds__(256) void pd_planes_packed_kernel(const uint8_t* __restrict__ p0, const uint8_t* __restrict__ p1,
                                                                const uint8_t* __restrict__ pc, size_t plane_pitch, size_t row_count,
                                                                uint32_t samples, uint32_t ploidy, int n_alleles, int n_planes, int allele_base,
-                                                               int ones_row, uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad) {
+                                                               int ones_row, uint32_t sb, uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int layout) {
   extern __shared__ __align__(16) unsigned char pd_smem[];
   constexpr uint32_t KS = FP4 ? 2 * kPdStageK : kPdStageK;  // sites per K block
   constexpr uint32_t PER = KS / 8;                          // sites per 16-byte chunk of the output row
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256) void pd_planes_packed_kernel(const uint8_t* __
                 if (site0 + chunk * PER + i < row_count) put(o, i, 1u);
             }
           }
-          *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<uint4*>(planes + pd_plane_offset(layout, (size_t)p, k_blocks, kb, n_pad, smp, chunk)) = make_uint4(o[0], o[1], o[2], o[3]);
         }
       }
       continue;
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256) void pd_planes_packed_kernel(const uint8_t* __
           put(out, i, val);
         }
       }
-      *reinterpret_cast<uint4*>(planes + (((size_t)p * k_blocks + kb) * n_pad + smp) * kPdStageK + ((chunk ^ ((smp >> 1) & 7)) << 4)) = make_uint4(out[0], out[1], out[2], out[3]);
+      *reinterpret_cast<uint4*>(planes + pd_plane_offset(layout, (size_t)p, k_blocks, kb, n_pad, smp, chunk)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
   }
 }
@@ -445,6 +456,221 @@ __global__ __launch_bounds__(WM * WN * 64) void pd_gram256_kernel(const uint8_t*
             if (v != 0) atomicAdd(&totals[i], (unsigned long long)v);
           }
         }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// pd_gram256p_kernel (round 4): the same Gram product on a phase-interleaved schedule
+// ------------------------------------------------------------------------------------------------
+// pd_gram256_kernel above has two 64-KiB stage buffers and one barrier per stage behind `s_waitcnt vmcnt(0)`: every stage ends waiting for
+// the slowest of its own global_load_lds, and LDS fragment reads, DMA issue and MFMAs of a wave run one after the other (46-47 % of the int8
+// peak).  This kernel follows the 256-squared multi-phase recipe of cdna_hip_programming.md section 5 (counted vmcnt, raw s_barrier, two wave
+// groups staggered by half a phase, s_setprio around the MFMA cluster), laid out for this operand format:
+//   * 8 waves = 2 (M) x 4 (N); a wave owns 128 x 64 of the 256 x 256 tile = 8 x 4 MFMA tiles (128 accumulator registers);
+//   * a K tile is 128 K bytes per sample = two K HALVES of 64 bytes; LDS holds two K tiles as 8 half-tile slots of 16 KiB
+//     [buffer][A k0 | B k0 | A k1 | B k1], each the byte-for-byte copy of one contiguous run of the planes (layout 1 of pd_plane_offset);
+//   * 4 phases per K tile: (rows 0-63, k0), (rows 64-127, k0), (rows 0-63, k1), (rows 64-127, k1) of the wave's 128 rows - 16 MFMAs each
+//     (4 x 4 tiles x one 64-deep K step), 4 A fragment reads per phase and 4 B fragment reads in the first phase of each K half;
+//   * every phase issues ONE half-tile of DMA (2 x global_load_lds_dwordx4 per wave), two K tiles ahead of the half it replaces:
+//       phase 1: B k0 of tile t+1   phase 2: A k1 of t+1   phase 3: B k1 of t+1   phase 4: A k0 of t+2
+//     A slot is refilled two phases after its last read (k0 slots are last read in phase 2, k1 slots in phase 4), and a half-tile is read
+//     one phase after the counted wait that retires it: `vmcnt(6)` - three half-tiles stay in flight - in phases 4 (retires k0 of t+1)
+//     and 2 (retires k1 of t); never vmcnt(0) inside the loop except in the last two K tiles of an item;
+//   * wave group 1 (wr == 1) runs one barrier behind group 0, so that on every SIMD one wave's MFMA cluster runs beside the other's
+//     fragment reads and DMA issue.
+// Phase p of a wave:  fragment ds_reads, DMA issue, [counted vmcnt]  |barrier|  lgkmcnt(0), 16 MFMAs under s_setprio 1  |barrier|.
+constexpr int kPdPhaseThreads = 512;
+constexpr int kPdHalfTileBytes = kPdBig * 64;            // 256 samples x 64 K bytes
+constexpr int kPdPhaseLdsBytes = 8 * kPdHalfTileBytes;   // two K tiles
+
+template <bool FP4>
+__global__ __launch_bounds__(kPdPhaseThreads) void pd_gram256p_kernel(const uint8_t* __restrict__ planes, size_t n_pad, size_t s_pad, int plane_begin,
+                                                                      int plane_count, size_t k_chunk, uint32_t slices_per_xcd, uint32_t n_samples,
+                                                                      int negate, unsigned long long* __restrict__ out,
+                                                                      unsigned long long* __restrict__ totals, int* __restrict__ slabs) {
+  extern __shared__ __align__(16) unsigned char pd_lds[];  // ALL of the kernel's LDS (a second __shared__ object makes hipcc wait vmcnt(0) before LDS reads)
+  const uint32_t nt = (uint32_t)(n_pad / kPdBig);
+  const uint32_t tiles = nt * (nt + 1) / 2;
+  const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wr = wave >> 2, wc = wave & 3;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  typedef typename std::conditional<FP4, pd_v4f, pd_v4i>::type acc_t;
+  // fragment addresses inside a half-tile slot: row r of the tile, 16-byte K chunk c = lane >> 4 at slot c ^ g((r >> 2) & 3)
+  const uint32_t frow = (uint32_t)(lane & 15), fc = (uint32_t)(lane >> 4);
+  const uint32_t fswz = (fc ^ ((0x3102u >> (4 * ((frow >> 2) & 3))) & 3u)) << 4;  // (tile rows are multiples of 16: the row's swizzle term is the lane's)
+  const uint32_t a_off = ((uint32_t)wr * 128u + frow) * 64u + fswz;  // + m * 1024 for M tile m (16 rows x 64 bytes)
+  const uint32_t b_off = ((uint32_t)wc * 64u + frow) * 64u + fswz;   // + n * 1024
+  const size_t k_blocks = s_pad / kPdStageK;
+  const size_t half_stride = n_pad * 64;  // bytes between the two K halves of a K block; a K block is 2 x half_stride
+  for (uint32_t item = slot; item < tiles * slices_per_xcd; item += slots) {
+    uint32_t t = item % tiles, bi = 0;
+    while (t >= nt - bi) { t -= nt - bi; ++bi; }
+    const uint32_t bj = bi + t;
+    const size_t k0 = ((size_t)xcd * slices_per_xcd + item / tiles) * k_chunk;
+    if (k0 >= s_pad) continue;  // uniform for the workgroup
+    acc_t acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = 0;
+    const size_t k1 = k0 + k_chunk < s_pad ? k0 + k_chunk : s_pad;
+    const uint32_t per_plane = (uint32_t)((k1 - k0) / kPdStageK);
+    const uint32_t n_kt = per_plane * (uint32_t)plane_count;
+    const size_t kb0 = k0 / kPdStageK;
+    // one cursor per half-tile stream (A k0, B k0, A k1, B k1): each advances one K tile per use; a wave copies chunks 2 w and 2 w + 1 of a half-tile
+    struct Cursor { const uint8_t* ptr; uint32_t in_plane; uint32_t kt; };
+    const size_t kblock_bytes = 2 * half_stride;
+    const size_t plane_skip = (k_blocks - per_plane) * kblock_bytes;
+    const size_t my_chunks = (size_t)wave * 2048 + (size_t)lane * 16;
+    auto cursor = [&](uint32_t tile_index, int half) {
+      Cursor c;
+      c.ptr = planes + ((size_t)plane_begin * k_blocks + kb0) * kblock_bytes + (size_t)half * half_stride + (size_t)tile_index * kPdBig * 64 + my_chunks;
+      c.in_plane = 0;
+      c.kt = 0;
+      return c;
+    };
+    Cursor ca0 = cursor(bi, 0), cb0 = cursor(bj, 0), ca1 = cursor(bi, 1), cb1 = cursor(bj, 1);
+    // (An L2 prefetch of the K block four tiles ahead - every workgroup touching its share of the lines with a 4-byte LDS-DMA into a landing pad -
+    // was measured and changed nothing: 0.788 vs 0.780 of round 3's kernel on two boxes.  The loop is not waiting for HBM.)
+    // issue the two DMA pieces of this wave for the cursor's K tile into half-tile slot `hs` of its buffer, then advance the cursor
+    auto stage = [&](Cursor& c, int hs) {
+      if (c.kt < n_kt) {
+        unsigned char* dst = pd_lds + ((size_t)((c.kt & 1) * 4 + hs)) * kPdHalfTileBytes + (size_t)wave * 2048;
+        __builtin_amdgcn_global_load_lds((gptr_t)c.ptr, (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(c.ptr + 1024), (lptr_t)(dst + 1024), 16, 0, 0);
+      }
+      ++c.kt;
+      c.ptr += kblock_bytes;
+      if (++c.in_plane == per_plane) { c.ptr += plane_skip; c.in_plane = 0; }
+    };
+    // prologue: K tile 0 whole and A k0 of K tile 1 - the state every K tile of the loop starts from
+    __builtin_amdgcn_s_barrier();  // the previous item's fragment reads are done in every wave before its slots are refilled
+    stage(ca0, 0); stage(cb0, 1); stage(ca1, 2); stage(cb1, 3); stage(ca0, 0);
+    if (n_kt > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind
+    pd_v4i fa[4], fb[4];
+    for (uint32_t kt = 0; kt < n_kt; ++kt) {
+      const unsigned char* buf = pd_lds + (size_t)(kt & 1) * 4 * kPdHalfTileBytes;
+      const bool tail = kt + 2 >= n_kt;  // fewer than three half-tiles are issued behind the one waited for: drain instead of counting
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int mh = ph & 1, kh = ph >> 1;
+        const unsigned char* ia = buf + (size_t)(kh * 2 + 0) * kPdHalfTileBytes;
+        const unsigned char* ib = buf + (size_t)(kh * 2 + 1) * kPdHalfTileBytes;
+        if (mh == 0) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const pd_v4i*>(&ib[b_off + (uint32_t)n * 1024u]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const pd_v4i*>(&ia[a_off + (uint32_t)(mh * 4 + m) * 1024u]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) stage(cb0, 1);
+        else if (ph == 1) stage(ca1, 2);
+        else if (ph == 2) stage(cb1, 3);
+        else stage(ca0, 0);
+        if (ph == 1 || ph == 3) {
+          if (tail) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // three half-tiles stay in flight
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if constexpr (FP4) {
+              const pd_v8i a8 = {fa[m][0], fa[m][1], fa[m][2], fa[m][3], 0, 0, 0, 0};
+              const pd_v8i b8 = {fb[n][0], fb[n][1], fb[n][2], fb[n][3], 0, 0, 0, 0};
+              acc[mh * 4 + m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[mh * 4 + m][n], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            } else {
+              acc[mh * 4 + m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[mh * 4 + m][n], 0, 0, 0);
+            }
+          }
+        // the phase's sums are pinned here: without a use hipcc sinks the FP4 MFMAs of all four phases into the last one (the scaled-MFMA builtin
+        // has no side effect and nothing reads an accumulator before the end of the item), which undoes the whole interleave
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(acc[mh * 4 + m][n]));
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 waits for group 1's last phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (slabs) {
+      // The item's 256 x 256 partial sums as ONE 256-KiB slab of plain 16-byte stores (32 per lane, whole KiB per wave instruction), summed into
+      // the 64-bit outputs by pd_slab_reduce_kernel afterwards.  As 64-bit atomics per element (128 per lane and item, 8.6 items per workgroup)
+      // the epilogues were a quarter of the kernel's time with the matrix pipes idle.
+      int* slab = slabs + ((size_t)xcd * tiles * slices_per_xcd + item) * (size_t)(kPdBig * kPdBig) + ((size_t)wave * 32 * 64 + (size_t)lane) * 4;
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          pd_v4i v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (int)acc[m][n][r];  // (FP4: integers up to 2^24 held exactly in f32)
+          *reinterpret_cast<pd_v4i*>(slab + (size_t)(m * 4 + n) * 64 * 4) = v;
+        }
+      continue;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t i = bi * kPdBig + (uint32_t)wr * 128u + (uint32_t)m * 16u + 4u * (uint32_t)(lane >> 4) + (uint32_t)r;
+          const uint32_t j = bj * kPdBig + (uint32_t)wc * 64u + (uint32_t)n * 16u + (uint32_t)(lane & 15);
+          if (i < j && j < n_samples) {
+            const long long v = (long long)acc[m][n][r];
+            if (v != 0) atomicAdd(&out[(size_t)i * n_samples + j], (unsigned long long)(negate ? -v : v));
+          } else if (totals && j == n_samples && i < n_samples) {  // the all-ones row: per-sample totals of the plane
+            const long long v = (long long)acc[m][n][r];
+            if (v != 0) atomicAdd(&totals[i], (unsigned long long)v);
+          }
+        }
+  }
+}
+
+// Sums the slabs pd_gram256p_kernel wrote for one launch into the 64-bit outputs: one thread per (tile pair, wave, MFMA tile, lane) = four
+// elements, over every K slice that exists.  slab layout: [xcd][slice][tile pair][wave][m][n][lane][4] int32.
+__global__ __launch_bounds__(256) void pd_slab_reduce_kernel(const int* __restrict__ slabs, uint32_t nt, uint32_t slices_per_xcd, size_t k_chunk, size_t s_pad,
+                                                             uint32_t n_samples, int negate, unsigned long long* __restrict__ out,
+                                                             unsigned long long* __restrict__ totals) {
+  const uint32_t tiles = nt * (nt + 1) / 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // tile pair * 16384 + vector within the slab
+  if (idx >= (size_t)tiles * 16384) return;
+  const uint32_t tp = (uint32_t)(idx >> 14), e = (uint32_t)(idx & 16383);
+  long long sum[4] = {0, 0, 0, 0};
+  for (uint32_t x = 0; x < 8; ++x)
+    for (uint32_t q = 0; q < slices_per_xcd; ++q) {
+      if (((size_t)x * slices_per_xcd + q) * k_chunk >= s_pad) continue;  // the kernel skipped this slice
+      const pd_v4i v = *reinterpret_cast<const pd_v4i*>(slabs + (((size_t)x * slices_per_xcd + q) * tiles + tp) * (size_t)(kPdBig * kPdBig) + (size_t)e * 4);
+      sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+    }
+  uint32_t t = tp, bi = 0;
+  while (t >= nt - bi) { t -= nt - bi; ++bi; }
+  const uint32_t bj = bi + t;
+  const uint32_t lane = e & 63, mn = (e >> 6) & 31, wave = e >> 11, m = mn >> 2, n = mn & 3, wr = wave >> 2, wc = wave & 3;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t i = bi * kPdBig + wr * 128u + m * 16u + 4u * (lane >> 4) + (uint32_t)r;
+    const uint32_t j = bj * kPdBig + wc * 64u + n * 16u + (lane & 15);
+    const long long v = sum[r];
+    if (v == 0) continue;
+    if (i < j && j < n_samples) out[(size_t)i * n_samples + j] += (unsigned long long)(negate ? -v : v);  // one thread per element: no atomics
+    else if (totals && j == n_samples && i < n_samples) totals[i] += (unsigned long long)v;
   }
 }
 

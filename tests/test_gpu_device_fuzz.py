@@ -239,7 +239,11 @@ def test_pairwise_single_plane_and_general_routes_agree(N):
         "    assert (both[iu] == S).all()\n"
         "print('routes ok')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, N, N, N, N)
-    for env in ({}, {"FMH_PD_TWO_PLANES": "1"}, {"FMH_PD_INT8": "1"}, {"FMH_PD_INT8": "1", "FMH_PD_TWO_PLANES": "1"}):
+    # ... and every Gram route: the phase-interleaved kernel with its slab epilogue (default), with 64-bit atomics instead (FMH_PD_SLABS=0, or slabs
+    # beyond the budget), and round 3's two-stage kernel with its own planes layout (FMH_PD_PHASED=0)
+    for env in ({}, {"FMH_PD_TWO_PLANES": "1"}, {"FMH_PD_INT8": "1"}, {"FMH_PD_INT8": "1", "FMH_PD_TWO_PLANES": "1"},
+                {"FMH_PD_SLABS": "0"}, {"FMH_PD_SLAB_BYTES": "4096", "FMH_PD_TWO_PLANES": "1"}, {"FMH_PD_PHASED": "0"},
+                {"FMH_PD_PHASED": "0", "FMH_PD_INT8": "1", "FMH_PD_TWO_PLANES": "1"}):
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert res.returncode == 0 and "routes ok" in res.stdout, (env, res.stderr[-2000:])
 

@@ -5,7 +5,7 @@
 # `python3 <script>` itself (no env / shell hop between rocprofv3 and the process that touches the GPU).
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp
