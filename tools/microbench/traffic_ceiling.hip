@@ -99,7 +99,7 @@ void run_all(const uint8_t* data, size_t rows, int n_f64, int n_u32, int n_u8, d
   for (int a = 6; a < argc || a == 6; ++a) {
     const int per_cu = a < argc ? atoi(argv[a]) : 4;
     const int grid = cus * per_cu;
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
       float best = 1e9f;
       for (int rep = 0; rep < 30; ++rep) {
         CHECK(hipEventRecord(e0));
@@ -110,6 +110,8 @@ void run_all(const uint8_t* data, size_t rows, int n_f64, int n_u32, int n_u8, d
         if (mode == 4) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 4>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
         if (mode == 5) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 8>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
         if (mode == 6) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 16>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
+        if (mode == 7) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 32>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
+        if (mode == 8) hipLaunchKernelGGL((ceiling_kernel<NV, true, true, 64>), dim3(grid), dim3(256), 0, 0, data, rows, n_f64, n_u32, n_u8, o64, o32, o8, sink);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -119,7 +121,7 @@ void run_all(const uint8_t* data, size_t rows, int n_f64, int n_u32, int n_u8, d
       const double bytes = (mode != 2 ? rd : 0.0) + (mode != 0 ? wr : 0.0);
       printf("{\"mode\": \"%s\", \"rows\": %zu, \"pitch\": %d, \"f64_tracks\": %d, \"u32_tracks\": %d, \"u8_tracks\": %d, \"workgroups_per_cu\": %d, \"best_ms\": %.4f, \"GBs\": %.0f, "
              "\"frac_of_8TBs\": %.3f}\n",
-             mode == 0 ? "read" : mode == 1 ? "read+tracks" : mode == 2 ? "tracks" : mode == 3 ? "read+tracks defer 2" : mode == 4 ? "read+tracks defer 4" : mode == 5 ? "read+tracks defer 8" : "read+tracks defer 16", rows, NV * 16, n_f64, n_u32, n_u8, per_cu, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
+             mode == 0 ? "read" : mode == 1 ? "read+tracks" : mode == 2 ? "tracks" : mode == 3 ? "read+tracks defer 2" : mode == 4 ? "read+tracks defer 4" : mode == 5 ? "read+tracks defer 8" : mode == 6 ? "read+tracks defer 16" : mode == 7 ? "read+tracks defer 32" : "read+tracks defer 64", rows, NV * 16, n_f64, n_u32, n_u8, per_cu, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
       fflush(stdout);
     }
     if (getenv("CEILING_ALIGNED")) {
