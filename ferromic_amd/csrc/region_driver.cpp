@@ -1,1149 +1,13 @@
-// run_vcf — MI355X-native drop-in for the reference's `run_vcf` CLI (src/run_vcf.rs) on the
-// per-site diversity / FST path: same flags (process.rs:67-144), same output surface
-// (output.csv 34 columns, per_site_diversity_output.falsta.gz, per_site_fst_output.falsta.gz,
-// hudson_fst_results.tsv.gz).  Host C++ does text ingest (config TSV, BED/TSV regions, FASTA index,
-// VCF) and the writers; every statistic over genotype data is computed on the GPU through the
-// C-ABI of libferromic_hip.so.  PHYLIP / CDS export and PCA are outside the path.
-#include <malloc.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <emmintrin.h>
-#include <zlib.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cinttypes>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <condition_variable>
-#include <cstring>
-#include <deque>
-#include <dirent.h>
-#include <fcntl.h>
-#include <unistd.h>
-#include <fstream>
-#include <functional>
-#include <map>
-#include <array>
-#include <memory>
-#include <optional>
-#include <set>
-#include <sstream>
-#include <stdexcept>
-#include <string>
-#include <string_view>
-#include <sys/stat.h>
-#include <thread>
-#include <mutex>
-#include <vector>
-
-#include "../../include/ferromic_hip.h"
-#include "host_cpus.hpp"
-#include "deflate_runs.hpp"
+// region_driver.cpp — run_vcf's device side and per-region driver: region matrices over the C-ABI of libferromic_hip.so, the statistics of
+// process.rs:821-1188 and stats.rs on top of the sweeps, CSV-defined populations, the per-config-entry driver (process.rs:2468-3653),
+// flags and main().  Every statistic over genotype data is computed on the GPU.
+#include "run_vcf.hpp"
 
 namespace {
 
+using namespace fmv;
 using std::string;
 using std::vector;
-using namespace fmv;  // CRC-32, gzip members, track sinks (deflate_runs.cpp)
-typedef std::pair<int64_t, int64_t> Interval;  // 0-based half-open unless said otherwise
-
-struct Error : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
-
-// The GPU check (HIP start-up: 0.07-0.2 s) runs on a helper thread under the text ingest; its verdict is polled once per block of VCF text and
-// when the helper is joined.  Not an Error: the per-chromosome handlers must not swallow it.
-struct NoGpuError : std::runtime_error {
-  using std::runtime_error::runtime_error;
-};
-struct GpuCheck {
-  std::atomic<int> state{0};  // 0 = pending or checked up front, 1 = present, 2 = absent
-  string message;
-} g_gpu_check;
-void throw_if_no_gpu() {
-  if (g_gpu_check.state.load(std::memory_order_acquire) == 2) throw NoGpuError(g_gpu_check.message);
-}
-
-void logmsg(const char* level, const string& m) {
-  static const bool quiet = getenv("FERROMIC_PROGRESS") && string(getenv("FERROMIC_PROGRESS")) == "0";
-  if (!quiet || string(level) != "INFO") fprintf(stderr, "[%s] %s\n", level, m.c_str());
-}
-
-// FERROMIC_TIMING=1: stage wall times on stderr as "[TIMING] stage seconds"
-struct StageTimer {
-  const char* stage;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  explicit StageTimer(const char* s) : stage(s) {}
-  ~StageTimer() {
-    static const bool on = getenv("FERROMIC_TIMING") && string(getenv("FERROMIC_TIMING")) == "1";
-    if (on) fprintf(stderr, "[TIMING] %s %.3f\n", stage, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  }
-};
-
-void fmh_check(int status, const char* what) {
-  if (status != FMH_OK) throw Error(string(what) + ": " + fmh_last_error());
-}
-
-// ---- host thread pool in its simplest form: T short-lived threads per parallel stage -----------------------
-unsigned worker_threads() {
-  static const unsigned n = [] {
-    if (const char* e = getenv("FERROMIC_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 256); }
-    return std::max(1u, std::min(fmh_host::usable_cpus(), 64u));  // the process's CPU share, not the machine (host_cpus.hpp)
-  }();
-  return n;
-}
-// Persistent workers: parallel stages are entered once per block of VCF text, per matrix and per region's tracks, so
-// thread start-up per stage would dominate configs with many small regions.  Callers are the main thread or the
-// per-GPU region workers; pool workers never enter parallel_for themselves.
-class ThreadPool {
- public:
-  explicit ThreadPool(unsigned n) {
-    for (unsigned i = 0; i < n; ++i)
-      workers_.emplace_back([this] {
-        for (;;) {
-          std::function<void()> job;
-          {
-            std::unique_lock<std::mutex> lock(m_);
-            cv_.wait(lock, [this] { return stop_ || !jobs_.empty(); });
-            if (stop_ && jobs_.empty()) return;
-            job = std::move(jobs_.front());
-            jobs_.pop_front();
-          }
-          job();
-        }
-      });
-  }
-  ~ThreadPool() {
-    { std::lock_guard<std::mutex> lock(m_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& w : workers_) w.join();
-  }
-  void submit(std::function<void()> job) {
-    { std::lock_guard<std::mutex> lock(m_); jobs_.push_back(std::move(job)); }
-    cv_.notify_one();
-  }
- private:
-  vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_;
-  std::deque<std::function<void()>> jobs_;
-  bool stop_ = false;
-};
-ThreadPool& thread_pool() {
-  static ThreadPool pool(worker_threads());
-  return pool;
-}
-template <class F> void parallel_for(unsigned tasks, F&& fn) {
-  if (tasks <= 1) { if (tasks) fn(0u); return; }
-  struct Sync { std::mutex m; std::condition_variable cv; unsigned left; std::exception_ptr failure; } sync;
-  sync.left = tasks;
-  auto run = [&](unsigned t) {
-    try { fn(t); } catch (...) { std::lock_guard<std::mutex> lock(sync.m); if (!sync.failure) sync.failure = std::current_exception(); }
-    std::lock_guard<std::mutex> lock(sync.m);
-    if (--sync.left == 0) sync.cv.notify_all();
-  };
-  for (unsigned t = 1; t < tasks; ++t) thread_pool().submit([&run, t] { run(t); });
-  run(0u);  // the caller takes a share
-  std::unique_lock<std::mutex> lock(sync.m);
-  sync.cv.wait(lock, [&] { return sync.left == 0; });
-  if (sync.failure) std::rethrow_exception(sync.failure);
-}
-
-// ---- small string helpers ------------------------------------------------------------------------
-vector<string> split(const string& s, char d) {
-  vector<string> out;
-  size_t b = 0;
-  for (;;) {
-    size_t e = s.find(d, b);
-    if (e == string::npos) { out.push_back(s.substr(b)); break; }
-    out.push_back(s.substr(b, e - b));
-    b = e + 1;
-  }
-  return out;
-}
-vector<string> split_ws(const string& s) {
-  vector<string> out;
-  std::istringstream is(s);
-  string t;
-  while (is >> t) out.push_back(t);
-  return out;
-}
-string trim(const string& s) {
-  size_t b = 0, e = s.size();
-  while (b < e && isspace((unsigned char)s[b])) ++b;
-  while (e > b && isspace((unsigned char)s[e - 1])) --e;
-  return s.substr(b, e - b);
-}
-string trim_start_matches(string s, const string& p) {
-  while (s.compare(0, p.size(), p) == 0 && !p.empty()) s = s.substr(p.size());
-  return s;
-}
-bool ends_with(const string& s, const string& x) { return s.size() >= x.size() && s.compare(s.size() - x.size(), x.size(), x) == 0; }
-bool starts_with(const string& s, const string& x) { return s.compare(0, x.size(), x) == 0; }
-// Rust str::parse::<i64>: optional sign, ASCII digits only (strtoll alone would also take leading whitespace)
-bool parse_i64(const string& s, int64_t* out) {
-  size_t i = (!s.empty() && (s[0] == '+' || s[0] == '-')) ? 1 : 0;
-  if (i >= s.size()) return false;
-  for (size_t k = i; k < s.size(); ++k)
-    if (s[k] < '0' || s[k] > '9') return false;
-  char* end = nullptr;
-  errno = 0;
-  long long v = strtoll(s.c_str(), &end, 10);
-  if (errno || *end) return false;
-  *out = v;
-  return true;
-}
-// Rust str::parse::<u8/u16>: optional '+', ASCII digits only
-bool parse_unsigned(const string& s, unsigned max, unsigned* out) {
-  size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
-  if (i >= s.size()) return false;
-  unsigned long v = 0;
-  for (; i < s.size(); ++i) {
-    if (s[i] < '0' || s[i] > '9') return false;
-    v = v * 10 + (s[i] - '0');
-    if (v > max) return false;
-  }
-  *out = (unsigned)v;
-  return true;
-}
-bool file_exists(const string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
-bool is_dir(const string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
-string dirname_of(const string& p) { size_t s = p.find_last_of('/'); return s == string::npos ? "." : (s == 0 ? "/" : p.substr(0, s)); }
-void mkdirs(const string& p) {
-  string cur;
-  for (const string& part : split(p, '/')) {
-    cur += part + "/";
-    if (!part.empty()) mkdir(cur.c_str(), 0777);
-  }
-}
-
-// ---- interval newtypes (process.rs:146-352) --------------------------------------------------------
-Interval from_1based_inclusive(int64_t s, int64_t e) {  // -> 0-based half-open (process.rs:193-206)
-  int64_t a = s < 1 ? 1 : s;
-  int64_t b = e < a ? a : e;
-  return {a - 1, b};
-}
-int64_t hal_len(const Interval& iv) { return (uint64_t)iv.second > (uint64_t)iv.first ? (int64_t)((uint64_t)iv.second - (uint64_t)iv.first) : 0; }
-bool hal_contains(const Interval& iv, int64_t pos) { return (uint64_t)pos >= (uint64_t)iv.first && (uint64_t)pos < (uint64_t)iv.second; }
-bool position_in_regions(int64_t pos, const vector<Interval>& r) {  // process.rs:738-744
-  for (auto& iv : r) if (pos >= iv.first && pos < iv.second) return true;
-  return false;
-}
-int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }  // release-build i64 wrap
-
-// ---- number formatting: Rust `{:.6}` ---------------------------------------------------------------
-string fmt6_printf(double x) {
-  if (std::isnan(x)) return "NaN";
-  if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
-  char buf[64];
-  snprintf(buf, sizeof buf, "%.6f", x);
-  return buf;
-}
-// The same text without printf: a region's tracks are tens of thousands of these (a dense 15-kb region: 65 000, 13 ms of snprintf).
-// |x| = m * 2^e exactly (m < 2^53), so |x| * 10^6 = (m * 10^6) / 2^-e is a 73-bit integer over a power of two: quotient and remainder are
-// exact, the quotient is rounded half to even on the remainder - the decimal expansion of the binary value, correctly rounded, which is
-// what both printf's %.6f and Rust's {:.6} print.  Values of 10^15 and beyond, NaN and infinities take the printf path.
-void fmt6_append(string& out, double x) {
-  if (!(std::fabs(x) < 1e15)) { out += fmt6_printf(x); return; }  // also NaN
-  uint64_t bits;
-  memcpy(&bits, &x, 8);
-  const bool neg = (bits >> 63) != 0;
-  const int be = (int)((bits >> 52) & 0x7FF);
-  uint64_t m = bits & ((1ull << 52) - 1);
-  int e;  // |x| = m * 2^e
-  if (be == 0) e = -1074; else { m |= 1ull << 52; e = be - 1075; }
-  unsigned __int128 q;
-  if (e >= 0) {
-    q = ((unsigned __int128)m << e) * 1000000u;  // |x| < 10^15 < 2^50: m << e < 2^50, the product < 2^70
-  } else {
-    const unsigned __int128 prod = (unsigned __int128)m * 1000000u;  // < 2^73
-    const int s = -e;
-    if (s > 80) q = 0;  // |x| * 10^6 < 2^73 / 2^81: far below one half
-    else {
-      q = prod >> s;
-      const unsigned __int128 rem = prod & ((((unsigned __int128)1) << s) - 1), half = ((unsigned __int128)1) << (s - 1);
-      if (rem > half || (rem == half && (q & 1))) ++q;
-    }
-  }
-  const uint64_t ip = (uint64_t)(q / 1000000u), fp = (uint64_t)(q % 1000000u);
-  char buf[32];
-  int n = 31;
-  buf[n] = 0;
-  uint64_t f = fp;
-  for (int k = 0; k < 6; ++k) { buf[--n] = (char)('0' + f % 10); f /= 10; }
-  buf[--n] = '.';
-  uint64_t i = ip;
-  do { buf[--n] = (char)('0' + i % 10); i /= 10; } while (i);
-  if (neg) buf[--n] = '-';
-  out.append(buf + n, (size_t)(31 - n));
-}
-string fmt6(double x) { string o; fmt6_append(o, x); return o; }
-string fmt_opt(const std::optional<double>& v) { return (!v || std::isnan(*v)) ? "NA" : fmt6(*v); }  // process.rs:3702-3713
-void falsta_div_value(string& out, double v) {  // process.rs:3786-3792
-  if (std::isnan(v)) out += "NA"; else if (v == 0.0) out += '0'; else fmt6_append(out, v);
-}
-void falsta_fst_value(string& out, double v) {  // process.rs:3842-3856
-  if (std::isnan(v)) out += "NA";
-  else if (std::isinf(v)) out += v > 0 ? "Infinity" : "-Infinity";
-  else if (v == 0.0) out += '0';
-  else fmt6_append(out, v);
-}
-
-// ---- data model (process.rs:397-536) --------------------------------------------------------------
-struct Variant {
-  int64_t position = 0;
-  vector<uint8_t> data;  // CompressedGenotypes: 0xFF sentinel
-  size_t stride = 0, num_samples = 0;
-  size_t max_len = 0;  // longest genotype in the row before the sentinel (0 = every sample None)
-  // genotype length of sample i (0 = None)
-  size_t glen(size_t i) const {
-    if (i >= num_samples || stride == 0) return 0;
-    size_t n = 0;
-    while (n < stride && data[i * stride + n] != 0xFF) ++n;
-    return n;
-  }
-};
-
-typedef vector<std::pair<string, std::pair<uint8_t, uint8_t>>> SampleMap;  // insertion-ordered, unique keys
-
-struct ConfigEntry {
-  string seqname;
-  Interval interval;  // 0-based half-open
-  SampleMap samples_unfiltered, samples_filtered;
-};
-
-enum : uint8_t { FLAG_PASS = 0, FLAG_MASK = 1, FLAG_ALLOW = 2, FLAG_LOW_GQ = 4, FLAG_MISSING = 8 };
-
-typedef std::map<string, vector<Interval>> RegionMap;
-
-// ---- parse.rs ---------------------------------------------------------------------------------------
-RegionMap parse_regions_file(const string& path) {  // parse.rs:15-88
-  std::ifstream in(path);
-  if (!in) throw Error("cannot open regions file " + path);
-  const bool is_bed = ends_with(path, ".bed");
-  RegionMap regions;
-  string line;
-  while (std::getline(in, line)) {
-    vector<string> f = split_ws(line);
-    if (f.size() < 3) continue;
-    int64_t s, e;
-    if (!parse_i64(f[1], &s) || !parse_i64(f[2], &e)) continue;
-    regions[trim_start_matches(f[0], "chr")].push_back(is_bed ? Interval{s, e} : from_1based_inclusive(s, e));
-  }
-  for (auto& kv : regions) std::stable_sort(kv.second.begin(), kv.second.end(), [](const Interval& a, const Interval& b) { return (uint64_t)a.first < (uint64_t)b.first; });
-  return regions;
-}
-
-void sample_map_set(SampleMap& m, const string& k, uint8_t l, uint8_t r) {
-  for (auto& kv : m) if (kv.first == k) { kv.second = {l, r}; return; }
-  m.push_back({k, {l, r}});
-}
-
-vector<ConfigEntry> parse_config_file(const string& path) {  // parse.rs:91-239
-  std::ifstream in(path);
-  if (!in) throw Error("cannot open config file " + path);
-  string line;
-  vector<string> headers;
-  vector<ConfigEntry> entries;
-  size_t line_no = 0;
-  while (std::getline(in, line)) {
-    if (!line.empty() && line.back() == '\r') line.pop_back();
-    if (line.empty()) continue;
-    ++line_no;
-    vector<string> rec = split(line, '\t');
-    if (headers.empty()) {
-      headers = rec;
-      if (headers.size() <= 7) throw Error("Parse(\"No sample names found in config file header.\")");
-      continue;
-    }
-    if (rec.size() != headers.size()) throw Error("Parse(\"Mismatched number of fields in record on line " + std::to_string(line_no) + "\")");
-    ConfigEntry e;
-    e.seqname = trim_start_matches(trim(rec[0]), "chr");
-    int64_t s, en;
-    if (!parse_i64(rec[1], &s)) throw Error("Parse(\"Invalid start\")");
-    if (!parse_i64(rec[2], &en)) throw Error("Parse(\"Invalid end\")");
-    e.interval = from_1based_inclusive(s, en);
-    for (size_t i = 7; i < rec.size(); ++i) {
-      const string& field = rec[i];
-      const string& name = headers[i];
-      const string g = split(field, '_')[0];
-      if (g.size() >= 3 && g[1] == '|' && isdigit((unsigned char)g[0]) && isdigit((unsigned char)g[2])) {
-        const int l = g[0] - '0', r = g[2] - '0';
-        if (l <= 1 && r <= 1) sample_map_set(e.samples_unfiltered, name, (uint8_t)l, (uint8_t)r);
-      }
-      if (field == "0|0" || field == "0|1" || field == "1|0" || field == "1|1")
-        sample_map_set(e.samples_filtered, name, (uint8_t)(field[0] - '0'), (uint8_t)(field[2] - '0'));
-    }
-    if (e.samples_unfiltered.empty()) continue;
-    entries.push_back(std::move(e));
-  }
-  if (headers.empty()) throw Error("empty config file");
-  return entries;
-}
-
-Interval parse_region(const string& r) {  // parse.rs:241-261
-  vector<string> p = split(r, '-');
-  int64_t s, e;
-  if (p.size() != 2) throw Error("InvalidRegion(\"Invalid region format. Use start-end\")");
-  if (!parse_i64(p[0], &s)) throw Error("InvalidRegion(\"Invalid start position\")");
-  if (!parse_i64(p[1], &e)) throw Error("InvalidRegion(\"Invalid end position\")");
-  if (s >= e) throw Error("InvalidRegion(\"Start position must be less than end position\")");
-  return from_1based_inclusive(s, e);
-}
-
-string find_vcf_file(const string& folder, const string& chr) {  // parse.rs:263-515
-  if (!is_dir(folder)) throw Error("VCF folder does not exist: " + folder);
-  for (const string& pat : {"chr" + chr + ".vcf.gz", "chr" + chr + ".vcf", chr + ".vcf.gz", chr + ".vcf"})
-    if (file_exists(folder + "/" + pat)) return folder + "/" + pat;
-  auto boundary_match = [&](const string& name) {
-    for (const string& pat : {"chr" + chr, chr}) {
-      size_t from = 0;
-      for (;;) {
-        size_t idx = name.find(pat, from);
-        if (idx == string::npos) break;
-        const bool after_ok = idx + pat.size() >= name.size() || !isdigit((unsigned char)name[idx + pat.size()]);
-        const bool before_ok = idx == 0 || !isdigit((unsigned char)name[idx - 1]);
-        if (after_ok && before_ok) return true;
-        from = idx + 1;
-      }
-    }
-    return false;
-  };
-  auto prefix_boundary = [](const string& name, const string& prefix) {
-    if (!starts_with(name, prefix)) return false;
-    return name.size() == prefix.size() || !isdigit((unsigned char)name[prefix.size()]);
-  };
-  vector<std::pair<int, string>> cands;
-  DIR* d = opendir(folder.c_str());
-  if (!d) throw Error("cannot read directory " + folder);
-  while (dirent* ent = readdir(d)) {
-    const string name = ent->d_name;
-    if (!(ends_with(name, ".vcf") || ends_with(name, ".vcf.gz"))) continue;
-    bool aux = false;
-    for (const char* x : {".csi", ".tbi", ".idx", ".md5", ".bai"}) aux |= ends_with(name, x);
-    if (aux || !boundary_match(name)) continue;
-    int score = 0;
-    if (name == "chr" + chr + ".vcf.gz") score += 100;
-    else if (name == "chr" + chr + ".vcf") score += 90;
-    else if (name == chr + ".vcf.gz") score += 80;
-    else if (name == chr + ".vcf") score += 70;
-    if (ends_with(name, ".vcf.gz")) score += 15;
-    if (prefix_boundary(name, "chr" + chr)) score += 10;
-    else if (prefix_boundary(name, chr)) score += 5;
-    score -= (int)(name.size() / 5);
-    cands.push_back({-score, folder + "/" + name});
-  }
-  closedir(d);
-  if (cands.empty()) throw Error("NoVcfFiles");
-  std::sort(cands.begin(), cands.end());
-  return cands[0].second;
-}
-
-// line reader over plain or (multi-member) gzip files
-// BGZF (bgzip / htslib) is a series of independent gzip members of <= 64 KiB, each announcing its compressed size in a
-// 'BC' extra subfield: the blocks of a batch are inflated in parallel, so a .vcf.gz from bgzip is ingested about as fast
-// as plain text.  Any other gzip stream stays on zlib's serial reader.
-struct BgzfSource {
-  int fd = -1;
-  int64_t file_off = 0;
-  bool file_eof = false;
-  vector<unsigned char> raw;  // compressed bytes not yet consumed
-  string out;                 // inflated text of the current batch
-  size_t out_pos = 0;
-
-  static bool is_bgzf(const string& path) {
-    unsigned char h[18];
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    const ssize_t got = pread(fd, h, sizeof h, 0);
-    close(fd);
-    return got == (ssize_t)sizeof h && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
-  }
-  explicit BgzfSource(const string& path) : fd(open(path.c_str(), O_RDONLY)) {
-    if (fd < 0) throw Error("cannot open " + path);
-  }
-  ~BgzfSource() { if (fd >= 0) close(fd); }
-
-  bool refill() {  // inflate the next batch of blocks into `out`; false at end of file
-    out.clear();
-    out_pos = 0;
-    for (;;) {
-      if (!file_eof) {
-        const size_t want = (size_t)32 << 20, had = raw.size();
-        raw.resize(had + want);
-        size_t got_total = 0;
-        while (got_total < want) {
-          const ssize_t got = pread(fd, raw.data() + had + got_total, want - got_total, file_off);
-          if (got <= 0) { file_eof = true; break; }
-          got_total += (size_t)got;
-          file_off += got;
-        }
-        raw.resize(had + got_total);
-      }
-      struct Block { size_t data, clen, isize, out_off; };
-      vector<Block> blocks;
-      size_t pos = 0, total = 0;
-      while (pos + 18 <= raw.size()) {
-        const unsigned char* h = raw.data() + pos;
-        if (!(h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4))) throw Error("corrupt BGZF block header");
-        const size_t xlen = h[10] | (h[11] << 8);
-        if (pos + 12 + xlen > raw.size()) break;
-        size_t bsize = 0;
-        for (size_t x = 12; x + 4 <= 12 + xlen;) {  // extra subfields: SI1 SI2 SLEN(2) data
-          const size_t slen = h[x + 2] | (h[x + 3] << 8);
-          if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] | (h[x + 5] << 8)) + 1;
-          x += 4 + slen;
-        }
-        if (!bsize || bsize < 12 + xlen + 8) throw Error("BGZF block without a BC size field");
-        if (pos + bsize > raw.size()) break;  // block not complete yet
-        const unsigned char* tail = raw.data() + pos + bsize - 4;
-        const size_t isize = (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
-        blocks.push_back({pos + 12 + xlen, bsize - 12 - xlen - 8, isize, total});
-        total += isize;
-        pos += bsize;
-      }
-      if (blocks.empty()) {
-        if (file_eof) { if (!raw.empty() && pos < raw.size()) throw Error("truncated BGZF file"); return false; }
-        continue;  // need more bytes for one whole block
-      }
-      out.resize(total);
-      std::atomic<size_t> next{0};
-      std::atomic<bool> bad{false};
-      parallel_for((unsigned)std::min<size_t>(worker_threads(), blocks.size()), [&](unsigned) {
-        for (;;) {
-          const size_t i = next.fetch_add(1);
-          if (i >= blocks.size()) break;
-          const Block& b = blocks[i];
-          if (b.isize == 0) continue;
-          z_stream z;
-          memset(&z, 0, sizeof z);
-          if (inflateInit2(&z, -15) != Z_OK) { bad = true; continue; }
-          z.next_in = raw.data() + b.data;
-          z.avail_in = (uInt)b.clen;
-          z.next_out = (Bytef*)&out[b.out_off];
-          z.avail_out = (uInt)b.isize;
-          const int rc = inflate(&z, Z_FINISH);
-          if (rc != Z_STREAM_END || z.avail_out != 0) bad = true;
-          inflateEnd(&z);
-        }
-      });
-      if (bad) throw Error("BGZF block failed to inflate");
-      raw.erase(raw.begin(), raw.begin() + (ptrdiff_t)pos);
-      if (total == 0) { if (file_eof && raw.empty()) return false; continue; }  // only empty (EOF marker) blocks in this batch
-      return true;
-    }
-  }
-  size_t read(char* dst, size_t n) {
-    size_t done = 0;
-    while (done < n) {
-      if (out_pos == out.size() && !refill()) break;
-      const size_t take = std::min(n - done, out.size() - out_pos);
-      memcpy(dst + done, out.data() + out_pos, take);
-      out_pos += take;
-      done += take;
-    }
-    return done;
-  }
-  bool next_line(string& line) {
-    line.clear();
-    for (;;) {
-      if (out_pos == out.size() && !refill()) return !line.empty();
-      const char* base = out.data() + out_pos;
-      const void* nl = memchr(base, '\n', out.size() - out_pos);
-      const size_t take = nl ? (size_t)((const char*)nl - base) + 1 : out.size() - out_pos;
-      line.append(base, take);
-      out_pos += take;
-      if (nl) return true;
-    }
-  }
-};
-
-struct LineReader {
-  gzFile f;
-  std::unique_ptr<BgzfSource> bgzf;
-  explicit LineReader(const string& path) : f(nullptr), path_(path) {
-    if (BgzfSource::is_bgzf(path)) { bgzf.reset(new BgzfSource(path)); return; }
-    f = gzopen(path.c_str(), "rb");
-    if (!f) throw Error("cannot open " + path);
-    gzbuffer(f, 1 << 20);
-  }
-  ~LineReader() { if (f) gzclose(f); if (raw_fd >= 0) close(raw_fd); if (map_base) munmap((void*)map_base, map_len); }
-  int raw_fd = -1;
-  int64_t raw_off = 0;
-  string path_;
-  size_t read(char* dst, size_t n) {  // raw bytes following whatever next() consumed
-    if (bgzf) return bgzf->read(dst, n);
-    if (raw_fd < 0 && gzdirect(f)) {  // plain text: skip zlib's copy and read the file itself from here on
-      raw_off = (int64_t)gztell(f);
-      raw_fd = open(path_.c_str(), O_RDONLY);
-    }
-    if (raw_fd >= 0) {
-      size_t total = 0;
-      while (total < n) {
-        const ssize_t got = pread(raw_fd, dst + total, n - total, raw_off);
-        if (got <= 0) break;
-        total += (size_t)got;
-        raw_off += got;
-      }
-      return total;
-    }
-    size_t total = 0;
-    while (total < n) {
-      const int got = gzread(f, dst + total, (unsigned)std::min<size_t>(n - total, 1u << 30));
-      if (got <= 0) break;
-      total += (size_t)got;
-    }
-    return total;
-  }
-  // Plain text only: the rest of the file (whatever follows the lines next() consumed) as one read-only mapping, so the
-  // body is parsed where the page cache holds it - no read() copy, no reader thread.  False for gzip / BGZF input.
-  const char* map_base = nullptr;
-  size_t map_len = 0;
-  bool map_rest(const char** base, size_t* len) {
-    if (bgzf || !gzdirect(f)) return false;
-    const int64_t off = (int64_t)gztell(f);
-    const int fd = open(path_.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size <= 0 || off > st.st_size) { close(fd); return false; }
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return false;
-    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-    map_base = (const char*)m;
-    map_len = (size_t)st.st_size;
-    *base = map_base + off;
-    *len = map_len - (size_t)off;
-    return true;
-  }
-  bool next(string& out) {
-    if (bgzf) return bgzf->next_line(out);
-    out.clear();
-    char buf[1 << 16];
-    for (;;) {
-      if (!gzgets(f, buf, sizeof buf)) return !out.empty();
-      out += buf;
-      if (!out.empty() && out.back() == '\n') return true;
-    }
-  }
-};
-
-struct FaiEntry { int64_t len, offset, line_bases, line_width; };
-
-std::map<string, FaiEntry> read_fai(const string& reference) {
-  std::ifstream in(reference + ".fai");
-  if (!in) throw Error("Failed to open reference index " + reference + ".fai");
-  std::map<string, FaiEntry> out;
-  string line;
-  while (std::getline(in, line)) {
-    vector<string> f = split(line, '\t');
-    if (f.size() < 5) continue;
-    FaiEntry e;
-    if (parse_i64(f[1], &e.len) && parse_i64(f[2], &e.offset) && parse_i64(f[3], &e.line_bases) && parse_i64(f[4], &e.line_width)) out[f[0]] = e;
-  }
-  return out;
-}
-
-string read_reference_sequence(const string& reference, const string& chr) {  // process.rs:1915-1952, parse.rs:545-650
-  auto fai = read_fai(reference);
-  auto it = fai.find(chr);
-  if (it == fai.end()) it = fai.find("chr" + chr);
-  if (it == fai.end()) throw Error("Chromosome " + chr + " not found in reference");
-  const FaiEntry& e = it->second;
-  std::ifstream in(reference, std::ios::binary);
-  if (!in) throw Error("Failed to open reference file " + reference);
-  string seq;
-  seq.reserve((size_t)e.len);
-  int64_t pos = 0;
-  vector<char> buf((size_t)std::max<int64_t>(e.line_bases, 1));
-  while (pos < e.len) {
-    const int64_t line_idx = pos / e.line_bases, col = pos % e.line_bases;
-    const int64_t take = std::min(e.line_bases - col, e.len - pos);
-    in.seekg(e.offset + line_idx * e.line_width + col);
-    in.read(buf.data(), take);
-    if (in.gcount() != take) throw Error("Failed to read sequence for " + chr);
-    seq.append(buf.data(), (size_t)take);
-    pos += take;
-  }
-  return seq;
-}
-
-vector<Interval> find_n_regions(const string& seq) {  // process.rs:1849-1874
-  vector<Interval> out;
-  bool in_n = false;
-  size_t start = 0;
-  for (size_t i = 0; i < seq.size(); ++i) {
-    const bool is_n = seq[i] == 'N' || seq[i] == 'n';
-    if (is_n && !in_n) { in_n = true; start = i; }
-    else if (!is_n && in_n) { in_n = false; out.push_back({(int64_t)start, (int64_t)i}); }
-  }
-  if (in_n) out.push_back({(int64_t)start, (int64_t)seq.size()});
-  return out;
-}
-
-vector<Interval> merge_intervals(vector<Interval> v) {  // process.rs:762-783
-  if (v.empty()) return v;
-  std::stable_sort(v.begin(), v.end(), [](const Interval& a, const Interval& b) { return (uint64_t)a.first < (uint64_t)b.first; });
-  vector<Interval> out;
-  Interval cur = v[0];
-  for (size_t i = 1; i < v.size(); ++i) {
-    if ((uint64_t)v[i].first <= (uint64_t)cur.second) cur.second = (int64_t)std::max((uint64_t)cur.second, (uint64_t)v[i].second);
-    else { out.push_back(cur); cur = v[i]; }
-  }
-  out.push_back(cur);
-  return out;
-}
-
-string normalize_chr_prefix(const string& c) {
-  for (const char* p : {"chr", "Chr", "CHR"}) if (starts_with(c, p)) return c.substr(3);
-  return c;
-}
-
-// ---- string_view twins of the helpers above for the per-cell hot loop (no allocation per genotype cell) ------
-typedef std::string_view sv;
-sv trim_sv(sv s) {
-  size_t b = 0, e = s.size();
-  while (b < e && isspace((unsigned char)s[b])) ++b;
-  while (e > b && isspace((unsigned char)s[e - 1])) --e;
-  return s.substr(b, e - b);
-}
-bool parse_unsigned_sv(sv s, unsigned max, unsigned* out) {  // Rust str::parse::<u8/u16>: optional '+', ASCII digits only
-  size_t i = (!s.empty() && s[0] == '+') ? 1 : 0;
-  if (i >= s.size()) return false;
-  unsigned long v = 0;
-  for (; i < s.size(); ++i) {
-    if (s[i] < '0' || s[i] > '9') return false;
-    v = v * 10 + (unsigned long)(s[i] - '0');
-    if (v > max) return false;
-  }
-  *out = (unsigned)v;
-  return true;
-}
-// the k-th ':'-separated part of a cell; false when the cell has fewer parts
-bool colon_part(sv cell, size_t k, sv* out) {
-  size_t b = 0;
-  for (size_t i = 0;; ++i) {
-    const size_t e = cell.find(':', b);
-    if (i == k) { *out = cell.substr(b, e == sv::npos ? sv::npos : e - b); return true; }
-    if (e == sv::npos) return false;
-    b = e + 1;
-  }
-}
-
-// per-thread scratch reused across lines
-struct VariantScratch {
-  vector<sv> cells;       // the kept sample columns of the line
-  vector<uint32_t> off;   // start of sample s in vals
-  vector<uint16_t> len;   // parsed alleles of sample s
-  vector<uint8_t> none;   // 1 = genotype is None
-  vector<uint8_t> vals;
-};
-
-// process_variant, process.rs:4471-4768.  Returns false when the line yields no variant.  `line` keeps its
-// trailing newline exactly as the reference's read_line buffer does.
-bool process_variant(sv line, const string& chr, const vector<Interval>& regions, const vector<size_t>& kept,
-                     unsigned min_gq, const RegionMap* allow, const RegionMap* mask, VariantScratch& scr, Variant* out, uint8_t* out_flags) {
-  // The nine fixed fields are cut first; the sample columns are then walked in place, one pass: a typical line is
-  // thousands of 7-byte cells, and tokenising it into a vector before looking at any cell cost more than parsing it.
-  // Every failure below makes the reference skip the line (an Err is printed and dropped, None is dropped), so only the
-  // set of conditions matters, not the order they are found in.
-  const char* const lbeg = line.data();
-  const char* const lend = lbeg + line.size();
-  sv fields[9];
-  const char* cur = lbeg;
-  bool more = true;  // a tab followed the last field cut so far
-  for (int f = 0; f < 9; ++f) {
-    if (!more) throw Error("Invalid VCF line format");
-    const char* t = (const char*)memchr(cur, '\t', (size_t)(lend - cur));
-    fields[f] = sv(cur, (size_t)((t ? t : lend) - cur));
-    more = t != nullptr;
-    cur = t ? t + 1 : lend;
-  }
-  const string vcf_chr = normalize_chr_prefix(string(trim_sv(fields[0])));
-  const bool chr_ok = vcf_chr == normalize_chr_prefix(trim(chr));
-  int64_t pos1 = 0;
-  const bool pos_ok = parse_i64(string(fields[1]), &pos1);
-  // the reference checks the column count before anything else; a short line is an error even on another chromosome,
-  // which is the same outcome (skipped) as the None of a foreign chromosome - so the cheap exits come first
-  if (!chr_ok) return false;
-  if (!pos_ok) throw Error("Invalid position");
-  if (pos1 < 1) throw Error("Invalid 1-based pos");
-  const int64_t pos0 = pos1 - 1;
-  bool in_regions = false;
-  for (auto& r : regions) if (hal_contains(r, pos0)) { in_regions = true; break; }
-  if (!in_regions) return false;
-  uint8_t flags = FLAG_PASS;
-  if (allow) {
-    auto it = allow->find(vcf_chr);
-    if (it != allow->end()) { if (!position_in_regions(pos0, it->second)) flags |= FLAG_ALLOW; }
-    else flags |= FLAG_ALLOW;
-  }
-  if (mask) {
-    auto it = mask->find(vcf_chr);
-    if (it != mask->end())
-      for (auto& m : it->second)
-        if (std::max<uint64_t>((uint64_t)pos0, (uint64_t)m.first) < std::min<uint64_t>((uint64_t)pos0 + 1, (uint64_t)m.second)) { flags |= FLAG_MASK; break; }
-  }
-  bool indel = fields[3].size() != 1;
-  if (!indel) {
-    const sv alts = fields[4];
-    for (size_t b = 0;;) {
-      const size_t e = alts.find(',', b);
-      if ((e == sv::npos ? alts.size() : e) - b != 1) indel = true;
-      if (e == sv::npos) break;
-      b = e + 1;
-    }
-  }
-  size_t gq_index = SIZE_MAX;
-  {
-    const sv fmt = fields[8];
-    size_t b = 0;
-    for (size_t i = 0;; ++i) {
-      const size_t e = fmt.find(':', b);
-      if (fmt.substr(b, e == sv::npos ? sv::npos : e - b) == "GQ") { gq_index = i; break; }
-      if (e == sv::npos) break;
-      b = e + 1;
-    }
-  }
-  const size_t n = kept.size();
-  scr.off.resize(n); scr.len.resize(n); scr.none.resize(n); scr.cells.resize(n);
-  scr.vals.clear();
-  bool low_gq = false, missing = false;
-  size_t max_len = 0;
-  // Whole-line fast path: every kept cell is "a|b:GQ[:...]" with one-digit alleles, GQ second, and no sample column is skipped.  The
-  // alleles go straight into the packed row, nothing else is recorded per cell; the first cell that looks different sends the whole
-  // line through the general walk below (same acceptance rules as its per-cell shortcut, so the outcome is the same).
-  if (gq_index == 1 && n && more && kept[0] == 9 && kept[n - 1] == 8 + n) {
-    scr.vals.resize(2 * n);
-    uint8_t* dst = scr.vals.data();
-    const char* p = cur;
-    size_t i = 0;
-    bool low = false;
-    for (; i < n; ++i) {
-      if (lend - p < 5) break;
-      const unsigned a = (unsigned)(p[0] - '0'), b = (unsigned)(p[2] - '0');
-      if (a > 9u || b > 9u || p[3] != ':' || (p[1] != '|' && p[1] != '/')) break;
-      const char* q = p + 4;
-      unsigned v = 0;
-      while (q < lend && (unsigned)(*q - '0') < 10u && v < 100000u) { v = v * 10 + (unsigned)(*q - '0'); ++q; }
-      if (q == p + 4 || v > 65535u) break;
-      if (q < lend && *q == ':') { const char* t = (const char*)memchr(q, '\t', (size_t)(lend - q)); q = t ? t : lend; }
-      else if (q < lend && *q == '\n' && q + 1 == lend) q = lend;
-      else if (q < lend && *q != '\t') break;
-      dst[2 * i] = (uint8_t)a;
-      dst[2 * i + 1] = (uint8_t)b;
-      low |= v < min_gq;
-      if (q == lend) { ++i; break; }  // the line ends with this cell
-      p = q + 1;
-    }
-    if (i == n) {
-      // all n cells were taken (a line that ends early leaves i < n and is reported by the general walk)
-      if (low) flags |= FLAG_LOW_GQ;
-      if (indel) return false;
-      out->position = pos0;
-      out->num_samples = n;
-      out->stride = 2;
-      out->max_len = 2;
-      out->data.swap(scr.vals);
-      scr.vals.clear();
-      *out_flags = flags;
-      return true;
-    }
-    scr.vals.clear();
-  }
-  size_t col = 9;  // column index of the field that starts at `cur` (valid while `more`)
-  for (size_t i = 0; i < n; ++i) {
-    // skip to column kept[i] (ascending: the header is read left to right)
-    while (col < kept[i]) {
-      if (!more) throw Error("Invalid VCF line format: missing genotype column");
-      const char* t = (const char*)memchr(cur, '\t', (size_t)(lend - cur));
-      more = t != nullptr;
-      cur = t ? t + 1 : lend;
-      ++col;
-    }
-    if (!more) throw Error("Invalid VCF line format: missing genotype column");
-    const char* c = cur;
-    const size_t room = (size_t)(lend - c);
-    scr.off[i] = (uint32_t)scr.vals.size();
-    const char* cell_end = nullptr;
-    bool fast = false;
-    // the overwhelmingly common cell "a|b:GQ..." with one-digit alleles and GQ second: parsed where it stands
-    if (gq_index == 1 && room >= 5 && c[3] == ':' && (c[1] == '|' || c[1] == '/') && (unsigned)(c[0] - '0') < 10u && (unsigned)(c[2] - '0') < 10u) {
-      size_t j = 4;
-      unsigned v = 0;
-      while (j < room && (unsigned)(c[j] - '0') < 10u && v < 100000u) { v = v * 10 + (unsigned)(c[j] - '0'); ++j; }
-      if (j > 4 && v <= 65535u) {
-        if (j == room || c[j] == '\t') { cell_end = c + j; fast = true; }
-        else if (c[j] == '\n' && j + 1 == room) { cell_end = lend; fast = true; }
-        else if (c[j] == ':') { const char* t = (const char*)memchr(c + j, '\t', room - j); cell_end = t ? t : lend; fast = true; }
-      }
-      if (fast) {
-        scr.vals.push_back((uint8_t)(c[0] - '0'));
-        scr.vals.push_back((uint8_t)(c[2] - '0'));
-        scr.len[i] = 2;
-        scr.none[i] = 2;  // called, and its GQ is already judged
-        max_len = std::max<size_t>(max_len, 2);
-        if (v < min_gq) low_gq = true;
-      }
-    }
-    if (!cell_end) { const char* t = (const char*)memchr(c, '\t', room); cell_end = t ? t : lend; }
-    const sv cell(c, (size_t)(cell_end - c));
-    scr.cells[i] = cell;
-    more = cell_end != lend;
-    cur = more ? cell_end + 1 : lend;
-    ++col;
-    if (fast) continue;
-    const sv alleles = cell.substr(0, cell.find(':'));
-    scr.len[i] = 0;
-    scr.none[i] = 1;
-    if (alleles == "." || alleles == "./." || alleles == ".|.") continue;
-    bool ok = true;
-    size_t b = 0, cnt = 0;
-    for (size_t j = 0; j <= alleles.size(); ++j) {
-      if (j == alleles.size() || alleles[j] == '|' || alleles[j] == '/') {
-        unsigned v;
-        if (!parse_unsigned_sv(alleles.substr(b, j - b), 255, &v)) { ok = false; break; }
-        scr.vals.push_back((uint8_t)v);
-        ++cnt;
-        b = j + 1;
-      }
-    }
-    if (!ok) { scr.vals.resize(scr.off[i]); continue; }
-    scr.none[i] = 0;
-    scr.len[i] = (uint16_t)std::min<size_t>(cnt, 65535);
-    max_len = std::max(max_len, cnt);
-  }
-  if (gq_index == SIZE_MAX) throw Error("GQ field not found in FORMAT");
-  for (size_t i = 0; i < n; ++i) {
-    if (scr.none[i] == 2) continue;
-    if (scr.none[i]) { missing = true; continue; }
-    sv part;
-    if (!colon_part(scr.cells[i], gq_index, &part)) throw Error("GQ value missing in sample genotype field");
-    const sv gq_str = trim_sv(part);
-    unsigned gq = 0;
-    if (!(gq_str == "." || gq_str.empty())) { if (!parse_unsigned_sv(gq_str, 65535, &gq)) gq = 0; }
-    if (gq < min_gq) low_gq = true;
-  }
-  if (low_gq) flags |= FLAG_LOW_GQ;
-  if (missing) flags |= FLAG_MISSING;
-  if (indel) return false;
-  // CompressedGenotypes::new, process.rs:440-477
-  size_t max_ploidy = max_len;
-  if (n) max_ploidy = std::max<size_t>(max_ploidy, 1);
-  out->position = pos0;
-  out->num_samples = n;
-  out->stride = max_ploidy;
-  out->max_len = max_len;
-  if (scr.vals.size() == n * max_ploidy && max_ploidy == 2 && !missing) {
-    // nothing is None, no genotype is longer than two alleles and there are 2 n alleles in all: every genotype is a called
-    // diploid one (the usual line) and the parsed alleles already ARE the packed row
-    out->data.swap(scr.vals);
-    scr.vals.clear();
-    *out_flags = flags;
-    return true;
-  }
-  out->data.assign(n * max_ploidy, 0xFF);
-  for (size_t s2 = 0; s2 < n; ++s2)
-    if (scr.none[s2] != 1) {
-      const uint8_t* src = &scr.vals[scr.off[s2]];
-      uint8_t* dst = &out->data[s2 * max_ploidy];
-      for (size_t k = 0, m = std::min<size_t>(scr.len[s2], max_ploidy); k < m; ++k) dst[k] = src[k];
-    }
-  *out_flags = flags;
-  return true;
-}
-
-struct VcfData {
-  vector<Variant> variants;
-  vector<uint8_t> flags;
-  vector<string> sample_names;
-};
-
-vector<string> read_sample_names_from_vcf(const string& path) {  // run_vcf.rs:190-214
-  LineReader r(path);
-  string line;
-  while (r.next(line)) {
-    if (starts_with(line, "#CHROM")) {
-      vector<string> f = split_ws(line);
-      if (f.size() <= 9) throw Error("VCF header found, but no sample columns");
-      return vector<string>(f.begin() + 9, f.end());
-    }
-  }
-  throw Error("No #CHROM line found in VCF header");
-}
-
-VcfData process_vcf(const string& path, const string& chr, const vector<Interval>& regions, unsigned min_gq,
-                    const RegionMap* mask, const RegionMap* allow, const std::set<string>& exclusion) {  // process.rs:4092-4469
-  VcfData d;
-  vector<size_t> kept;
-  LineReader r(path);
-  string line;
-  bool header = false;
-  while (r.next(line)) {
-    if (starts_with(line, "##")) continue;
-    if (starts_with(line, "#CHROM")) {
-      string h = line;
-      vector<string> tabs = split(h, '\t');
-      static const char* req[9] = {"#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"};
-      bool ok = tabs.size() >= 9;
-      for (int i = 0; ok && i < 9; ++i) ok = tabs[i] == req[i];
-      if (!ok) throw Error("InvalidVcfFormat(\"Invalid VCF header format\")");
-      vector<string> f = split_ws(h);
-      for (size_t i = 9; i < f.size(); ++i) if (!exclusion.count(f[i])) { d.sample_names.push_back(f[i]); kept.push_back(i); }
-      header = true;
-      break;
-    }
-  }
-  if (!header || d.sample_names.empty()) throw Error("Parse(\"No samples remain after applying exclusions\")");
-  // Body: blocks of whole lines are cut from the (gunzipped) stream and parsed by a pool of threads, each on a
-  // contiguous run of lines; results are concatenated in file order, so the outcome equals a serial read
-  // (the reference runs the same stage as a reader thread + rayon consumers, process.rs:4274-4392).
-  vector<std::pair<Variant, uint8_t>> items;
-  const unsigned T = worker_threads();
-  // one block of whole lines: cut into T line-aligned runs, each parsed by one pool thread; results keep the file order
-  auto parse_block = [&](const char* bdata, size_t usable) {
-    struct { const char* d; const char* data() const { return d; } } block{bdata};
-    // line-aligned cut points
-    vector<size_t> cut(T + 1, usable);
-    cut[0] = 0;
-    for (unsigned t = 1; t < T; ++t) {
-      size_t p = std::max(cut[t - 1], usable * t / T);
-      if (p < usable) { const void* q = memchr(block.data() + p, '\n', usable - p); p = q ? (size_t)((const char*)q - block.data()) + 1 : usable; }
-      cut[t] = p;
-    }
-    vector<vector<std::pair<Variant, uint8_t>>> parts(T);
-    vector<string> complaints(T);
-    throw_if_no_gpu();
-    StageTimer tparse("    ingest:parse_block");
-    parallel_for(T, [&](unsigned t) {
-      VariantScratch scr;
-      size_t b = cut[t];
-      const size_t end = cut[t + 1];
-      while (b < end) {
-        const void* q = memchr(block.data() + b, '\n', end - b);
-        const size_t e = q ? (size_t)((const char*)q - block.data()) + 1 : end;
-        Variant v;
-        uint8_t fl;
-        try {
-          if (process_variant(sv(block.data() + b, e - b), chr, regions, kept, min_gq, allow, mask, scr, &v, &fl)) parts[t].push_back({std::move(v), fl});
-        } catch (const Error& err) {
-          complaints[t] += string(err.what()) + "\n";  // the collector prints and carries on (process.rs:4358-4360)
-        }
-        b = e;
-      }
-    });
-    for (unsigned t = 0; t < T; ++t) {
-      if (!complaints[t].empty()) fputs(complaints[t].c_str(), stderr);
-      for (auto& it : parts[t]) items.push_back(std::move(it));
-    }
-  };
-  const char* mapped = nullptr;
-  size_t mapped_len = 0;
-  static const bool env_no_mmap = getenv("FERROMIC_NO_MMAP") != nullptr;
-  if (!env_no_mmap && r.map_rest(&mapped, &mapped_len)) {
-    // plain text: blocks are windows of the mapping, each ending at a line end (a line longer than a block is one block)
-    const size_t kWindow = getenv("FERROMIC_INGEST_BLOCK") ? std::max<size_t>(16, (size_t)atoll(getenv("FERROMIC_INGEST_BLOCK"))) : ((size_t)64 << 20);
-    size_t off = 0;
-    while (off < mapped_len) {
-      size_t bsize = std::min(kWindow, mapped_len - off);
-      if (off + bsize < mapped_len) {
-        const void* nl = memrchr(mapped + off, '\n', bsize);
-        if (nl) {
-          bsize = (size_t)((const char*)nl - (mapped + off)) + 1;
-        } else {
-          const void* nl2 = memchr(mapped + off + bsize, '\n', mapped_len - off - bsize);
-          bsize = nl2 ? (size_t)((const char*)nl2 - (mapped + off)) + 1 : mapped_len - off;
-        }
-      }
-      parse_block(mapped + off, bsize);
-      off += bsize;
-    }
-  } else {
-    string cur, next, carry, spill;
-    // (FERROMIC_INGEST_BLOCK / FERROMIC_INGEST_HEAD shrink the two sizes so that tests cross block borders on small files)
-    const size_t kBlock = getenv("FERROMIC_INGEST_BLOCK") ? std::max<size_t>(16, (size_t)atoll(getenv("FERROMIC_INGEST_BLOCK"))) : ((size_t)64 << 20);
-    const size_t kHead = getenv("FERROMIC_INGEST_HEAD") ? (size_t)atoll(getenv("FERROMIC_INGEST_HEAD")) : ((size_t)4 << 20);  // room in front of every block for the unfinished line of the previous one
-    bool eof = false;
-    // the next block is read (and inflated) by a helper thread while this one is parsed; the two buffers are allocated
-    // once and a block is never copied: the carried-over partial line is written into the headroom in front of it
-    auto fetch = [&r, kBlock, kHead](string* dst) -> size_t { if (dst->size() != kHead + kBlock) dst->resize(kHead + kBlock); return r.read(&(*dst)[kHead], kBlock); };
-    size_t next_got = fetch(&next);
-    while (!eof) {
-      cur.swap(next);
-      const size_t got = next_got;
-      if (got < kBlock) eof = true;
-      const char* bdata;
-      size_t bsize;
-      if (carry.size() <= kHead) {
-        memcpy(&cur[kHead - carry.size()], carry.data(), carry.size());
-        bdata = cur.data() + (kHead - carry.size());
-        bsize = carry.size() + got;
-      } else {  // a line longer than the headroom: the slow way, once
-        spill.assign(carry);
-        spill.append(cur.data() + kHead, got);
-        bdata = spill.data();
-        bsize = spill.size();
-      }
-      std::thread reader;
-      if (!eof) reader = std::thread([&] { next_got = fetch(&next); });
-      struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) { StageTimer w("    ingest:wait_for_reader"); t.join(); } } } joiner{reader};
-      size_t usable = bsize;
-      if (!eof) {
-        const void* nlp = memrchr(bdata, '\n', bsize);
-        if (!nlp) { carry.assign(bdata, bsize); continue; }
-        usable = (size_t)((const char*)nlp - bdata) + 1;
-        carry.assign(bdata + usable, bsize - usable);
-      } else {
-        carry.clear();
-      }
-      if (usable) parse_block(bdata, usable);
-    }
-  }
-  StageTimer tsort("    ingest:sort_and_store");
-  std::stable_sort(items.begin(), items.end(), [](const auto& a, const auto& b) {
-    if (a.first.position != b.first.position) return a.first.position < b.first.position;
-    return a.first.data < b.first.data;  // lexicographic on the flat genotype bytes (process.rs:4397-4405)
-  });
-  for (auto& it : items) { d.variants.push_back(std::move(it.first)); d.flags.push_back(it.second); }
-  return d;
-}
-
-// ---- sample-name mapping (process.rs:1192-1333) -----------------------------------------------------
-string normalize_sample_name(const string& n) { return (ends_with(n, "_L") || ends_with(n, "_R")) ? n.substr(0, n.size() - 2) : n; }
-
-std::map<string, size_t> map_sample_names_to_indices(const vector<string>& names) {
-  std::map<string, size_t> exact;
-  std::map<string, std::optional<size_t>> alias;
-  for (size_t i = 0; i < names.size(); ++i) {
-    exact[names[i]] = i;
-    const size_t us = names[i].rfind('_');
-    if (us != string::npos) {
-      const string suffix = names[i].substr(us + 1);
-      auto it = alias.find(suffix);
-      if (it == alias.end()) alias[suffix] = i;
-      else if (!(it->second && *it->second == i)) it->second = std::nullopt;
-    }
-  }
-  for (auto& kv : alias) if (kv.second && !exact.count(kv.first)) exact[kv.first] = *kv.second;
-  return exact;
-}
-
-typedef vector<std::pair<size_t, int>> HapList;  // (sample index, side)
-
-HapList haplotypes_for_group(uint8_t group, const SampleMap& filter, const std::map<string, size_t>& index) {
-  HapList out;
-  for (auto& kv : filter) {
-    auto it = index.find(normalize_sample_name(kv.first));
-    if (it == index.end()) continue;
-    if (kv.second.first == group) out.push_back({it->second, 0});
-    if (kv.second.second == group) out.push_back({it->second, 1});
-  }
-  return out;
-}
 
 // ---- device side --------------------------------------------------------------------------------------
 struct GroupsHandle;
@@ -1715,7 +579,6 @@ void process_variants_pair(const vector<const Variant*>& vs, const RegionMatrix&
   }
 }
 
-struct WcSite { int64_t pos1; double overall_fst, overall_num, overall_den, pair_fst, pair_num, pair_den; };
 struct WcRegion {
   bool computed = false;
   // overall FstEstimate pieces for the CSV (extract_wc_fst_components, stats.rs:4860-4914)
@@ -1960,438 +823,6 @@ HudsonRegion hudson_groups(const vector<const Variant*>& vs, const RegionMatrix&
   }
   if (out.pi0 && out.pi1) out.avg = 0.5 * (*out.pi0 + *out.pi1);
   return out;
-}
-
-// ---- writers --------------------------------------------------------------------------------------------
-const char* kCsvHeader[34] = {
-    "chr", "region_start", "region_end", "0_sequence_length", "1_sequence_length", "0_sequence_length_adjusted",
-    "1_sequence_length_adjusted", "0_segregating_sites", "1_segregating_sites", "0_w_theta", "1_w_theta", "0_pi", "1_pi",
-    "0_segregating_sites_filtered", "1_segregating_sites_filtered", "0_w_theta_filtered", "1_w_theta_filtered",
-    "0_pi_filtered", "1_pi_filtered", "0_num_hap_no_filter", "1_num_hap_no_filter", "0_num_hap_filter", "1_num_hap_filter",
-    "inversion_freq_no_filter", "inversion_freq_filter", "haplotype_overall_fst_wc", "haplotype_between_pop_variance_wc",
-    "haplotype_within_pop_variance_wc", "haplotype_num_informative_sites_wc", "hudson_fst_hap_group_0v1",
-    "hudson_dxy_hap_group_0v1", "hudson_pi_hap_group_0", "hudson_pi_hap_group_1", "hudson_pi_avg_hap_group_0v1"};
-
-string csv_field(const string& f) {  // csv crate default quoting: only when needed
-  if (f.find_first_of(",\"\n\r") == string::npos) return f;
-  string o = "\"";
-  for (char c : f) { if (c == '"') o += '"'; o += c; }
-  return o + "\"";
-}
-string join(const vector<string>& v, char d, bool csv_quote = false) {
-  string o;
-  for (size_t i = 0; i < v.size(); ++i) { if (i) o += d; o += csv_quote ? csv_field(v[i]) : v[i]; }
-  return o;
-}
-
-void gz_append(const string& path, const string& text) {  // open_append_compressed: one gzip member per call
-  gzFile f = gzopen(path.c_str(), "ab");
-  if (!f) throw Error("cannot open " + path);
-  for (size_t off = 0; off < text.size();) {
-    const size_t n = std::min<size_t>(text.size() - off, (size_t)1 << 30);
-    if (gzwrite(f, text.data() + off, (unsigned)n) <= 0) { gzclose(f); throw Error("write failed: " + path); }
-    off += n;
-  }
-  gzclose(f);
-}
-
-// (the CRC-32, the zlib member writer, the track sinks and the run-aware DEFLATE writer live in deflate_runs.cpp)
-
-// FALSTA tracks of one region: every track is formatted and deflated on its own thread and lands in the file as
-// its own gzip member, in track order (the files are multi-member already: one member per region in the
-// reference; readers see the same decompressed text).
-// One track: write(sink) puts header + line into the sink and returns false (having written nothing) when the track is not to appear;
-// `records` / `tokens` say how dense it is (values against positions), which picks the writer.
-struct TrackFn {
-  std::function<bool(TrackSink&)> write;
-  size_t records = 0, tokens = 0;
-  string text() const { TextSink t; return write(t) ? std::move(t.out) : string(); }  // tests, --print_formats
-};
-// `files` = one list of tracks per output file; returns, per file, the gzip members of its tracks in order (empty tracks dropped).
-// All tracks form one batch: formatted and deflated on the pool when they are large, inline when the whole region is small (hundreds of
-// small regions are compressed by their region workers side by side; waking the pool for 40-kB tracks cost more than deflating them).
-std::atomic<unsigned> g_region_workers{1};  // region workers running side by side (set by run())
-vector<vector<string>> compress_tracks(const vector<vector<TrackFn>>& files, size_t approx_tokens) {
-  vector<std::pair<size_t, size_t>> jobs;  // (file, track)
-  for (size_t f = 0; f < files.size(); ++f) for (size_t t = 0; t < files[f].size(); ++t) jobs.push_back({f, t});
-  vector<string> members(jobs.size());
-  std::atomic<size_t> next{0};
-  auto work = [&](unsigned) {
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= jobs.size()) break;
-      const TrackFn& track = files[jobs[i].first][jobs[i].second];
-      // mostly runs (fewer than one value per eight positions): the run-aware writer; dense: the text through zlib (entropy-coded values).
-      // FERROMIC_TRACK_WRITER=zlib | runs forces one of them (tests run both).
-      static const char* forced = getenv("FERROMIC_TRACK_WRITER");
-      const bool runs = forced ? strcmp(forced, "runs") == 0 : track.records * 8 < track.tokens;
-      if (runs) {
-        RunDeflateSink sink(track.records >= 48);  // a member with a few dozen values repays the tuned code's 60-byte header
-        if (track.write(sink)) members[i] = sink.finish();
-      } else {
-        const string text = track.text();
-        if (!text.empty()) members[i] = gzip_member(text);
-      }
-    }
-  };
-  // inline when the tracks are tiny; else the shared pool, however many region workers there are (500 regions of 2-25 kb, 16 CPUs:
-  // 2 / 4 / 8 / 16 workers 3.9 / 2.0 / 1.1 / 0.73 ms per region inline, 1.1-1.2 / 0.65-0.69 / 0.63-0.68 / 0.74 through the pool,
-  // profiles/r03/run_vcf_tracks_pool_or_inline.jsonl).  FERROMIC_TRACKS_POOL=0 | 1 forces one of them (measurement).
-  static const int force = getenv("FERROMIC_TRACKS_POOL") ? atoi(getenv("FERROMIC_TRACKS_POOL")) : -1;
-  if (force == 0 || (force < 0 && approx_tokens * jobs.size() < ((size_t)1 << 16))) work(0u);
-  else parallel_for((unsigned)std::min<size_t>(worker_threads(), jobs.size()), work);
-  vector<vector<string>> out(files.size());
-  for (size_t i = 0; i < jobs.size(); ++i) if (!members[i].empty()) out[jobs[i].first].push_back(std::move(members[i]));
-  return out;
-}
-void append_members(const string& path, const vector<string>& members) {
-  if (members.empty()) return;
-  FILE* f = fopen(path.c_str(), "ab");
-  if (!f) throw Error("cannot open " + path);
-  for (const string& m : members)
-    if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); throw Error("write failed: " + path); }
-  fclose(f);
-}
-
-struct RegionOutput {
-  vector<string> csv_row;
-  string seqname;
-  int64_t region_start1 = 0, region_end1 = 0;
-  vector<std::tuple<int64_t, double, double, int, bool>> diversity;  // (pos1, pi, theta, group, filtered)
-  vector<WcSite> wc_sites;
-  vector<std::tuple<int64_t, double, double, double>> hudson_sites;
-  vector<vector<string>> hudson_rows;
-  vector<vector<string>> wc_rows;
-  vector<string> diversity_members, fst_members;  // the region's FALSTA tracks as gzip members, made by the region's worker
-};
-
-// One dense FALSTA line: `n` comma-joined tokens, `dflt` everywhere except at the positions present, where the
-// LAST record of a position wins (the reference assigns into a Vec in record order).
-// Written into a TrackSink: the gaps between records are runs of (comma + default token).
-template <class PosAt, class TokenAt>
-bool falsta_line(TrackSink& out, const Interval& region, int64_t n, size_t count, PosAt pos_at, TokenAt token_at, const char* dflt,
-                 vector<int32_t>& slot) {
-  const size_t dl = strlen(dflt);
-  string unit(1, ',');
-  unit.append(dflt, dl);  // ",0" / ",NA": what a default position adds to a line that has begun
-  // `tokens` default positions starting at position `at` of the line
-  auto default_run = [&](int64_t at, size_t tokens) {
-    if (!tokens) return;
-    if (at == 0) { out.text(dflt, dl); --tokens; }
-    out.run(unit.data(), unit.size(), tokens);
-  };
-  string tok;
-  // Records in ascending position order (the usual case: variants are sorted): the gaps between them are runs of the default token;
-  // equal positions are neighbours, so "the last record wins" is "skip a record whose successor has its position".
-  bool ascending = true;
-  for (size_t i = 1; i < count && ascending; ++i) ascending = pos_at(i - 1) <= pos_at(i);
-  if (ascending) {
-    bool any_rec = false;
-    int64_t next_k = 0;  // first position of the line not written yet
-    for (size_t i = 0; i < count; ++i) {
-      const int64_t p = pos_at(i) - 1;
-      if (!hal_contains(region, p)) continue;
-      any_rec = true;
-      if (i + 1 < count && pos_at(i + 1) - 1 == p) continue;
-      const int64_t k = p - region.first;
-      default_run(next_k, (size_t)(k - next_k));
-      tok.clear();
-      if (k) tok.push_back(',');
-      token_at(tok, i);
-      out.text(tok);
-      next_k = k + 1;
-    }
-    if (n > next_k) default_run(next_k, (size_t)(n - next_k));
-    out.text("\n", 1);
-    return any_rec;
-  }
-  slot.assign((size_t)n, -1);
-  bool any = false;
-  for (size_t i = 0; i < count; ++i) {
-    const int64_t p = pos_at(i) - 1;
-    if (!hal_contains(region, p)) continue;
-    slot[(size_t)(p - region.first)] = (int32_t)i;
-    any = true;
-  }
-  for (int64_t k = 0; k < n; ++k) {
-    tok.clear();
-    if (k) tok.push_back(',');
-    if (slot[(size_t)k] < 0) tok.append(dflt, dl);
-    else token_at(tok, (size_t)slot[(size_t)k]);
-    out.text(tok);
-  }
-  out.text("\n", 1);
-  return any;
-}
-// is any record of the track inside the region? (a diversity track without one is not written at all)
-template <class PosAt>
-bool falsta_any(const Interval& region, size_t count, PosAt pos_at) {
-  for (size_t i = 0; i < count; ++i) if (hal_contains(region, pos_at(i) - 1)) return true;
-  return false;
-}
-
-vector<TrackFn> diversity_tracks(const RegionOutput& r) {  // append_diversity_falsta, process.rs:3740-3806
-  vector<TrackFn> tracks;
-  if (r.diversity.empty()) return tracks;
-  const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
-  const int64_t n = hal_len(region);
-  if (n > (int64_t)1 << 31 || r.diversity.size() >= (size_t)1 << 31) throw Error("region too long for a dense FALSTA track");
-  std::set<int> gids;
-  for (auto& d : r.diversity) gids.insert(std::get<3>(d));
-  struct Spec { bool filtered; bool is_pi; const char* prefix; };
-  static const Spec specs[4] = {{false, true, "unfiltered_pi_"}, {false, false, "unfiltered_theta_"}, {true, true, "filtered_pi_"}, {true, false, "filtered_theta_"}};
-  for (int g : gids)
-    for (const Spec& sp : specs)
-    {
-      TrackFn track;
-      track.tokens = (size_t)n;
-      for (auto& d : r.diversity) track.records += std::get<3>(d) == g && std::get<4>(d) == sp.filtered;
-      track.write = [&r, region, n, g, sp](TrackSink& out) -> bool {
-        vector<size_t> sel;  // records of this (group, filter) in record order
-        for (size_t i = 0; i < r.diversity.size(); ++i)
-          if (std::get<3>(r.diversity[i]) == g && std::get<4>(r.diversity[i]) == sp.filtered) sel.push_back(i);
-        auto pos_at = [&](size_t i) { return std::get<0>(r.diversity[sel[i]]); };
-        if (!falsta_any(region, sel.size(), pos_at)) return false;
-        out.text(">" + string(sp.prefix) + "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" +
-                 std::to_string(r.region_end1) + "_group_" + std::to_string(g) + "\n");
-        vector<int32_t> slot;
-        falsta_line(out, region, n, sel.size(), pos_at,
-                    [&](string& o, size_t i) { const auto& d = r.diversity[sel[i]]; falsta_div_value(o, sp.is_pi ? std::get<1>(d) : std::get<2>(d)); }, "0", slot);
-        return true;
-      };
-      tracks.push_back(std::move(track));
-    }
-  return tracks;
-}
-
-vector<TrackFn> fst_tracks(const RegionOutput& r) {  // append_fst_falsta, process.rs:3809-4003
-  vector<TrackFn> tracks;
-  if (r.wc_sites.empty() && r.hudson_sites.empty()) return tracks;
-  const Interval region = from_1based_inclusive(r.region_start1, r.region_end1);
-  const int64_t n = hal_len(region);
-  if (n > (int64_t)1 << 31 || r.wc_sites.size() >= (size_t)1 << 31 || r.hudson_sites.size() >= (size_t)1 << 31)
-    throw Error("region too long for a dense FALSTA track");
-  const string suffix = "chr_" + r.seqname + "_start_" + std::to_string(r.region_start1) + "_end_" + std::to_string(r.region_end1);
-  auto add = [&](const string& header, size_t count, auto getter) {  // getter(i) -> (position, value); no std::function on the per-record path
-    TrackFn track;
-    track.tokens = (size_t)n;
-    track.records = count;
-    track.write = [=](TrackSink& out) -> bool {
-      out.text(">" + header + "_" + suffix + "\n");
-      vector<int32_t> slot;
-      falsta_line(out, region, n, count, [&](size_t i) { return getter(i).first; }, [&](string& o, size_t i) { falsta_fst_value(o, getter(i).second); }, "NA", slot);
-      return true;
-    };
-    tracks.push_back(std::move(track));
-  };
-  if (!r.wc_sites.empty()) {
-    const vector<WcSite>* w = &r.wc_sites;
-    add("haplotype_overall_fst_summary", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].overall_fst); });
-    add("haplotype_overall_fst_numerator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].overall_num); });
-    add("haplotype_overall_fst_denominator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].overall_den); });
-    add("haplotype_0v1_pairwise_fst_summary", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].pair_fst); });
-    add("haplotype_0v1_pairwise_fst_numerator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].pair_num); });
-    add("haplotype_0v1_pairwise_fst_denominator", w->size(), [w](size_t i) { return std::make_pair((*w)[i].pos1, (*w)[i].pair_den); });
-  }
-  if (!r.hudson_sites.empty()) {
-    const auto* h = &r.hudson_sites;
-    add("hudson_pairwise_fst_hap_0v1", h->size(), [h](size_t i) { return std::make_pair(std::get<0>((*h)[i]), std::get<1>((*h)[i])); });
-    add("hudson_pairwise_fst_hap_0v1_numerator", h->size(), [h](size_t i) { return std::make_pair(std::get<0>((*h)[i]), std::get<2>((*h)[i])); });
-    add("hudson_pairwise_fst_hap_0v1_denominator", h->size(), [h](size_t i) { return std::make_pair(std::get<0>((*h)[i]), std::get<3>((*h)[i])); });
-  }
-  return tracks;
-}
-
-const char* kHudsonTsvHeader = "chr\tregion_start_0based\tregion_end_0based\tpop1_id_type\tpop1_id_name\tpop2_id_type\tpop2_id_name\tDxy\tpi_pop1\tpi_pop2\tpi_xy_avg\tFST\n";  // process.rs:1576-1590
-const char* kWcTsvHeader = "chr\tregion_start_1based\tregion_end_1based\tcomparison_type\tpop1\tpop2\tfst\tnumerator_a\tdenominator_a_plus_b\tinformative_sites\n";  // process.rs:1628-1650
-
-// --print_formats (no GPU): the header lines of every output file and the FALSTA records the writers produce for one tiny
-// made-up region, so that the output surface can be pinned against the reference's committed exemplars
-// (data/output.csv, data/FST_data.tsv, data/per_site_diversity_output.falsta.gz) on a machine without a GPU.
-int print_formats() {
-  vector<string> header(kCsvHeader, kCsvHeader + 34);
-  printf("output.csv\t%s\n", join(header, ',', true).c_str());
-  printf("hudson_fst_results.tsv\t%s", kHudsonTsvHeader);
-  printf("wc_fst_results.tsv\t%s", kWcTsvHeader);
-  RegionOutput r;
-  r.seqname = "1";
-  r.region_start1 = 5;
-  r.region_end1 = 12;
-  for (int g = 0; g < 2; ++g)
-    for (int f = 0; f < 2; ++f) {
-      r.diversity.push_back({6, 0.289855, 0.267788, g, f != 0});
-      r.diversity.push_back({9, NAN, NAN, g, f != 0});
-      r.diversity.push_back({11, 0.0, 0.0, g, f != 0});
-    }
-  r.wc_sites.push_back({6, 0.5, 0.25, 0.5, 0.5, 0.25, 0.5});
-  r.wc_sites.push_back({9, NAN, 0.0, 0.0, INFINITY, 1.0, 0.0});
-  r.hudson_sites.push_back({6, 1.0, 1.0, 1.0});
-  r.hudson_sites.push_back({7, -0.5, -0.5, 1.0});
-  r.hudson_sites.push_back({11, NAN, 0.0, 0.0});
-  for (auto& t : diversity_tracks(r)) printf("per_site_diversity_output.falsta\t%s", t.text().c_str());
-  for (auto& t : fst_tracks(r)) printf("per_site_fst_output.falsta\t%s", t.text().c_str());
-  return 0;
-}
-
-// The adversarial tracks of --check_writers / --dump_writer_cases: both default tokens, runs of every length around 258 and its multiples, dense
-// and sparse, records at the first and the last position, unsorted records, empty lines.  `next` is the caller's xorshift stream; the SAME
-// track is written twice (text sink, then run-aware sink) by replaying the record list drawn the first time.
-struct AdversarialTrack { const char* dflt; int64_t n; vector<std::pair<int64_t, double>> recs; };
-template <class Next> void adversarial_track(int rep, Next& next, TrackSink& out, bool replay = false) {
-  static thread_local AdversarialTrack t;
-  if (!replay) {
-    t.dflt = (rep & 1) ? "NA" : "0";
-    t.n = rep < 8 ? rep : (int64_t)(next() % (rep % 7 == 0 ? 700000 : 3000));
-    t.recs.clear();
-    const uint64_t gap = 1 + next() % (rep % 5 == 0 ? 3 : 600);
-    for (int64_t p = (int64_t)(next() % 3); p < t.n; p += 1 + (int64_t)(next() % gap)) t.recs.push_back({1001 + p, (double)(next() >> 11) / 9007199254740992.0});
-    if (rep % 11 == 0 && t.n > 0) { t.recs.insert(t.recs.begin(), {1001, 0.5}); t.recs.push_back({1000 + t.n, -0.25}); }
-    for (size_t special : {(size_t)258, (size_t)259, (size_t)260, (size_t)261, (size_t)516, (size_t)517, (size_t)130})  // gaps that hit the match-length edges
-      if (rep % 13 == 0 && (int64_t)(special * 3) < t.n) t.recs.push_back({t.recs.empty() ? 1001 + (int64_t)special : t.recs.back().first + (int64_t)special, 1.0});
-    if (rep % 17 != 0) std::sort(t.recs.begin(), t.recs.end()); else if (t.recs.size() > 2) std::swap(t.recs[0], t.recs[t.recs.size() / 2]);  // (the unsorted path too)
-  }
-  const Interval region{1000, 1000 + t.n};
-  out.text(string(">header_") + t.dflt + "\n");
-  vector<int32_t> slot;
-  falsta_line(out, region, t.n, t.recs.size(), [&](size_t i) { return t.recs[i].first; }, [&](string& o, size_t i) { falsta_fst_value(o, t.recs[i].second); }, t.dflt, slot);
-}
-
-// --dump_writer_cases DIR [N] (no GPU): N adversarial tracks (default 60), each as DIR/case_<k>.txt (the text), .runs.gz (the run-aware writer's
-// member, fixed and tuned code sets alternating) and .zlib.gz (the same text through zlib level 1): tests/test_output_formats_cpu.py inflates
-// both members with zlib AND Python's gzip module and compares all of them with the text.
-int dump_writer_cases(const string& dir, int count) {
-  mkdirs(dir);
-  uint64_t state = 0x243F6A8885A308D3ull;
-  auto next = [&] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
-  auto put = [&](const string& path, const string& bytes) {
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f || fwrite(bytes.data(), 1, bytes.size(), f) != bytes.size()) throw Error("cannot write " + path);
-    fclose(f);
-  };
-  for (int k = 0; k < count; ++k) {
-    const int rep = k < 20 ? k : 7 * k + 3;  // the tiny regions, then a spread over the generator's cases (multiples of 7: up to 700 000 positions)
-    TextSink text;
-    RunDeflateSink runs(k % 2 == 0);
-    adversarial_track(rep, next, text);
-    adversarial_track(rep, next, runs, true);
-    const string base = dir + "/case_" + std::to_string(k);
-    put(base + ".txt", text.out);
-    put(base + ".runs.gz", runs.finish());
-    put(base + ".zlib.gz", gzip_member(text.out));
-  }
-  printf("%d writer cases in %s\n", count, dir.c_str());
-  return 0;
-}
-
-// --check_writers N (no GPU; self-checks of the output writers): the CRC-32 against zlib's, the run-aware gzip writer against the text writer
-// through zlib's inflate, and fmt6 against printf's %.6f on N pseudo-random doubles of every magnitude a statistic can take, exact ties
-// (k / 128 and their neighbours one ulp away), values next to a carry (0.9999995, 9.9999995, ...), zeros and subnormals.
-int check_fmt6(size_t n) {
-  uint64_t state = 0x9E3779B97F4A7C15ull;
-  auto next = [&] { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
-  size_t bad = 0, checked = 0;
-  auto check = [&](double v) {
-    ++checked;
-    const string a = fmt6(v), b = fmt6_printf(v);
-    if (a != b && bad++ < 10) fprintf(stderr, "fmt6 mismatch: %.17g -> '%s' vs printf '%s'\n", v, a.c_str(), b.c_str());
-  };
-  const double specials[] = {0.0, -0.0, 5e-7, 4.9999999999999998e-7, 5.0000000000000004e-7, 1.5e-6, 2.5e-6, 0.9999995, 0.99999949999999994, 9.9999995,
-                             99.9999995, 1e-300, -1e-300, 4.9e-324, 1e15, 999999999999999.9, 123456789012345.67, 0.1, 0.2, 0.3, 1.0 / 3.0, 2.0 / 3.0,
-                             1e-6, 1e-7, 0.000001499999999, 0.0078125, -0.0078125, 0.0234375, NAN, INFINITY, -INFINITY, 1e16, -1e22};
-  for (double v : specials) { check(v); check(-v); check(std::nextafter(v, 1e300)); check(std::nextafter(v, -1e300)); }
-  for (int k = 0; k < 200000; ++k) {  // exact ties of the sixth decimal and their neighbours
-    const double t = (double)k / 128.0;
-    check(t); check(std::nextafter(t, 1e300)); check(std::nextafter(t, -1e300)); check(-t);
-  }
-  for (size_t i = 0; i < n; ++i) {
-    const uint64_t r = next();
-    double v;
-    switch (r % 5) {
-      case 0: v = (double)(next() >> 11) / 9007199254740992.0; break;                                  // [0, 1)
-      case 1: v = ((double)(next() >> 11) / 9007199254740992.0) * std::pow(10.0, (double)((int)(r >> 8 & 31) - 12)); break;  // 1e-12 .. 1e19
-      case 2: { uint64_t b = next(); b = (b & 0x800FFFFFFFFFFFFFull) | ((uint64_t)(1023 - 40 + (r >> 8) % 80) << 52); memcpy(&v, &b, 8); break; }  // 2^-40 .. 2^40
-      case 3: v = (double)((int64_t)(next() % 2000000000) - 1000000000) / 1000000.0 + ((r >> 8 & 1) ? 5e-7 : 0.0); break;            // near six-decimal grid points / half-way points
-      default: { uint64_t b = next(); memcpy(&v, &b, 8); break; }                                                                        // any bit pattern
-    }
-    check(v);
-  }
-  printf("fmt6: %zu values checked against printf, %zu differ\n", checked, bad);
-  size_t crc_bad = 0, crc_checked = 0;
-  vector<uint8_t> buf(70000);
-  for (int rep = 0; rep < 400; ++rep) {
-    for (auto& b : buf) b = (uint8_t)(next() >> 56);
-    const size_t off = (size_t)(next() % 9), len = (size_t)(next() % (buf.size() - 8));
-    ++crc_checked;
-    if (crc32_slice8(buf.data() + off, len) != (uint32_t)crc32(0L, buf.data() + off, (uInt)len)) ++crc_bad;
-  }
-  const string member = gzip_member(string(100000, 'x') + "tail");
-  printf("crc32: %zu buffers checked against zlib, %zu differ; a 100 004-byte member is %zu bytes\n", crc_checked, crc_bad, member.size());
-  // the run-aware gzip writer against the text writer: random tracks (both default tokens, runs of every length around 258 and its multiples,
-  // dense and sparse, records at the first and the last position, empty lines), each member inflated by zlib - which also verifies the
-  // CRC-32 and the length of the trailer - and compared with the text
-  auto inflate_member = [](const string& m, string& out) {
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, 15 + 16) != Z_OK) return false;
-    out.clear();
-    out.resize(1 << 16);
-    z.next_in = (Bytef*)m.data();
-    z.avail_in = (uInt)m.size();
-    size_t off = 0;
-    int rc;
-    do {
-      if (out.size() - off < (1 << 15)) out.resize(out.size() * 2);
-      z.next_out = (Bytef*)&out[off];
-      z.avail_out = (uInt)(out.size() - off);
-      rc = inflate(&z, Z_NO_FLUSH);
-      off = out.size() - z.avail_out;
-    } while (rc == Z_OK);
-    inflateEnd(&z);
-    out.resize(off);
-    return rc == Z_STREAM_END && z.avail_in == 0;
-  };
-  size_t tracks_checked = 0, tracks_bad = 0;
-  for (int rep = 0; rep < 600; ++rep) {
-    TextSink text;
-    RunDeflateSink runs(rep % 2 == 0);  // both code sets
-    adversarial_track(rep, next, text);
-    adversarial_track(rep, next, runs, /*replay=*/true);
-    const string member2 = runs.finish();
-    string back;
-    ++tracks_checked;
-    if (!inflate_member(member2, back) || back != text.out) {
-      if (tracks_bad++ < 5) fprintf(stderr, "run-aware member differs: rep %d, text %zu bytes, inflated %zu\n", rep, text.out.size(), back.size());
-    }
-    string back2;
-    if (!inflate_member(gzip_member(text.out), back2) || back2 != text.out) ++tracks_bad;
-  }
-  printf("run-aware gzip writer: %zu tracks inflated by zlib and compared with the text, %zu differ\n", tracks_checked, tracks_bad);
-  return bad || crc_bad || tracks_bad ? 1 : 0;
-}
-
-// --bench_tracks [variants [length]] (no GPU): formats and deflates the tracks of a made-up 15-kb region (or `length` bp) with 120 variants (or `variants`), 500 times on one thread;
-// what the writers cost per small region.
-int bench_tracks(int variants, int length) {  // 120 = a variant every 125 bp; 3 750 = every 4 bp (tools/run_vcf_many_regions.py's cohort)
-  RegionOutput r;
-  r.seqname = "1";
-  r.region_start1 = 1000;
-  r.region_end1 = 1000 + length - 1;
-  const int step = std::max(1, length / std::max(variants, 1));
-  for (int g = 0; g < 2; ++g)
-    for (int f = 0; f < 2; ++f)
-      for (int i = 0; i < variants; ++i) r.diversity.push_back({1000 + step * i, 0.289855 + i * 1e-5, 0.267788 + i * 1e-6, g, f != 0});
-  for (int i = 0; i < variants; ++i) {
-    r.wc_sites.push_back({1000 + step * i, 0.5 + i * 1e-6, 0.25, 0.5, 0.5, 0.25 + i * 1e-6, 0.5});
-    r.hudson_sites.push_back({1000 + step * i, 0.25 + i * 1e-6, 0.125, 0.5});
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  size_t bytes = 0, members = 0;
-  const int reps = length > 100000 ? 20 : 500;
-  for (int rep = 0; rep < reps; ++rep)
-    for (auto& file : compress_tracks({diversity_tracks(r), fst_tracks(r)}, (size_t)length)) for (auto& m : file) { bytes += m.size(); ++members; }
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
-  printf("tracks of one region: %.3f ms, %zu members, %zu bytes\n", ms, members / (size_t)reps, bytes / (size_t)reps);
-  return 0;
 }
 
 // ---- per-region driver (process.rs:2468-3653) ----------------------------------------------------------------
