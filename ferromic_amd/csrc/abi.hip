@@ -82,6 +82,8 @@ const OptionRow kOptionRows[] = {
     {"FMH_FLAT_SLOTS", &Options::flat_slots, 0, nullptr},
     {"FMH_FLAT_DEFER", &Options::flat_defer, 0, nullptr},
     {"FMH_WC_EXACT", &Options::wc_exact, 1, nullptr},
+    {"FMH_WC_BI_TOTALS", &Options::wc_bi_totals, 1, nullptr},
+    {"FMH_WC_BI_REPLICAS", &Options::wc_bi_replicas, 0, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -1518,30 +1520,62 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   if (totals_only) {
     // chunks of whole tiles of sixteen sites; enough of them to fill the chip with the pairs' workgroups, at most 1 024 (the partials are
     // nslots x chunks x 24 B), at least one tile each
-    const size_t pair_blocks = (nslots - 1 + 255) / 256;
+    // biallelic and nothing missing, up to 64 groups: wc_pair_totals_biallelic_kernel (R replicas of every pair, blocks sized to the items)
+    const bool bi = pre && !general && n_groups <= kWcBiGroupsMax && options().wc_bi_totals.load() != 0;
+    const size_t npairs = nslots - 1;
+    size_t R = 1, bi_blocks = 1, bi_threads = 256;
+    if (bi) {
+      // replicas: lanes launched per item (the last wave of every workgroup is partly idle) against what every further workgroup of a chunk
+      // costs - each stages the whole tile and waits out its barriers with less arithmetic per tile.  5 % per workgroup orders the measured
+      // replica counts of 12, 26 and 40 groups at 2 M sites correctly (profiles/r04/wc_many_groups_pair_kernel_trace.csv): 4, 4, 1.
+      double best = 1e30;
+      for (size_t r = 1; r <= 8; r *= 2) {
+        const size_t blocks = (npairs * r + 511) / 512;
+        const size_t threads = std::max<size_t>(std::max<size_t>(256, round_up(8 * G, (size_t)64)), round_up((npairs * r + blocks - 1) / blocks, (size_t)64));
+        const double cost = (double)(blocks * threads) / (double)(npairs * r) * (1.0 + 0.05 * (double)blocks);
+        if (cost < best) { best = cost; R = r; }
+      }
+      if (const long long v = options().wc_bi_replicas.load(); v == 1 || v == 2 || v == 4 || v == 8) R = (size_t)v;
+      bi_blocks = (npairs * R + 511) / 512;
+      // at least 8 threads per group: a thread stages at most four cells of a tile (G x 32 cells)
+      bi_threads = std::max<size_t>(std::max<size_t>(256, round_up(8 * G, (size_t)64)), round_up((npairs * R + bi_blocks - 1) / bi_blocks, (size_t)64));
+    }
+    const size_t pair_blocks = bi ? bi_blocks : (nslots - 1 + 255) / 256;
     // (about 8 000 workgroups: a CU holds five or so at a time and a launch of only eight per CU ran in two uneven rounds; the partials stay below 4 M entries)
-    size_t chunks = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8192, ((size_t)4 << 20) / nslots), (8192 + pair_blocks - 1) / pair_blocks));
-    size_t chunk_rows = round_up((row_count + chunks - 1) / chunks, (size_t)kWcTotTile);
+    size_t chunks = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8192 / R, ((size_t)4 << 20) / (nslots * R)), (8192 + pair_blocks - 1) / pair_blocks));
+    const size_t tile_rows = bi ? (size_t)kWcBiTile : (size_t)kWcTotTile;
+    size_t chunk_rows = round_up((row_count + chunks - 1) / chunks, tile_rows);
     chunks = (row_count + chunk_rows - 1) / chunk_rows;
+    const size_t parts = chunks * R;  // partial sums per slot; the overall kernel is launched over as many (shorter) chunks
+    const size_t overall_rows = (row_count + parts - 1) / parts;
     double *pa = nullptr, *pb = nullptr;
     unsigned long long* pi = nullptr;
-    FMH_TRY(scratch.get(&pa, nslots * chunks));
-    FMH_TRY(scratch.get(&pb, nslots * chunks));
-    FMH_TRY(scratch.get(&pi, nslots * chunks));
+    FMH_TRY(scratch.get(&pa, nslots * parts));
+    FMH_TRY(scratch.get(&pb, nslots * parts));
+    FMH_TRY(scratch.get(&pi, nslots * parts));
     FMH_TRY(scratch.get(&sa, nslots));
     FMH_TRY(scratch.get(&sb, nslots));
     FMH_TRY(scratch.get(&si, nslots));
-    hipLaunchKernelGGL(wc_overall_totals_kernel, dim3((unsigned)chunks), dim3(256), 0, st, n_groups, n_alleles, row_count, chunk_rows, chunks,
+    hipLaunchKernelGGL(wc_overall_totals_kernel, dim3((unsigned)parts), dim3(256), 0, st, n_groups, n_alleles, row_count, overall_rows, parts,
                        (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, pa, pb, pi,
                        (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
     HIP_TRY(hipGetLastError());
-    auto* pair_kernel = tot_cells <= 4 * 256 ? wc_pair_totals_kernel<4> : wc_pair_totals_kernel<kWcTotCellsMax>;
-    if (tot_lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot_lds));
-    hipLaunchKernelGGL(pair_kernel, dim3((unsigned)pair_blocks, (unsigned)chunks), dim3(256), tot_lds, st, n_groups, n_alleles, row_count,
-                       chunk_rows, chunks, (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, pa, pb, pi,
-                       (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
+    if (bi) {
+      const size_t bi_lds = (size_t)kWcBiTile * G * sizeof(WcBiCell);  // at most 64 KiB (64 groups)
+      const size_t cells = (G * kWcBiTile + bi_threads - 1) / bi_threads;  // <= 4
+      auto* bi_kernel = cells <= 2 ? wc_pair_totals_biallelic_kernel<2> : wc_pair_totals_biallelic_kernel<4>;
+      if (bi_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)bi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bi_lds));
+      hipLaunchKernelGGL(bi_kernel, dim3((unsigned)(8 * ((chunks + 7) / 8) * bi_blocks)), dim3((unsigned)bi_threads), bi_lds, st, n_groups, (int)R,
+                         (int)bi_blocks, row_count, chunk_rows, chunks, (const uint32_t*)alt, pa, pb, pi, (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
+    } else {
+      auto* pair_kernel = tot_cells <= 4 * 256 ? wc_pair_totals_kernel<4> : wc_pair_totals_kernel<kWcTotCellsMax>;
+      if (tot_lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tot_lds));
+      hipLaunchKernelGGL(pair_kernel, dim3((unsigned)pair_blocks, (unsigned)chunks), dim3(256), tot_lds, st, n_groups, n_alleles, row_count,
+                         chunk_rows, chunks, (const uint32_t*)called, (const uint32_t*)alt, (const uint32_t*)acounts, (const uint32_t*)n_all, pa, pb, pi,
+                         (const WcSlotPre*)pre, (const double*)grcp, (const uint32_t*)gsize);
+    }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(wc_slot_finalize_wave_kernel, dim3((unsigned)nslots), dim3(64), 0, st, chunks, (const double*)pa, (const double*)pb,
+    hipLaunchKernelGGL(wc_slot_finalize_wave_kernel, dim3((unsigned)nslots), dim3(64), 0, st, parts, (const double*)pa, (const double*)pb,
                        (const unsigned long long*)pi, sa, sb, si);
     HIP_TRY(hipGetLastError());
   } else {

@@ -72,6 +72,8 @@ struct Options {
   std::atomic<long long> flat_slots{0};          // FMH_FLAT_SLOTS: 0 = the register-staged variant (default); 1 | 2 = the LDS-DMA variants with that many tile images per wave
   std::atomic<long long> flat_defer{0};          // FMH_FLAT_DEFER: tiles a wave counts before it runs their epilogues on the register-staged variant (1..8); 0 = by the launch size
   std::atomic<long long> wc_exact{1};            // FMH_WC_EXACT: 0 = five to seven W&C groups run the padded eight-group kernel again (A/B of the exact kernels)
+  std::atomic<long long> wc_bi_totals{1};        // FMH_WC_BI_TOTALS: 0 = more than eight groups' regional sums through the general pair kernel again (A/B of the biallelic one)
+  std::atomic<long long> wc_bi_replicas{0};      // FMH_WC_BI_REPLICAS: 1 | 2 | 4 | 8 threads per pair in the biallelic pair kernel; 0 = by the lanes the last wave would waste
   std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
   std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };

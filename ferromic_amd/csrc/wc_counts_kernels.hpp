@@ -403,6 +403,175 @@ __global__ __launch_bounds__(256) void wc_pair_totals_kernel(int G, int n_allele
   if (active) { part_a[(1 + pair) * chunks + c] = va; part_b[(1 + pair) * chunks + c] = vb; part_inf[(1 + pair) * chunks + c] = vi; }
 }
 
+// The pair sums of a BIALLELIC matrix with NOTHING MISSING (the 1000-Genomes-populations case: 26 groups, 325 pairs): the kernel above in
+// its one shape that matters, without its run-time arms.  What a pair needs of a group at a site - the allele's frequency in the group and
+// its count - does not depend on the other group, so the staging threads compute it once per (site, group) instead of the pair threads
+// once per (site, pair): the tile in LDS is [site][group] of {p1 = c1 / n, p0 = (n - c1) / n, c1, n - c1} as doubles (32 bytes, two
+// ds_read_b128; groups of one site lie side by side, so the 64 pairs of a wave read different banks).  Per pair, site and allele that
+// leaves div_shared for the pair frequency, two differences, the five operations of the numerator and wc_apply: 28 f64 operations where
+// the general kernel issues 40 and the conversions - the same operands in the same order, so the same bits per (site, pair).  The R
+// replicas of a pair (threads pair + npairs * r, r < R) take the sites r, r + R, ... of every tile: 325 pairs fill 5.08 waves, 4 x 325 fill
+// 20.3 of 21.  Partials land in part[(1 + pair)][chunk * R + r]; wc_slot_finalize_wave_kernel adds them in that order.
+constexpr int kWcBiTile = 32;       // sites per tile: 128-byte runs of every group's count row
+constexpr int kWcBiGroupsMax = 64;  // 64 KiB of LDS; beyond that the general kernel
+struct alignas(16) WcBiCell { double p1, p0, c1, c0; };
+typedef double wc_f64x2 __attribute__((ext_vector_type(2)));
+// Both alleles of one (site, pair) in lockstep: the two chains are independent until their terms are added (allele 0 first, the order of
+// the allele loop), and written side by side they stay side by side in the ISA - a dependent v_*_f64 waits ~8 cycles behind the one before
+// it, which two or three waves per SIMD do not cover on their own.  Every expression is wc_pair_site_pre's / wc_apply<true>'s (a live pair
+// always has s2_ok; the select keeps the flag's meaning without a branch).
+// N independent (site, allele) chains of one pair in lockstep: every step is written for all chains before the next step, and stays so in
+// the ISA - a dependent v_*_f64 issues ~12 cycles after the one it waits for (tools/microbench/f64_issue_rates.hip: 11.7 cycles alone on a
+// SIMD, 4.4 with four chains on four waves), which the three or four resident waves per SIMD do not cover on their own.  Every expression is
+// wc_pair_site_pre's / wc_apply<true>'s (a live pair always has s2_ok; the select keeps the flag's meaning without a branch).
+// c = c_i + c_j (integers below 2^33: exact), pi / pj = the allele's frequency in either group; out: the allele's a term and x_wc.
+template <int N>
+__device__ __forceinline__ void wc_bi_chains(const double (&c)[N], const double (&pi)[N], const double (&pj)[N], double ndi, double ndj,
+                                             const WcSlotPre& o, const WcShape& sh, double (&a)[N], double (&x)[N]) {
+  double g[N], q[N], e[N], di[N], dj[N], num[N], s[N], t[N];
+#define FMH_EACH for (int k = 0; k < N; ++k)
+#define FMH_DIV(out, n, d, r) /* div_shared, step by step over the chains */ \
+  _Pragma("unroll") FMH_EACH q[k] = (n) * (r);                               \
+  _Pragma("unroll") FMH_EACH e[k] = __builtin_fma(-(d), q[k], (n));          \
+  _Pragma("unroll") FMH_EACH out[k] = __builtin_fma(e[k], (r), q[k]);
+  FMH_DIV(g, c[k], o.total, o.rcp_total)
+#pragma unroll
+  FMH_EACH { di[k] = pi[k] - g[k]; dj[k] = pj[k] - g[k]; }
+#pragma unroll
+  FMH_EACH { di[k] = ndi * di[k] * di[k]; dj[k] = ndj * dj[k] * dj[k]; }
+#pragma unroll
+  FMH_EACH num[k] = di[k] + dj[k];  // (0.0 + x) + y of the allele loop: x is never -0.0
+  FMH_DIV(s, num[k], sh.s2_den, o.rcp[0])
+#pragma unroll
+  FMH_EACH s[k] = sh.s2_ok ? s[k] : 0.0;
+#pragma unroll
+  FMH_EACH x[k] = g[k] * (1.0 - g[k]) - sh.rm1_over_r * s[k];
+  FMH_DIV(t, x[k], sh.nbar_m1, o.rcp[1])
+#pragma unroll
+  FMH_EACH t[k] = s[k] - t[k];
+  FMH_DIV(a, t[k], sh.a_den, o.rcp[2])
+#undef FMH_DIV
+#undef FMH_EACH
+}
+// SITES sites of one pair: chains (site 0 allele 0, site 0 allele 1, site 1 allele 0, ...); the sums take the sites in order and, per site,
+// allele 0 then allele 1 - the allele loop's wa = 0.0; wa += a0; wa += a1; va += wa without the 0.0: that matters only when a0 and a1 are
+// both -0.0, and then va + (-0.0) and va + 0.0 are the same bits (va starts at +0.0 and never becomes -0.0)
+struct WcBiPairCells { wc_f64x2 fi, ni, fj, nj; };  // {p1, p0} and {c1, c0} of the pair's two groups at one site
+__device__ __forceinline__ WcBiPairCells wc_bi_load(const WcBiCell* __restrict__ tile, int G, int gi, int gj, int t) {
+  const wc_f64x2* ci = reinterpret_cast<const wc_f64x2*>(tile + (size_t)t * G + gi);
+  const wc_f64x2* cj = reinterpret_cast<const wc_f64x2*>(tile + (size_t)t * G + gj);
+  WcBiPairCells v;
+  v.fi = ci[0]; v.ni = ci[1]; v.fj = cj[0]; v.nj = cj[1];
+  return v;
+}
+// SITES sites of one pair: chains (site 0 allele 0, site 0 allele 1, site 1 allele 0, ...); the sums take the sites in order and, per site,
+// allele 0 then allele 1 - the allele loop's wa = 0.0; wa += a0; wa += a1; va += wa without the 0.0: that matters only when a0 and a1 are
+// both -0.0, and then va + (-0.0) and va + 0.0 are the same bits (va starts at +0.0 and never becomes -0.0)
+template <int SITES>
+__device__ __forceinline__ void wc_bi_sites(const WcBiPairCells (&v)[SITES], double ndi, double ndj, const WcSlotPre& o, const WcShape& sh,
+                                            double& va, double& vb) {
+  double c[2 * SITES], pi[2 * SITES], pj[2 * SITES], a[2 * SITES], x[2 * SITES];
+#pragma unroll
+  for (int u = 0; u < SITES; ++u) {
+    c[2 * u] = v[u].ni.y + v[u].nj.y; c[2 * u + 1] = v[u].ni.x + v[u].nj.x;
+    pi[2 * u] = v[u].fi.y; pi[2 * u + 1] = v[u].fi.x;
+    pj[2 * u] = v[u].fj.y; pj[2 * u + 1] = v[u].fj.x;
+  }
+  wc_bi_chains<2 * SITES>(c, pi, pj, ndi, ndj, o, sh, a, x);
+#pragma unroll
+  for (int u = 0; u < SITES; ++u) {
+    va += a[2 * u] + a[2 * u + 1];
+    vb += sh.b_fac * x[2 * u] + sh.b_fac * x[2 * u + 1];
+  }
+}
+template <int CELLS>  // cells of a tile a thread stages: G x 32 <= CELLS x blockDim.x
+__global__ __launch_bounds__(512, 5) void wc_pair_totals_biallelic_kernel(int G, int R, int blocks_per_chunk, size_t rows, size_t chunk_rows, size_t chunks,
+                                                                       const uint32_t* __restrict__ alt, double* __restrict__ part_a,
+                                                                       double* __restrict__ part_b, unsigned long long* __restrict__ part_inf,
+                                                                       const WcSlotPre* __restrict__ pre, const double* __restrict__ grcp,
+                                                                       const uint32_t* __restrict__ gsize) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wc_bi_lds[];  // WcBiCell[kWcBiTile][G]
+  WcBiCell* tile = reinterpret_cast<WcBiCell*>(wc_bi_lds);
+  const size_t npairs = (size_t)G * (G - 1) / 2;
+  const uint32_t B = blockDim.x;  // a multiple of 64 (the host sizes it to the items of a block)
+  // The workgroups of one chunk read the same rows of the count tables: they go to ONE XCD, next to each other in its dispatch order, so the
+  // second and later ones find the rows in that XCD's L2 (workgroup ids go round the eight XCDs; 40 groups with seven workgroups per chunk
+  // re-read 2.2 GB from HBM before this mapping).  Grid: 8 x ceil(chunks / 8) x blocks_per_chunk workgroups, the padding ones leave at once.
+  const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
+  const size_t c = (size_t)(slot / (uint32_t)blocks_per_chunk) * 8u + xcd;
+  if (c >= chunks) return;
+  const size_t item = (size_t)(slot % (uint32_t)blocks_per_chunk) * B + threadIdx.x;
+  const bool active = item < npairs * (size_t)R;
+  const size_t pair = active ? item % npairs : 0;
+  const int rep = active ? (int)(item / npairs) : 0;
+  int gi = 0, gj = 1;
+  wc_pair_of_slot(pair, G, gi, gj);
+  const WcSlotPre mine = pre[1 + pair];
+  const WcShape sh = wc_shape_of_pre(mine);
+  const double ndi = (double)gsize[gi], ndj = (double)gsize[gj];
+  const bool work = active && mine.has_data && mine.live;
+  const size_t s0 = c * chunk_rows, s1 = s0 + chunk_rows < rows ? s0 + chunk_rows : rows;
+  // the staging side: cell q of this thread is site threadIdx.x % 32 of group threadIdx.x / 32 + q B / 32
+  constexpr int kCellsMax = CELLS;
+  const uint32_t st_t = threadIdx.x % kWcBiTile, st_g0 = threadIdx.x / kWcBiTile, st_gstep = B / kWcBiTile;
+  uint32_t next[kCellsMax], st_n[kCellsMax];
+  double st_r[kCellsMax];
+#pragma unroll
+  for (int q = 0; q < kCellsMax; ++q) {  // the groups of this thread's cells: sizes and reciprocals once
+    const uint32_t g = st_g0 + st_gstep * q;
+    st_n[q] = g < (uint32_t)G ? gsize[g] : 0;
+    st_r[q] = g < (uint32_t)G ? grcp[g] : 0.0;
+  }
+  auto fetch = [&](size_t t0) {
+    const bool in = t0 + st_t < s1;
+    const uint32_t* src = alt + (size_t)st_g0 * rows + t0 + st_t;
+#pragma unroll
+    for (int q = 0; q < kCellsMax; ++q) {
+      next[q] = 0;
+      if (in && st_g0 + st_gstep * q < (uint32_t)G) next[q] = src[(size_t)(st_gstep * q) * rows];
+    }
+  };
+  double va = 0.0, vb = 0.0;
+  unsigned long long vi = 0;
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < kCellsMax; ++q) {
+      const uint32_t g = st_g0 + st_gstep * q;
+      if (g >= (uint32_t)G) continue;
+      const uint32_t n = st_n[q], c1 = next[q];
+      const double nd = (double)n, r = st_r[q];
+      WcBiCell cell;  // (a group without members: its cells are never read - its pairs have no data)
+      cell.c1 = (double)c1;
+      cell.c0 = (double)(n - c1);
+      cell.p1 = div_shared(cell.c1, nd, r);
+      cell.p0 = div_shared(cell.c0, nd, r);
+      tile[(size_t)st_t * G + g] = cell;
+    }
+  };
+  if (s0 < s1) fetch(s0);
+  for (size_t t0 = s0; t0 < s1; t0 += kWcBiTile) {
+    __syncthreads();  // the previous tile has been read
+    stage();
+    __syncthreads();
+    if (t0 + kWcBiTile < s1) fetch(t0 + kWcBiTile);  // the next tile's counts travel while this one is worked on
+    const int tmax = s1 - t0 < (size_t)kWcBiTile ? (int)(s1 - t0) : kWcBiTile;
+    if (active && mine.has_data && rep < tmax) vi += (unsigned long long)((tmax - rep + R - 1) / R);
+    if (!work) continue;
+    // One site = two chains per step, five waves per SIMD.  Measured and not kept (profiles/r04/wc_many_groups_pair_kernel_variants.md): two
+    // sites in lockstep on four waves per SIMD (3-6 % behind), a second tile image with one barrier per tile (level), the next site's cells
+    // read from LDS a site ahead (level to 8 % behind).
+#pragma unroll 2
+    for (int t = rep; t < tmax; t += R) {
+      const WcBiPairCells cells[1] = {wc_bi_load(tile, G, gi, gj, t)};
+      wc_bi_sites<1>(cells, ndi, ndj, mine, sh, va, vb);
+    }
+  }
+  if (active) {
+    const size_t k = (1 + pair) * (chunks * (size_t)R) + c * (size_t)R + (size_t)rep;
+    part_a[k] = va; part_b[k] = vb; part_inf[k] = vi;
+  }
+}
+
 __global__ __launch_bounds__(256) void wc_overall_totals_kernel(int G, int n_alleles, size_t rows, size_t chunk_rows, size_t chunks,
                                                                 const uint32_t* __restrict__ called, const uint32_t* __restrict__ alt,
                                                                 const uint32_t* __restrict__ acounts, const uint32_t* __restrict__ n_all,

@@ -84,7 +84,7 @@ def assert_bits_equal(actual: np.ndarray, expected: Sequence[float], what: str):
     a = np.asarray(actual, dtype=np.float64)
     assert a.shape == exp.shape, what
     both_nan = np.isnan(a) & np.isnan(exp)
-    same = (a.view(np.uint64) == exp.view(np.uint64)) | both_nan | ((a == 0) & (exp == 0))
+    same = (a.view(np.uint64) == exp.view(np.uint64)) | both_nan  # the sign of a zero counts: +0.0 and -0.0 are different bits
     if not same.all():
         i = int(np.argmin(same))
         raise AssertionError(f"{what}: first mismatch at {i}: gpu={a[i]!r} oracle={exp[i]!r}")

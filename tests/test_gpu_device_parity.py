@@ -398,6 +398,35 @@ def test_many_groups_totals_without_tracks(dev, G, max_allele, p_missing, S):
         assert np.allclose(tot.sum_a, full.sum_a, rtol=1e-10, atol=1e-10) and np.allclose(tot.sum_b, full.sum_b, rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize("G,S", [(9, 3000), (12, 2111), (26, 20_000), (64, 1500)])
+def test_biallelic_pair_totals_kernel_against_the_general_one(dev, fmh_opts, G, S):
+    """More than eight groups, biallelic, nothing missing, no track asked for: wc_pair_totals_biallelic_kernel (frequencies per site and
+    group staged once, R threads per pair) against the general pair kernel (FMH_WC_BI_TOTALS=0) and against the sums of the per-site
+    route - informative sites exactly, the sums to the order of the additions, for every replica count and ragged row ranges."""
+    rng = np.random.default_rng(77 * G)
+    N = 200
+    m = H.random_dense_matrix(rng, S, N, 2, 1, 0.0)
+    dm = upload(dev, m)
+    pop_of_sample = rng.integers(0, G, size=N)
+    pop_of_sample[:G] = np.arange(G)
+    if G == 12:
+        pop_of_sample[pop_of_sample == 5] = 6  # a group without members
+    masks = np.stack([dev.Groups.mask_from_haplotypes(dm, H.haps_for_samples(np.nonzero(pop_of_sample == g)[0].tolist())) for g in range(G)])
+    for (r0, rows) in ((0, S), (S // 3, S // 2 + 5), (7, 3), (1, 33)):
+        fmh_opts.setenv("FMH_WC_BI_TOTALS", "0")
+        general = dev.wc_sweep_many(dm, masks, r0, rows, sites=False)
+        fmh_opts.delenv("FMH_WC_BI_TOTALS")
+        full = dev.wc_sweep_many(dm, masks, r0, rows)
+        for replicas in ("0", "1", "2", "4", "8"):
+            fmh_opts.setenv("FMH_WC_BI_REPLICAS", replicas)
+            tot = dev.wc_sweep_many(dm, masks, r0, rows, sites=False)
+            assert np.array_equal(tot.informative_sites, general.informative_sites), replicas
+            assert np.array_equal(tot.informative_sites, full.informative_sites), replicas
+            for got, want in ((tot.sum_a, general.sum_a), (tot.sum_b, general.sum_b), (tot.sum_a, full.sum_a), (tot.sum_b, full.sum_b)):
+                assert np.allclose(got, want, rtol=1e-11, atol=1e-12), replicas
+        fmh_opts.delenv("FMH_WC_BI_REPLICAS")
+
+
 def test_mask_routes_agree(dev, fmh_opts):
     """The sweep keeps the group masks as bytes in LDS, as bits in LDS (rows too wide for bytes) or as bytes in global
     memory (rows too wide for bits); FMH_MASK_MODE forces the slower routes on rows that do not need them.  All three
