@@ -84,6 +84,7 @@ const OptionRow kOptionRows[] = {
     {"FMH_WC_EXACT", &Options::wc_exact, 1, nullptr},
     {"FMH_WC_BI_TOTALS", &Options::wc_bi_totals, 1, nullptr},
     {"FMH_WC_BI_REPLICAS", &Options::wc_bi_replicas, 0, nullptr},
+    {"FMH_WC_BI_CHUNKS", &Options::wc_bi_chunks, 0, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -1543,6 +1544,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
     const size_t pair_blocks = bi ? bi_blocks : (nslots - 1 + 255) / 256;
     // (about 8 000 workgroups: a CU holds five or so at a time and a launch of only eight per CU ran in two uneven rounds; the partials stay below 4 M entries)
     size_t chunks = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8192 / R, ((size_t)4 << 20) / (nslots * R)), (8192 + pair_blocks - 1) / pair_blocks));
+    if (const long long v = options().wc_bi_chunks.load(); bi && v > 0) chunks = std::max<size_t>(1, std::min<size_t>((size_t)v, ((size_t)4 << 20) / (nslots * R)));
     const size_t tile_rows = bi ? (size_t)kWcBiTile : (size_t)kWcTotTile;
     size_t chunk_rows = round_up((row_count + chunks - 1) / chunks, tile_rows);
     chunks = (row_count + chunk_rows - 1) / chunk_rows;

@@ -74,6 +74,7 @@ struct Options {
   std::atomic<long long> wc_exact{1};            // FMH_WC_EXACT: 0 = five to seven W&C groups run the padded eight-group kernel again (A/B of the exact kernels)
   std::atomic<long long> wc_bi_totals{1};        // FMH_WC_BI_TOTALS: 0 = more than eight groups' regional sums through the general pair kernel again (A/B of the biallelic one)
   std::atomic<long long> wc_bi_replicas{0};      // FMH_WC_BI_REPLICAS: 1 | 2 | 4 | 8 threads per pair in the biallelic pair kernel; 0 = by the lanes the last wave would waste
+  std::atomic<long long> wc_bi_chunks{0};        // FMH_WC_BI_CHUNKS: row chunks of the biallelic pair kernel (measurement); 0 = about 8 192 workgroups
   std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
   std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };
