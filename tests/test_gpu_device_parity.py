@@ -425,6 +425,12 @@ def test_biallelic_pair_totals_kernel_against_the_general_one(dev, fmh_opts, G, 
             for got, want in ((tot.sum_a, general.sum_a), (tot.sum_b, general.sum_b), (tot.sum_a, full.sum_a), (tot.sum_b, full.sum_b)):
                 assert np.allclose(got, want, rtol=1e-11, atol=1e-12), replicas
         fmh_opts.delenv("FMH_WC_BI_REPLICAS")
+        for chunks in ("1", "7"):  # one workgroup walks every tile / ragged last chunk; the XCD padding of the grid leaves at once
+            fmh_opts.setenv("FMH_WC_BI_CHUNKS", chunks)
+            tot = dev.wc_sweep_many(dm, masks, r0, rows, sites=False)
+            assert np.array_equal(tot.informative_sites, general.informative_sites), chunks
+            assert np.allclose(tot.sum_a, general.sum_a, rtol=1e-11, atol=1e-12) and np.allclose(tot.sum_b, general.sum_b, rtol=1e-11, atol=1e-12), chunks
+        fmh_opts.delenv("FMH_WC_BI_CHUNKS")
 
 
 def test_mask_routes_agree(dev, fmh_opts):
