@@ -22,7 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BIN = os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")
+BIN = os.environ.get("RUN_VCF_BIN") or os.path.join(ROOT, "ferromic_amd", "bin", "run_vcf")  # RUN_VCF_BIN: another build of the binary (A/Bs)
 
 
 class BgzfWriter:
