@@ -7,13 +7,13 @@ O=$R/gpurun_out/${1:-r04_split}
 mkdir -p $O
 cd /tmp
 for rep in 1 2 3; do
-  for b in split mono; do
+  for b in ${AB_ORDER:-split mono}; do
     if [ $b = mono ]; then export RUN_VCF_BIN=$R/build/variants/r04mono/run_vcf; else unset RUN_VCF_BIN; fi
     python3 $R/tools/run_vcf_many_regions.py 2>/dev/null | tail -1 | sed "s/^{/{\"build\": \"$b\", /" >> $O/run_vcf_500_regions_split_vs_mono.jsonl
   done
 done
 for rep in 1 2; do
-  for b in split mono; do
+  for b in ${AB_ORDER:-split mono}; do
     if [ $b = mono ]; then export RUN_VCF_BIN=$R/build/variants/r04mono/run_vcf; else unset RUN_VCF_BIN; fi
     python3 $R/tools/run_vcf_scale.py --sites 200000 --samples 2500 --bin ${RUN_VCF_BIN:-$R/ferromic_amd/bin/run_vcf} 2>/dev/null | tail -1 | sed "s/^{/{\"build\": \"$b\", /" >> $O/run_vcf_scale_split_vs_mono.jsonl
   done
