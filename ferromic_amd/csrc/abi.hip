@@ -1451,7 +1451,7 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
   scratch.device = m->device;
   scratch.stream = st;
   uint32_t *called = d_group_called, *alt = nullptr, *acounts = nullptr, *n_all = nullptr, *all_alt = nullptr;
-  if (!called) FMH_TRY(scratch.get(&called, G * row_count));
+  if (!called && m->has_missing) FMH_TRY(scratch.get(&called, G * row_count));  // (nothing missing: the called counts are the group sizes, no table)
   FMH_TRY(scratch.get(&n_all, row_count));
   if (general) {
     FMH_TRY(scratch.get(&acounts, (size_t)n_alleles * G * row_count));
@@ -1508,7 +1508,8 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
     FMH_TRY(fmh_groups_create(m, h_column_mask + g0 * m->columns, cnt, &g));
     SweepArgs a{};
     a.row_begin = row_begin; a.row_count = row_count; a.formula = FMH_FORMULA_SPARSE;
-    a.called = called + g0 * row_count;
+    // nothing missing: a group's called count is its size at every site - the kernels below take the sizes, the table is written only for a caller who asked for it
+    if (!pre || d_group_called) a.called = called + g0 * row_count;
     if (alt) a.alt = alt + g0 * row_count;
     a.acounts = acounts; a.acounts_groups = (uint32_t)G; a.acounts_group0 = (uint32_t)g0;
     SweepResult r;
@@ -1549,7 +1550,10 @@ extern "C" int fmh_wc_sweep_many(const fmh_matrix* m, const uint8_t* h_column_ma
     size_t chunk_rows = round_up((row_count + chunks - 1) / chunks, tile_rows);
     chunks = (row_count + chunk_rows - 1) / chunk_rows;
     const size_t parts = chunks * R;  // partial sums per slot; the overall kernel is launched over as many (shorter) chunks
-    const size_t overall_rows = (row_count + parts - 1) / parts;
+    // (the overall slot: one thread per site; at most 1 024 of the `parts` workgroups take rows - eight or so sites per thread amortise the block
+    // reduction - the others write the zeros of their partials)
+    const size_t overall_parts = std::min<size_t>(parts, 1024);
+    const size_t overall_rows = (row_count + overall_parts - 1) / overall_parts;
     double *pa = nullptr, *pb = nullptr;
     unsigned long long* pi = nullptr;
     FMH_TRY(scratch.get(&pa, nslots * parts));

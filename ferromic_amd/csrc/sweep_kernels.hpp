@@ -1372,8 +1372,25 @@ constexpr int sweep_min_waves() { return (MM == 3 /* kMaskPacked */ && !GENERAL 
 // __launch_bounds__' second argument (workgroups of four waves per CU = waves per SIMD): the eight-group W&C kernels of a packed matrix
 // (biallelic, and multi-allelic on two planes) end one register above 256 when left alone - one wave per SIMD instead of two; the
 // three-plane ones would spill to scratch under that bound and are left alone
-template <int P, int MODE, bool GENERAL, int MM, int NPL>
-constexpr int sweep_min_blocks() { return (MM == 3 /* kMaskPacked */ && P >= 5 && (MODE & kModeWc) != 0 && NPL == 2) ? 2 : 1; }
+// Kernels whose register count sat just above an occupancy step (512 VGPRs per SIMD: 128 -> four waves, 168 -> three) are held to the step
+// when hipcc reaches it without spilling (tools/kernel_resources.py; the CPU suite fails on any scratch).  Round 4 found the eight-group
+// summaries kernel of sixteen-lane rows - the counting sweeps of more than eight W&C groups - at 171 VGPRs, two waves per SIMD, streaming its
+// planes at 2.5 TB/s; at 133 VGPRs and three waves it streams at 3.75 TB/s (profiles/r04/occupancy_steps_*).  FMH_OCC_STEPS=0: the rules off.
+#ifndef FMH_OCC_STEPS
+#define FMH_OCC_STEPS 1
+#endif
+template <int P, int MODE, bool GENERAL, int MM, int NPL, int LPR = 16, bool MISSING = false>
+constexpr int sweep_min_blocks() {
+  if (FMH_OCC_STEPS && MM == 3 /* kMaskPacked */ && !GENERAL && !MISSING && NPL == 2) {
+    if (P == 8 && MODE == kModeSummary && LPR == 16) return 3;  // 171 -> 133
+    if (P == 4 && MODE == kModeWc && LPR == 16) return 3;       // 171 -> 147
+    if (P == 6 && MODE == kModeWc && LPR == 4) return 3;        // 170
+    if (P == 5 && MODE == kModeWc && LPR == 16) return 3;       // 173
+    // (two groups on four-lane rows, 131-135 VGPRs: the diversity and W&C kernels spill two registers at 128, and one and two groups take the
+    // pipelined kernel there anyway)
+  }
+  return (MM == 3 /* kMaskPacked */ && P >= 5 && (MODE & kModeWc) != 0 && NPL == 2) ? 2 : 1;
+}
 
 // Which kernels defer their epilogues (see sweep_kernel), how many u32 they park per site and how many tiles deep (LDS per workgroup =
 // 4 waves x depth x 64 sites x values x 4 B: 16 or 32 KiB).  The host sizes the dynamic LDS with the same functions (defer_lds_bytes).
@@ -1401,7 +1418,7 @@ inline size_t defer_lds_bytes(int P, int mode, bool missing, int depth) {
 }
 
 template <int P, int MODE, bool MISSING, bool GENERAL, int MM = kMaskLdsBytes, int LPR = 16, int NPL = 2>
-__global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL>())) void sweep_kernel(const SweepArgs A) {
+__global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL, LPR, MISSING>())) void sweep_kernel(const SweepArgs A) {
   static_assert(NPL == 2 || (NPL == 3 && GENERAL && MM == kMaskPacked), "a third plane exists on packed multi-allelic matrices only");
   static_assert(LPR == 16 || ((LPR == 4 || LPR == 8) && MM == kMaskPacked), "four / eight lanes per row exist for the packed cores only");
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1932,6 +1949,7 @@ __device__ __forceinline__ void tiles_pipelined(const SweepArgs& A, const Matrix
   }
 }
 
+// (held to three waves per SIMD every pipelined kernel above 168 VGPRs spills: they keep the next tile's loads in registers by design)
 template <int P, int MODE, int LPR>
 __global__ __launch_bounds__(kBlock) void sweep_kernel_pipe(const SweepArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
