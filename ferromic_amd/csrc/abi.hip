@@ -85,6 +85,7 @@ const OptionRow kOptionRows[] = {
     {"FMH_WC_BI_TOTALS", &Options::wc_bi_totals, 1, nullptr},
     {"FMH_WC_BI_REPLICAS", &Options::wc_bi_replicas, 0, nullptr},
     {"FMH_WC_BI_CHUNKS", &Options::wc_bi_chunks, 0, nullptr},
+    {"FMH_ROW_HI", &Options::row_hi, 1, nullptr},
 };
 bool parse_option(const OptionRow& row, const char* text, long long* out) {
   if (row.words) {
@@ -400,7 +401,24 @@ static int alloc_planes(fmh_matrix* m) {
 }
 static void free_planes(fmh_matrix* m) {
   pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->p2); pool_free(m->device, m->pc);
+  pool_free(m->device, m->row_hi);
   m->p0 = m->p1 = m->p2 = m->pc = nullptr;
+  m->row_hi = nullptr;
+}
+// after the planes of a multi-allelic matrix have been written: which rows have a bit above plane 0 (row_hi_kernel).  FMH_ROW_HI=0: no table,
+// the sweeps read every plane of every row as before round 4.
+static int mark_upper_plane_rows(fmh_matrix* m) {
+  if (!m->p1 || m->variants == 0 || options().row_hi.load() == 0) return FMH_OK;
+  if (!m->row_hi) {
+    const hipError_t e = pool_malloc(m->device, (void**)&m->row_hi, m->variants);
+    if (e != hipSuccess) { m->row_hi = nullptr; return FMH_OK; }  // no table: every row is read in full
+  }
+  const int blocks = (int)std::min<size_t>((m->variants * 16 + 255) / 256, 1 << 16);
+  hipLaunchKernelGGL(row_hi_kernel, dim3(blocks), dim3(256), 0, 0, (const uint8_t*)m->p1, (const uint8_t*)m->p2, m->plane_pitch, m->variants, m->row_hi);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(0);
+  if (e != hipSuccess) return fail(FMH_ERR_HIP, "marking the rows with alleles above 1 failed: %s", hipGetErrorString(e));
+  return FMH_OK;
 }
 // byte rows (and, when `bits` is given, their called rows) -> planes rows [row0, row0 + rows)
 // `d_overflow` (one zeroed device word, may be null) is set when a called entry carries an allele bit the planes do not store
@@ -447,6 +465,7 @@ extern "C" int fmh_matrix_pack(fmh_matrix* m, int release_bytes) {
     free_planes(m);
     return fail(FMH_ERR_INVALID, "a called entry holds an allele above max_allele = %u: the packed layout cannot represent it", (unsigned)m->max_allele);
   }
+  FMH_TRY(mark_upper_plane_rows(m));
   if (release_bytes && m->owns) {
     pool_free(m->device, m->data);
     pool_free(m->device, m->bits);
@@ -482,6 +501,7 @@ extern "C" int fmh_matrix_create(const uint8_t* h_data, const uint64_t* h_missin
     const int rc = upload_planes_from_bytes(m, h_data, h_missing, &overflow);
     if (rc != FMH_OK) return bail(rc);
     if (overflow) return bail(fail(FMH_ERR_INVALID, "a called entry holds an allele above max_allele = %u: the packed layout cannot represent it", (unsigned)max_allele));
+    if (const int rh = mark_upper_plane_rows(m); rh != FMH_OK) return bail(rh);
     *out = m;
     return FMH_OK;
   }
@@ -537,6 +557,7 @@ extern "C" int fmh_matrix_create_packed(const uint8_t* h_plane0, const uint8_t* 
   const uint8_t* planes[4] = {h_plane0, h_plane1, h_plane2, h_called};
   const int rc = upload_planes_from_planes(m, planes, h_pitch);
   if (rc != FMH_OK) { fmh_matrix_destroy(m); return rc; }
+  if (const int rh = mark_upper_plane_rows(m); rh != FMH_OK) { fmh_matrix_destroy(m); return rh; }
   *out = m;
   return FMH_OK;
 }
@@ -914,6 +935,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.mv.data1 = m->p1;
     a.mv.data2 = m->p2;
     a.mv.bits = m->pc;
+    a.mv.row_hi = m->row_hi;
     a.mv.pitch = m->plane_pitch;
     a.mv.bits_pitch = m->plane_pitch;
     a.mv.nvec = m->pvec;
@@ -923,6 +945,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.mv.data1 = nullptr;
     a.mv.data2 = nullptr;
     a.mv.bits = m->bits;
+    a.mv.row_hi = nullptr;
     a.mv.pitch = m->pitch;
     a.mv.bits_pitch = m->bits_pitch;
     a.mv.nvec = m->nvec;

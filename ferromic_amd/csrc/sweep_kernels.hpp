@@ -45,6 +45,7 @@ struct MatrixView {
   const uint8_t* data1;  // packed layout with alleles 2..7: bit plane 1 ((allele >> 1) & 1); else null
   const uint8_t* data2;  // packed layout with alleles 4..7: bit plane 2 (allele >> 2); else null
   const uint8_t* bits;  // called bits, may be null
+  const uint8_t* row_hi;  // packed layout with alleles 2..7: one byte per row, non-zero when a plane above plane 0 has a bit set in that row; may be null (= every row may)
   size_t pitch;
   size_t bits_pitch;
   uint32_t columns;  // H = samples * ploidy
@@ -676,8 +677,9 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
       const uint32_t v = v0 + LPR * u;
       const uint32_t vc = v < last ? v : last;
       x[0][u] = load_stream(row0 + (size_t)vc * 16);
-      if constexpr (NPL >= 2) x[1][u] = load_stream(row1 + (size_t)vc * 16);
-      if constexpr (NPL >= 3) x[2][u] = load_stream(row2 + (size_t)vc * 16);
+      // (a null upper plane: the row carries no allele above 1 - MatrixView::row_hi - and its upper planes are not read)
+      if constexpr (NPL >= 2) x[1][u] = row1 ? load_stream(row1 + (size_t)vc * 16) : make_uint4(0, 0, 0, 0);
+      if constexpr (NPL >= 3) x[2][u] = row2 ? load_stream(row2 + (size_t)vc * 16) : make_uint4(0, 0, 0, 0);
       if (MISSING) cb[u] = load_stream(called_ptr + (size_t)vc * 16);
     }
   };
@@ -1637,6 +1639,18 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
     // packed cores: the batch depth U is the launch's (A.unroll); with eight groups only the shallow batches are built in this row loop -
     // deeper ones kept P x U mask vectors live and spilled to scratch (the one-batch-per-row loop above takes any depth: its masks stay in LDS)
     constexpr bool kShallow = P >= 5;
+    // Multi-allelic packed matrices: real cohorts carry an allele above 1 at a few sites in a hundred, yet every row used to pay for
+    // every plane (two planes: twice the bytes of a biallelic sweep; 0.2 % such sites: 2.0 x the time).  row_hi says which rows of the
+    // tile have a bit in an upper plane; a step none of whose rows has one runs the one-plane core (its upper subset sums are zero), a
+    // step with some reads the upper planes of those rows only.
+    unsigned long long hi_mask = ~0ull;
+    if constexpr (GENERAL && MM == kMaskPacked) {
+      if (mv.row_hi) {
+        const size_t r = tile_row0 + (size_t)lane;
+        const uint8_t f = r < A.row_count ? mv.row_hi[A.row_begin + r] : (uint8_t)0;
+        hi_mask = __ballot(f != 0);
+      }
+    }
     for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;
@@ -1647,9 +1661,40 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
       uint32_t n[P], n_all, aor, sp[P][NS];
       if constexpr (MM == kMaskPacked) {
         const uint4* lm = reinterpret_cast<const uint4*>(lds_mask);
-        const uint8_t* row_ptr1 = NPLK >= 2 ? mv.data1 + row * mv.pitch : nullptr;
-        const uint8_t* row_ptr2 = NPLK >= 3 ? mv.data2 + row * mv.pitch : nullptr;
+        constexpr unsigned long long kStepRows = LPR == 16 ? 0x0001000100010001ull : (LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull);
+        const bool step_hi = (hi_mask & (kStepRows << s)) != 0;                 // wave-uniform: some row of this step has an upper-plane bit
+        const bool row_hi = ((hi_mask >> (grp * LPR + s)) & 1ull) != 0;         // this lane group's row
+        const uint8_t* row_ptr1 = NPLK >= 2 && row_hi ? mv.data1 + row * mv.pitch : nullptr;
+        const uint8_t* row_ptr2 = NPLK >= 3 && row_hi ? mv.data2 + row * mv.pitch : nullptr;
         constexpr bool NA_ALL = GENERAL || NEED_ALL;
+        bool counted_low = false;
+        if constexpr (GENERAL && NPLK >= 2) {
+          if (!step_hi) {  // the one-plane core; allele 1 may be present (aor = 1: an allele a site does not carry adds exact zeros)
+            uint32_t low[P][1], aor_low;
+#define FMH_COUNT_LOW(UV) count_row_packed<P, MISSING, NA_ALL, 1, UV, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, bits_ptr, gl, n, n_all, aor_low, low, P == 8 ? A.n_groups : P)
+            if constexpr (LPR != 16) {
+              if constexpr (kShallow) { if (A.unroll == 2) FMH_COUNT_LOW(2); else FMH_COUNT_LOW(1); }
+              else if (A.unroll == 5) FMH_COUNT_LOW(5);
+              else if (A.unroll == 3) FMH_COUNT_LOW(3);
+              else if (A.unroll == 2) FMH_COUNT_LOW(2);
+              else FMH_COUNT_LOW(1);
+            } else {
+              if constexpr (kShallow) FMH_COUNT_LOW(2);
+              else if (A.unroll == 4) FMH_COUNT_LOW(4);
+              else if (A.unroll == 3) FMH_COUNT_LOW(3);
+              else FMH_COUNT_LOW(2);
+            }
+#undef FMH_COUNT_LOW
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+              for (int k = 0; k < NS; ++k) sp[p][k] = k == 0 ? low[p][0] : 0u;
+            }
+            aor = 1;
+            counted_low = true;
+          }
+        }
+        if (!counted_low) {
 #define FMH_COUNT_PACKED(UV) count_row_packed<P, MISSING, NA_ALL, NPLK, UV, LPR>(mv, lm, nvec_pad, row_ptr, row_ptr1, row_ptr2, bits_ptr, gl, n, n_all, aor, sp, P == 8 ? A.n_groups : P)
         if constexpr (LPR != 16) {
           if constexpr (kShallow) { if (A.unroll == 2) FMH_COUNT_PACKED(2); else FMH_COUNT_PACKED(1); }
@@ -1663,6 +1708,7 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
           else if (A.unroll == 3) FMH_COUNT_PACKED(3);
           else FMH_COUNT_PACKED(2);
         }
+        }  // !counted_low
 #undef FMH_COUNT_PACKED
       } else if constexpr (!GENERAL) {
         uint32_t alt[P];

@@ -176,6 +176,28 @@ __global__ void pack_rows_kernel(const uint8_t* __restrict__ data, size_t pitch,
   if (overflow && overflow_flag) atomicOr(overflow_flag, 1u);
 }
 
+// row_hi[r] = 1 when row r of a packed multi-allelic matrix has a bit in plane 1 or plane 2 (a called allele above 1), else 0: the sweeps
+// read the upper planes of those rows only (MatrixView::row_hi).  Sixteen lanes per row, as many 16-byte vectors each as the row needs.
+__global__ __launch_bounds__(256) void row_hi_kernel(const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2, size_t plane_pitch, size_t rows,
+                                                     uint8_t* __restrict__ row_hi) {
+  const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 16, groups = (size_t)gridDim.x * blockDim.x / 16;
+  const uint32_t gl = threadIdx.x % 16, nvec = (uint32_t)(plane_pitch / 16);
+  for (size_t r = group; r < rows; r += groups) {
+    uint32_t any = 0;
+    for (uint32_t v = gl; v < nvec; v += 16) {
+      const uint4 a = *reinterpret_cast<const uint4*>(p1 + r * plane_pitch + (size_t)v * 16);
+      any |= a.x | a.y | a.z | a.w;
+      if (p2) {
+        const uint4 b = *reinterpret_cast<const uint4*>(p2 + r * plane_pitch + (size_t)v * 16);
+        any |= b.x | b.y | b.z | b.w;
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) any |= __shfl_xor(any, off, 64);
+    if (gl == 0) row_hi[r] = any != 0 ? 1 : 0;
+  }
+}
+
 // planes -> bytes: one thread per (row, 16 columns); padding columns come out zero
 // (pc = called plane or null: the value bits of a missing entry are masked out, so that a download does not depend on which upload route
 // built the matrix - fmh_matrix_create_packed takes the caller's planes as they are)

@@ -5,6 +5,8 @@ regional sums within 1e-9 relative (1e-12 absolute near zero), the tolerance nor
 
 import random
 
+import math
+
 import numpy as np
 import pytest
 
@@ -431,6 +433,87 @@ def test_biallelic_pair_totals_kernel_against_the_general_one(dev, fmh_opts, G, 
             assert np.array_equal(tot.informative_sites, general.informative_sites), chunks
             assert np.allclose(tot.sum_a, general.sum_a, rtol=1e-11, atol=1e-12) and np.allclose(tot.sum_b, general.sum_b, rtol=1e-11, atol=1e-12), chunks
         fmh_opts.delenv("FMH_WC_BI_CHUNKS")
+
+
+def _same_result(a, b, what):
+    """Two results of the same call on two images of one matrix: every array the same bits, every scalar equal."""
+    if isinstance(a, dict):
+        assert a.keys() == b.keys(), what
+        for k in a:
+            _same_result(a[k], b[k], f"{what}.{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), what
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same_result(x, y, f"{what}[{i}]")
+    elif isinstance(a, np.ndarray):
+        assert a.shape == b.shape and a.dtype == b.dtype, what
+        if a.dtype.kind == "f":
+            H.assert_bits_equal(a.reshape(-1), b.reshape(-1), what)
+        else:
+            assert np.array_equal(a, b), what
+    elif isinstance(a, float):
+        assert (math.isnan(a) and math.isnan(b)) or a == b, what
+    elif a is None or isinstance(a, (int, str, bool, np.integer)):
+        assert a == b, what
+    else:
+        _same_result(vars(a), vars(b), what)
+
+
+@pytest.mark.parametrize("S,N,max_allele,p_missing,p_multi", [(700, 60, 2, 0.0, 0.03), (450, 2100, 3, 0.02, 0.02), (260, 2100, 5, 0.0, 0.05),
+                                                              (400, 150, 6, 0.03, 0.1), (200, 40, 2, 0.0, 0.0), (130, 70, 3, 0.0, 1.0)])
+def test_rows_without_alleles_above_one_skip_the_upper_planes(dev, fmh_opts, S, N, max_allele, p_missing, p_multi):
+    """A packed multi-allelic matrix carries a table of the rows that have a bit in plane 1 or 2 (row_hi_kernel); the sweeps read the upper
+    planes of those rows only and run the one-plane core on steps without any.  Same matrix uploaded with the table (default) and without
+    (FMH_ROW_HI=0): every track and every total the same bits, on four- and sixteen-lane rows, two and three planes, with missing calls,
+    on unaligned row ranges; and the dense Hudson tracks against the oracle."""
+    rng = np.random.default_rng(S * 7 + N + max_allele)
+    Hc = 2 * N
+    freq = rng.beta(0.8, 0.8, size=(S, 1))
+    data = (rng.random((S, Hc)) < freq).astype(np.uint8)
+    multi_rows = np.nonzero(rng.random(S) < p_multi)[0]
+    if p_multi > 0 and len(multi_rows) == 0:
+        multi_rows = np.array([S // 2])
+    for r in multi_rows:
+        vals = rng.integers(0, max_allele + 1, size=Hc, dtype=np.uint8)
+        vals[rng.random(Hc) < 0.5] = 0
+        data[r] = vals
+    if len(multi_rows):
+        data[multi_rows[0], 3] = max_allele  # the matrix's max_allele is met
+    missing = None
+    if p_missing > 0:
+        miss = rng.random((S, Hc)) < p_missing
+        data[miss] = 0
+        bits = np.packbits(miss.reshape(-1), bitorder="little")
+        words = np.frombuffer(np.concatenate([bits, np.zeros((-len(bits)) % 8, np.uint8)]).tobytes(), dtype="<u8")
+        missing = [int(w) for w in words]
+    declared = max(int(data.max()), 2)  # (p_multi = 0: a matrix declared multi-allelic whose rows are all biallelic)
+    m = R.DenseGenotypeMatrix(bytes(data.reshape(-1)), missing, S, N, 2, declared)
+    with_table = upload(dev, m)
+    fmh_opts.setenv("FMH_ROW_HI", "0")
+    without = upload(dev, m)
+    fmh_opts.delenv("FMH_ROW_HI")
+    third = N // 3
+    lists2 = [H.haps_for_samples(range(0, N // 2)), H.haps_for_samples(range(N // 2, N - 1))]
+    lists3 = [H.haps_for_samples(range(i * third, (i + 1) * third)) for i in range(3)]
+    results = []
+    for dm in (with_table, without):
+        g2, g3, g1 = dev.Groups.from_haplotype_lists(dm, lists2), dev.Groups.from_haplotype_lists(dm, lists3), dev.Groups.from_haplotype_lists(dm, lists2[:1])
+        out = []
+        for (r0, rows) in ((0, S), (5, S - 9), (S // 2 + 1, 70), (3, 1)):
+            out.append(dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE, r0, rows))
+            out.append(dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE, r0, rows))
+            out.append(dev.wc_sweep(dm, g3, r0, rows))
+            out.append(dev.population_summaries(dm, g3, dev.FORMULA_DENSE, r0, rows))
+            out.append(dev.diversity_sites(dm, g1, r0, rows))
+        results.append(out)
+    for i, (a, b) in enumerate(zip(*results)):
+        _same_result(a, b, f"call {i}")
+    if S * N <= 60_000:  # the oracle's dense Hudson sites on the small shapes
+        off1, off2 = R.dense_membership_offsets(m, lists2[0]), R.dense_membership_offsets(m, lists2[1])
+        exp = R.dense_hudson_sites(m, [R.Variant(7 * i, None) for i in range(S)], off1, off2)
+        hs = results[0][0]
+        H.assert_bits_equal(hs.sites["dxy"], [H.opt(e.d_xy) for e in exp], "dxy vs oracle")
+        H.assert_bits_equal(hs.sites["fst"], [H.opt(e.fst) for e in exp], "fst vs oracle")
 
 
 def test_mask_routes_agree(dev, fmh_opts):

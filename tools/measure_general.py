@@ -41,7 +41,7 @@ def main():
         data = rng.integers(0, 2, size=(S, H), dtype=np.uint8)
         if max_allele > 1:
             extra = rng.integers(0, max_allele + 1, size=(S, H), dtype=np.uint8)
-            pick = rng.random((S, 1)) < 0.5      # half of the sites are multi-allelic
+            pick = rng.random((S, 1)) < float(os.environ.get("MEASURE_MULTI_FRACTION", "0.5"))  # share of multi-allelic sites (default: half)
             data = np.where(pick, extra, data).astype(np.uint8)
         dm = device.DeviceMatrix.from_host(data, None, S, N, 2, int(data.max()))
         timed_hudson(dm, device.Groups(dm, masks), S, f"hudson max_allele={max_allele}", H + 56)
