@@ -408,7 +408,10 @@ static void free_planes(fmh_matrix* m) {
 // after the planes of a multi-allelic matrix have been written: which rows have a bit above plane 0 (row_hi_kernel).  FMH_ROW_HI=0: no table,
 // the sweeps read every plane of every row as before round 4.
 static int mark_upper_plane_rows(fmh_matrix* m) {
-  if (!m->p1 || m->variants == 0 || options().row_hi.load() == 0) return FMH_OK;
+  // (a matrix of a few thousand rows is swept in one launch-bound round either way: no table, no extra launch and synchronisation per
+  // small region of run_vcf; FMH_ROW_HI=2 builds it for any size - tests)
+  const long long mode = options().row_hi.load();
+  if (!m->p1 || m->variants == 0 || mode == 0 || (mode != 2 && m->variants < 4096)) return FMH_OK;
   if (!m->row_hi) {
     const hipError_t e = pool_malloc(m->device, (void**)&m->row_hi, m->variants);
     if (e != hipSuccess) { m->row_hi = nullptr; return FMH_OK; }  // no table: every row is read in full

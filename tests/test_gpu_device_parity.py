@@ -460,7 +460,8 @@ def _same_result(a, b, what):
 
 
 @pytest.mark.parametrize("S,N,max_allele,p_missing,p_multi", [(700, 60, 2, 0.0, 0.03), (450, 2100, 3, 0.02, 0.02), (260, 2100, 5, 0.0, 0.05),
-                                                              (400, 150, 6, 0.03, 0.1), (200, 40, 2, 0.0, 0.0), (130, 70, 3, 0.0, 1.0)])
+                                                              (400, 150, 6, 0.03, 0.1), (200, 40, 2, 0.0, 0.0), (130, 70, 3, 0.0, 1.0),
+                                                              (5000, 30, 2, 0.0, 0.01)])  # the last one: above the default size threshold
 def test_rows_without_alleles_above_one_skip_the_upper_planes(dev, fmh_opts, S, N, max_allele, p_missing, p_multi):
     """A packed multi-allelic matrix carries a table of the rows that have a bit in plane 1 or 2 (row_hi_kernel); the sweeps read the upper
     planes of those rows only and run the one-plane core on steps without any.  Same matrix uploaded with the table (default) and without
@@ -488,10 +489,12 @@ def test_rows_without_alleles_above_one_skip_the_upper_planes(dev, fmh_opts, S, 
         missing = [int(w) for w in words]
     declared = max(int(data.max()), 2)  # (p_multi = 0: a matrix declared multi-allelic whose rows are all biallelic)
     m = R.DenseGenotypeMatrix(bytes(data.reshape(-1)), missing, S, N, 2, declared)
+    fmh_opts.setenv("FMH_ROW_HI", "2")  # the table at any size (by default matrices below 4 096 rows go without)
     with_table = upload(dev, m)
     fmh_opts.setenv("FMH_ROW_HI", "0")
     without = upload(dev, m)
     fmh_opts.delenv("FMH_ROW_HI")
+    by_default = upload(dev, m) if S >= 4096 else None
     third = N // 3
     lists2 = [H.haps_for_samples(range(0, N // 2)), H.haps_for_samples(range(N // 2, N - 1))]
     lists3 = [H.haps_for_samples(range(i * third, (i + 1) * third)) for i in range(3)]
@@ -499,7 +502,7 @@ def test_rows_without_alleles_above_one_skip_the_upper_planes(dev, fmh_opts, S, 
     for dm in (with_table, without):
         g2, g3, g1 = dev.Groups.from_haplotype_lists(dm, lists2), dev.Groups.from_haplotype_lists(dm, lists3), dev.Groups.from_haplotype_lists(dm, lists2[:1])
         out = []
-        for (r0, rows) in ((0, S), (5, S - 9), (S // 2 + 1, 70), (3, 1)):
+        for (r0, rows) in ((0, S), (5, S - 9), (S // 2 + 1, min(70, S - S // 2 - 1)), (3, 1)):
             out.append(dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE, r0, rows))
             out.append(dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE, r0, rows))
             out.append(dev.wc_sweep(dm, g3, r0, rows))
@@ -508,6 +511,9 @@ def test_rows_without_alleles_above_one_skip_the_upper_planes(dev, fmh_opts, S, 
         results.append(out)
     for i, (a, b) in enumerate(zip(*results)):
         _same_result(a, b, f"call {i}")
+    if by_default is not None:
+        g2 = dev.Groups.from_haplotype_lists(by_default, lists2)
+        _same_result(dev.hudson_sweep(by_default, g2, dev.FORMULA_DENSE, 0, S), results[1][0], "default options")
     if S * N <= 60_000:  # the oracle's dense Hudson sites on the small shapes
         off1, off2 = R.dense_membership_offsets(m, lists2[0]), R.dense_membership_offsets(m, lists2[1])
         exp = R.dense_hudson_sites(m, [R.Variant(7 * i, None) for i in range(S)], off1, off2)

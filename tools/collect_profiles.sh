@@ -90,6 +90,7 @@ python3 $R/tools/summarize_rocprof.py pmc $O/cfg_pmc1 $O/c2_c3_c4_pmc_issue_wait
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_LDS_BANK_CONFLICT --output-format csv -d $O/cfg_pmc2 -o p -- python3 $R/tools/measure_configs.py C2 C3 C3h C4 C4f > /dev/null 2> $O/cfg_pmc2.log
 python3 $R/tools/summarize_rocprof.py pmc $O/cfg_pmc2 $O/c2_c3_c4_pmc_inst_mix_summary.csv
 step "multi-allelic paths"; python3 $R/tools/measure_general.py 2>/dev/null | grep '^{' | grep hudson > $O/general_path.jsonl
+for hi in 1 0; do for f in 0.02 0.002; do FMH_ROW_HI=$hi MEASURE_MULTI_FRACTION=$f python3 $R/tools/measure_general.py 2>/dev/null | grep hudson | sed "s/^{/{\"FMH_ROW_HI\": $hi, \"multi_fraction\": $f, /" >> $O/general_path_mostly_biallelic.jsonl; done; done
 MEASURE_ALLELE7=1 python3 $R/tools/measure_wc_general.py 2>/dev/null | grep '^{' > $O/wc_general_5_8_groups.jsonl
 python3 $R/tools/measure_wc_groups.py 2 4 5 8 12 26 2>/dev/null | grep '^{' > $O/wc_groups.jsonl
 step "pairwise"; python3 $R/tools/measure_pairwise.py 1000000x2500 200000x500 2>/dev/null | grep '^{' > $O/pairwise.jsonl
