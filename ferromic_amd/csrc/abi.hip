@@ -402,25 +402,31 @@ static int alloc_planes(fmh_matrix* m) {
 static void free_planes(fmh_matrix* m) {
   pool_free(m->device, m->p0); pool_free(m->device, m->p1); pool_free(m->device, m->p2); pool_free(m->device, m->pc);
   pool_free(m->device, m->row_hi);
+  pool_free(m->device, m->row_gap);
   m->p0 = m->p1 = m->p2 = m->pc = nullptr;
-  m->row_hi = nullptr;
+  m->row_hi = m->row_gap = nullptr;
 }
-// after the planes of a multi-allelic matrix have been written: which rows have a bit above plane 0 (row_hi_kernel).  FMH_ROW_HI=0: no table,
-// the sweeps read every plane of every row as before round 4.
+// after the planes of a matrix have been written: which rows have a bit above plane 0 (row_hi_kernel) and which have an uncalled column
+// (row_gap_kernel) - the sweeps read the upper / called planes of those rows only.  FMH_ROW_HI=0: no tables, every plane of every row is read
+// as before round 4.  (A matrix of a few thousand rows is swept in one launch-bound round either way: no tables, no extra launches and
+// synchronisation per small region of run_vcf; FMH_ROW_HI=2 builds them for any size - tests.)
 static int mark_upper_plane_rows(fmh_matrix* m) {
-  // (a matrix of a few thousand rows is swept in one launch-bound round either way: no table, no extra launch and synchronisation per
-  // small region of run_vcf; FMH_ROW_HI=2 builds it for any size - tests)
   const long long mode = options().row_hi.load();
-  if (!m->p1 || m->variants == 0 || mode == 0 || (mode != 2 && m->variants < 4096)) return FMH_OK;
-  if (!m->row_hi) {
-    const hipError_t e = pool_malloc(m->device, (void**)&m->row_hi, m->variants);
-    if (e != hipSuccess) { m->row_hi = nullptr; return FMH_OK; }  // no table: every row is read in full
-  }
+  if ((!m->p1 && !m->pc) || m->variants == 0 || mode == 0 || (mode != 2 && m->variants < 4096)) return FMH_OK;
   const int blocks = (int)std::min<size_t>((m->variants * 16 + 255) / 256, 1 << 16);
-  hipLaunchKernelGGL(row_hi_kernel, dim3(blocks), dim3(256), 0, 0, (const uint8_t*)m->p1, (const uint8_t*)m->p2, m->plane_pitch, m->variants, m->row_hi);
-  hipError_t e = hipGetLastError();
+  hipError_t e = hipSuccess;
+  if (m->p1) {
+    if (!m->row_hi && pool_malloc(m->device, (void**)&m->row_hi, m->variants) != hipSuccess) m->row_hi = nullptr;  // no table: every row is read in full
+    if (m->row_hi) hipLaunchKernelGGL(row_hi_kernel, dim3(blocks), dim3(256), 0, 0, (const uint8_t*)m->p1, (const uint8_t*)m->p2, m->plane_pitch, m->variants, m->row_hi);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && m->pc) {
+    if (!m->row_gap && pool_malloc(m->device, (void**)&m->row_gap, m->variants) != hipSuccess) m->row_gap = nullptr;
+    if (m->row_gap) hipLaunchKernelGGL(row_gap_kernel, dim3(blocks), dim3(256), 0, 0, (const uint8_t*)m->pc, m->plane_pitch, m->variants, m->columns, m->row_gap);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(0);
-  if (e != hipSuccess) return fail(FMH_ERR_HIP, "marking the rows with alleles above 1 failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(FMH_ERR_HIP, "marking the rows with alleles above 1 / uncalled columns failed: %s", hipGetErrorString(e));
   return FMH_OK;
 }
 // byte rows (and, when `bits` is given, their called rows) -> planes rows [row0, row0 + rows)
@@ -939,6 +945,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.mv.data2 = m->p2;
     a.mv.bits = m->pc;
     a.mv.row_hi = m->row_hi;
+    a.mv.row_gap = m->row_gap;
     a.mv.pitch = m->plane_pitch;
     a.mv.bits_pitch = m->plane_pitch;
     a.mv.nvec = m->pvec;
@@ -949,6 +956,7 @@ int fmhi::enqueue_sweep(const fmh_matrix* m, const fmh_groups* g, int mode, Swee
     a.mv.data2 = nullptr;
     a.mv.bits = m->bits;
     a.mv.row_hi = nullptr;
+    a.mv.row_gap = nullptr;
     a.mv.pitch = m->pitch;
     a.mv.bits_pitch = m->bits_pitch;
     a.mv.nvec = m->nvec;

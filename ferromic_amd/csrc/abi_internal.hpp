@@ -75,7 +75,7 @@ struct Options {
   std::atomic<long long> wc_bi_totals{1};        // FMH_WC_BI_TOTALS: 0 = more than eight groups' regional sums through the general pair kernel again (A/B of the biallelic one)
   std::atomic<long long> wc_bi_replicas{0};      // FMH_WC_BI_REPLICAS: 1 | 2 | 4 | 8 threads per pair in the biallelic pair kernel; 0 = by the lanes the last wave would waste
   std::atomic<long long> wc_bi_chunks{0};        // FMH_WC_BI_CHUNKS: row chunks of the biallelic pair kernel (measurement); 0 = about 8 192 workgroups
-  std::atomic<long long> row_hi{1};              // FMH_ROW_HI: 0 = packed multi-allelic matrices get no table of the rows with alleles above 1 (every plane of every row is read)
+  std::atomic<long long> row_hi{1};              // FMH_ROW_HI: 0 = packed matrices get no tables of the rows with alleles above 1 / with uncalled columns (every plane of every row is read); 2 = tables at any size
   std::atomic<long long> graph{0};               // FMH_GRAPH: 1 = replay a repeated pipelined sweep on a local communicator from a captured hipGraph
   std::atomic<unsigned long long> generation{0}; // bumped by every fmh_set_option: a captured launch is never replayed across an option change
 };
@@ -219,6 +219,7 @@ struct fmh_matrix {
   // pc = called bits; plane_pitch bytes per row, pvec = ceil(columns / 128) 16-byte vectors.  data / bits may have been
   // released (nullptr).
   uint8_t *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *pc = nullptr;
+  uint8_t* row_gap = nullptr; // with pc: one byte per row, non-zero when some column of the row is not called (written wherever the planes are)
   uint8_t* row_hi = nullptr;  // with p1: one byte per row, non-zero when the row has a bit in plane 1 or 2 (written wherever the planes are)
   size_t plane_pitch = 0;
   uint32_t pvec = 0;

@@ -45,6 +45,7 @@ struct MatrixView {
   const uint8_t* data1;  // packed layout with alleles 2..7: bit plane 1 ((allele >> 1) & 1); else null
   const uint8_t* data2;  // packed layout with alleles 4..7: bit plane 2 (allele >> 2); else null
   const uint8_t* bits;  // called bits, may be null
+  const uint8_t* row_gap; // packed layout with a called plane: one byte per row, non-zero when some column of that row is not called; may be null (= every row may)
   const uint8_t* row_hi;  // packed layout with alleles 2..7: one byte per row, non-zero when a plane above plane 0 has a bit set in that row; may be null (= every row may)
   size_t pitch;
   size_t bits_pitch;
@@ -680,7 +681,8 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
       // (a null upper plane: the row carries no allele above 1 - MatrixView::row_hi - and its upper planes are not read)
       if constexpr (NPL >= 2) x[1][u] = row1 ? load_stream(row1 + (size_t)vc * 16) : make_uint4(0, 0, 0, 0);
       if constexpr (NPL >= 3) x[2][u] = row2 ? load_stream(row2 + (size_t)vc * 16) : make_uint4(0, 0, 0, 0);
-      if (MISSING) cb[u] = load_stream(called_ptr + (size_t)vc * 16);
+      // (a null called plane on a MISSING core: every column of the row is called - MatrixView::row_gap - all ones; the masks are zero beyond the row)
+      if (MISSING) cb[u] = called_ptr ? load_stream(called_ptr + (size_t)vc * 16) : make_uint4(~0u, ~0u, ~0u, ~0u);
     }
   };
   auto count_trip = [&](uint32_t v0, const uint4 (&x)[NPL][U], const uint4 (&cb)[U]) {
@@ -749,7 +751,7 @@ __device__ __forceinline__ void count_row_packed(const MatrixView& mv, const uin
 #pragma unroll
     for (int k = 0; k < NS; ++k) s[p][k] = group_sum<LPR>(s[p][k]);
   }
-  if (MISSING && NEED_ALL) n_all = group_sum<LPR>(n_all);
+  if (MISSING && NEED_ALL) n_all = called_ptr ? group_sum<LPR>(n_all) : mv.columns;  // (all ones would count the padding of the last vector)
   if (NPL >= 2) allele_or = group_or<LPR>(allele_or);
 }
 
@@ -1391,6 +1393,11 @@ constexpr int sweep_min_blocks() {
     // (two groups on four-lane rows, 131-135 VGPRs: the diversity and W&C kernels spill two registers at 128, and one and two groups take the
     // pipelined kernel there anyway)
   }
+  // (the complete-row fast path of the kernels with a called plane - row_gap - added ten registers: these three crossed the step at 128)
+  if (FMH_OCC_STEPS && MM == 3 && !GENERAL && MISSING && NPL == 2 && P == 2) {
+    if (LPR == 4 && (MODE == (kModeSummary | kModeHudson) || MODE == (kModeSummary | kModeHudson | kModeDiversity))) return 4;  // 129
+    if (LPR == 16 && MODE == kModeWc) return 4;                                                                                 // 130
+  }
   return (MM == 3 /* kMaskPacked */ && P >= 5 && (MODE & kModeWc) != 0 && NPL == 2) ? 2 : 1;
 }
 
@@ -1516,13 +1523,48 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
               counted = true;
             }
           }
+          // rows every column of which is called do not read their called plane (MatrixView::row_gap); a step of such rows runs the
+          // no-missing core and takes the group sizes as its called counts - the values the popcounts would give
+          unsigned long long gap_mask = ~0ull;
+          if constexpr (MISSING && MM == kMaskPacked) {
+            if (mv.row_gap) {
+              const size_t r = tile_row0 + (size_t)lane;
+              const uint8_t f = r < A.row_count ? mv.row_gap[A.row_begin + r] : (uint8_t)0;
+              gap_mask = __ballot(f != 0);
+            }
+          }
           if (!counted) {
             for (int s = 0; s < LPR; ++s) {
               const size_t rel = tile_row0 + (size_t)grp * LPR + s;
               const size_t row = A.row_begin + (rel < A.row_count ? rel : A.row_count - 1);
               const uint8_t* row_ptr = mv.data + row * mv.pitch;
-              const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
+              constexpr unsigned long long kStepRowsD = LPR == 16 ? 0x0001000100010001ull : (LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull);
+              const bool step_gap = (gap_mask & (kStepRowsD << s)) != 0;           // wave-uniform
+              const bool my_gap = ((gap_mask >> (grp * LPR + s)) & 1ull) != 0;     // this lane group's row
+              const uint8_t* bits_ptr = MISSING && my_gap ? mv.bits + row * mv.bits_pitch : nullptr;
               uint32_t n[P], n_all, aor, sp[P][1];
+              bool counted_full = false;
+              if constexpr (MISSING && MM == kMaskPacked) {
+                if (!step_gap) {
+#define FMH_COUNT_FULL(UV) count_row_packed<P, false, false, 1, UV, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp)
+                  if constexpr (LPR != 16) {
+                    if (A.unroll == 5) FMH_COUNT_FULL(5);
+                    else if (A.unroll == 3) FMH_COUNT_FULL(3);
+                    else if (A.unroll == 2) FMH_COUNT_FULL(2);
+                    else FMH_COUNT_FULL(1);
+                  } else {
+                    if (A.unroll == 4) FMH_COUNT_FULL(4);
+                    else if (A.unroll == 3) FMH_COUNT_FULL(3);
+                    else FMH_COUNT_FULL(2);
+                  }
+#undef FMH_COUNT_FULL
+#pragma unroll
+                  for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
+                  n_all = mv.columns;
+                  counted_full = true;
+                }
+              }
+              if (!counted_full) {
 #define FMH_COUNT_DEFER(UV) count_row_packed<P, MISSING, NEED_ALL, 1, UV, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, bits_ptr, gl, n, n_all, aor, sp)
               if constexpr (MM != kMaskPacked) {  // u8 rows: the dot4 core
                 uint32_t alt[P];
@@ -1540,6 +1582,7 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
                 else if (A.unroll == 3) FMH_COUNT_DEFER(3);
                 else FMH_COUNT_DEFER(2);
               }
+              }  // !counted_full
 #undef FMH_COUNT_DEFER
               if (gl == s) {
 #pragma unroll
@@ -1651,12 +1694,22 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
         hi_mask = __ballot(f != 0);
       }
     }
+    // the same for the called plane: rows every column of which is called (MatrixView::row_gap) do not read it
+    unsigned long long gap_mask = ~0ull;
+    if constexpr (MISSING && MM == kMaskPacked) {
+      if (mv.row_gap) {
+        const size_t r = tile_row0 + (size_t)lane;
+        const uint8_t f = r < A.row_count ? mv.row_gap[A.row_begin + r] : (uint8_t)0;
+        gap_mask = __ballot(f != 0);
+      }
+    }
     for (int s = 0; s < LPR && !rows_done; ++s) {
       const size_t rel = tile_row0 + (size_t)grp * LPR + s;
       const bool row_ok = rel < A.row_count;
       const size_t row = A.row_begin + (row_ok ? rel : A.row_count - 1);  // rows past the end are clamped to the last row (their results are discarded by row_ok)
       const uint8_t* row_ptr = mv.data + row * mv.pitch;
-      const uint8_t* bits_ptr = MISSING ? mv.bits + row * mv.bits_pitch : nullptr;
+      const bool my_gap = ((gap_mask >> (grp * LPR + s)) & 1ull) != 0;
+      const uint8_t* bits_ptr = MISSING && my_gap ? mv.bits + row * mv.bits_pitch : nullptr;
       const bool own = gl == s;
       uint32_t n[P], n_all, aor, sp[P][NS];
       if constexpr (MM == kMaskPacked) {
@@ -1668,6 +1721,28 @@ __global__ __launch_bounds__(kBlock, (sweep_min_blocks<P, MODE, GENERAL, MM, NPL
         const uint8_t* row_ptr2 = NPLK >= 3 && row_hi ? mv.data2 + row * mv.pitch : nullptr;
         constexpr bool NA_ALL = GENERAL || NEED_ALL;
         bool counted_low = false;
+        if constexpr (MISSING && !GENERAL) {
+          if ((gap_mask & (kStepRows << s)) == 0) {  // no row of this step has an uncalled column: the no-missing core, called counts = group sizes
+#define FMH_COUNT_FULL(UV) count_row_packed<P, false, false, 1, UV, LPR>(mv, lm, nvec_pad, row_ptr, nullptr, nullptr, nullptr, gl, n, n_all, aor, sp, P == 8 ? A.n_groups : P)
+            if constexpr (LPR != 16) {
+              if constexpr (kShallow) { if (A.unroll == 2) FMH_COUNT_FULL(2); else FMH_COUNT_FULL(1); }
+              else if (A.unroll == 5) FMH_COUNT_FULL(5);
+              else if (A.unroll == 3) FMH_COUNT_FULL(3);
+              else if (A.unroll == 2) FMH_COUNT_FULL(2);
+              else FMH_COUNT_FULL(1);
+            } else {
+              if constexpr (kShallow) FMH_COUNT_FULL(2);
+              else if (A.unroll == 4) FMH_COUNT_FULL(4);
+              else if (A.unroll == 3) FMH_COUNT_FULL(3);
+              else FMH_COUNT_FULL(2);
+            }
+#undef FMH_COUNT_FULL
+#pragma unroll
+            for (int p = 0; p < P; ++p) n[p] = A.group_size[p];
+            n_all = mv.columns;
+            counted_low = true;
+          }
+        }
         if constexpr (GENERAL && NPLK >= 2) {
           if (!step_hi) {  // the one-plane core; allele 1 may be present (aor = 1: an allele a site does not carry adds exact zeros)
             uint32_t low[P][1], aor_low;

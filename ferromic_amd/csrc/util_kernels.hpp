@@ -176,6 +176,24 @@ __global__ void pack_rows_kernel(const uint8_t* __restrict__ data, size_t pitch,
   if (overflow && overflow_flag) atomicOr(overflow_flag, 1u);
 }
 
+// row_gap[r] = 1 when some column of row r of a packed matrix with a called plane is NOT called (the plane's bits beyond the row are zero, so:
+// fewer set bits than columns), else 0: the sweeps read the called plane of those rows only (MatrixView::row_gap).
+__global__ __launch_bounds__(256) void row_gap_kernel(const uint8_t* __restrict__ pc, size_t plane_pitch, size_t rows, uint32_t columns,
+                                                      uint8_t* __restrict__ row_gap) {
+  const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / 16, groups = (size_t)gridDim.x * blockDim.x / 16;
+  const uint32_t gl = threadIdx.x % 16, nvec = (uint32_t)(plane_pitch / 16);
+  for (size_t r = group; r < rows; r += groups) {
+    uint32_t called = 0;
+    for (uint32_t v = gl; v < nvec; v += 16) {
+      const uint4 a = *reinterpret_cast<const uint4*>(pc + r * plane_pitch + (size_t)v * 16);
+      called += __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w);
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) called += __shfl_xor(called, off, 64);
+    if (gl == 0) row_gap[r] = called != columns ? 1 : 0;
+  }
+}
+
 // row_hi[r] = 1 when row r of a packed multi-allelic matrix has a bit in plane 1 or plane 2 (a called allele above 1), else 0: the sweeps
 // read the upper planes of those rows only (MatrixView::row_hi).  Sixteen lanes per row, as many 16-byte vectors each as the row needs.
 __global__ __launch_bounds__(256) void row_hi_kernel(const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2, size_t plane_pitch, size_t rows,

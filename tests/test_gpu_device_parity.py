@@ -522,6 +522,65 @@ def test_rows_without_alleles_above_one_skip_the_upper_planes(dev, fmh_opts, S, 
         H.assert_bits_equal(hs.sites["fst"], [H.opt(e.fst) for e in exp], "fst vs oracle")
 
 
+@pytest.mark.parametrize("S,N,p_gap_rows,max_allele", [(900, 60, 0.03, 1), (700, 2100, 0.02, 1), (300, 45, 0.0, 1), (260, 50, 1.0, 1), (5000, 40, 0.01, 1),
+                                                        (600, 80, 0.05, 3), (400, 2100, 0.04, 2)])
+def test_rows_without_uncalled_columns_skip_the_called_plane(dev, fmh_opts, S, N, p_gap_rows, max_allele):
+    """A packed matrix with a called plane carries a table of the rows that have an uncalled column (row_gap_kernel); the sweeps read the
+    called plane of those rows only, and a counting step of complete rows runs the no-missing core with the group sizes as called counts.
+    Same matrix uploaded with the table and without: every track and every total the same bits (deferring two-group kernels, four- and
+    sixteen-lane rows, biallelic and multi-allelic, unaligned row ranges); dense Hudson tracks against the oracle on the small shapes."""
+    rng = np.random.default_rng(S * 3 + N)
+    Hc = 2 * N
+    freq = rng.beta(0.8, 0.8, size=(S, 1))
+    data = (rng.random((S, Hc)) < freq).astype(np.uint8)
+    if max_allele > 1:
+        for r in np.nonzero(rng.random(S) < 0.05)[0]:
+            data[r] = np.where(rng.random(Hc) < 0.5, 0, rng.integers(0, max_allele + 1, size=Hc)).astype(np.uint8)
+        data[S // 3, 1] = max_allele
+    miss = np.zeros((S, Hc), dtype=bool)
+    gap_rows = np.nonzero(rng.random(S) < p_gap_rows)[0]
+    if p_gap_rows > 0 and len(gap_rows) == 0:
+        gap_rows = np.array([S // 2])
+    for r in gap_rows:
+        miss[r] = rng.random(Hc) < (0.5 if r % 7 == 0 else 0.03)
+        miss[r, int(rng.integers(0, Hc))] = True
+    data[miss] = 0
+    bits = np.packbits(miss.reshape(-1), bitorder="little")
+    words = np.frombuffer(np.concatenate([bits, np.zeros((-len(bits)) % 8, np.uint8)]).tobytes(), dtype="<u8")
+    m = R.DenseGenotypeMatrix(bytes(data.reshape(-1)), [int(w) for w in words], S, N, 2, max(int(data.max()), max_allele))
+    fmh_opts.setenv("FMH_ROW_HI", "2")
+    with_table = upload(dev, m)
+    fmh_opts.setenv("FMH_ROW_HI", "0")
+    without = upload(dev, m)
+    fmh_opts.delenv("FMH_ROW_HI")
+    by_default = upload(dev, m) if S >= 4096 else None
+    third = N // 3
+    lists2 = [H.haps_for_samples(range(0, N // 2)), H.haps_for_samples(range(N // 2, N - 1))]
+    lists3 = [H.haps_for_samples(range(i * third, (i + 1) * third)) for i in range(3)]
+    results = []
+    for dm in (with_table, without):
+        g2, g3, g1 = dev.Groups.from_haplotype_lists(dm, lists2), dev.Groups.from_haplotype_lists(dm, lists3), dev.Groups.from_haplotype_lists(dm, lists2[:1])
+        out = []
+        for (r0, rows) in ((0, S), (5, S - 9), (S // 2 + 1, min(70, S - S // 2 - 1)), (3, 1)):
+            out.append(dev.hudson_sweep(dm, g2, dev.FORMULA_DENSE, r0, rows))
+            out.append(dev.hudson_sweep(dm, g2, dev.FORMULA_SPARSE, r0, rows))
+            out.append(dev.wc_sweep(dm, g3, r0, rows))
+            out.append(dev.population_summaries(dm, g3, dev.FORMULA_DENSE, r0, rows))
+            out.append(dev.diversity_sites(dm, g1, r0, rows))
+        results.append(out)
+    for i, (a, b) in enumerate(zip(*results)):
+        _same_result(a, b, f"call {i}")
+    if by_default is not None:
+        g2 = dev.Groups.from_haplotype_lists(by_default, lists2)
+        _same_result(dev.hudson_sweep(by_default, g2, dev.FORMULA_DENSE, 0, S), results[1][0], "default options")
+    if S * N <= 60_000:
+        off1, off2 = R.dense_membership_offsets(m, lists2[0]), R.dense_membership_offsets(m, lists2[1])
+        exp = R.dense_hudson_sites(m, [R.Variant(7 * i, None) for i in range(S)], off1, off2)
+        hs = results[0][0]
+        H.assert_bits_equal(hs.sites["dxy"], [H.opt(e.d_xy) for e in exp], "dxy vs oracle")
+        H.assert_bits_equal(hs.sites["fst"], [H.opt(e.fst) for e in exp], "fst vs oracle")
+
+
 def test_mask_routes_agree(dev, fmh_opts):
     """The sweep keeps the group masks as bytes in LDS, as bits in LDS (rows too wide for bytes) or as bytes in global
     memory (rows too wide for bits); FMH_MASK_MODE forces the slower routes on rows that do not need them.  All three

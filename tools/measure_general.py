@@ -46,6 +46,21 @@ def main():
         dm = device.DeviceMatrix.from_host(data, None, S, N, 2, int(data.max()))
         timed_hudson(dm, device.Groups(dm, masks), S, f"hudson max_allele={max_allele}", H + 56)
         dm.close()
+    # biallelic with missing calls concentrated in a share of the rows (MEASURE_GAP_FRACTION, default: every row): the called plane is read
+    # for those rows only (MatrixView::row_gap)
+    gap = float(os.environ.get("MEASURE_GAP_FRACTION", "1.0"))
+    data = rng.integers(0, 2, size=(S, H), dtype=np.uint8)
+    miss = np.zeros((S, H), dtype=bool)
+    rows = np.nonzero(rng.random(S) < gap)[0]
+    miss[rows] = rng.random((len(rows), H)) < 0.01
+    data[miss] = 0
+    bits = np.packbits(miss.reshape(-1), bitorder="little")
+    words = np.frombuffer(np.concatenate([bits, np.zeros((-len(bits)) % 8, np.uint8)]).tobytes(), dtype="<u8").copy()
+    dm = device.DeviceMatrix.from_host(data, words, S, N, 2, 1)
+    timed_hudson(dm, device.Groups(dm, masks), S, f"hudson biallelic, 1 % missing in {gap:g} of the rows", H + H // 8 + 56)
+    dm.close()
+    if os.environ.get("MEASURE_SKIP_PAIRWISE"):
+        return
     # pairwise differences, C2 shape scaled: 1000 haplotypes (500 samples)
     for S2, N2 in ((200_000, 500), (50_000, 2500), (1_000_000, 2500)):
         data = rng.integers(0, 2, size=(S2, 2 * N2), dtype=np.uint8)
